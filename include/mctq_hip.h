@@ -1,0 +1,98 @@
+/*
+ * mctq_hip.h -- C ABI of libmctq_hip.so, the MI355X (gfx950) implementation of the
+ * sony/mct_quantizers PyTorch inferable-quantizer hot path.
+ *
+ * Every entry point replaces one tensor-runtime call site of the reference
+ * (paths relative to /root/reference/mct_quantizers/):
+ *
+ *   mctq_fq_per_tensor_f32    torch.fake_quantize_per_tensor_affine at
+ *                             pytorch/quantizers/weights_inferable_quantizers/weights_symmetric_inferable_quantizer.py:147
+ *                             .../weights_uniform_inferable_quantizer.py:161
+ *                             pytorch/quantizers/activation_inferable_quantizers/activation_symmetric_inferable_quantizer.py:113
+ *                             .../activation_uniform_inferable_quantizer.py:124
+ *   mctq_fq_per_channel_f32   torch.fake_quantize_per_channel_affine at
+ *                             .../weights_symmetric_inferable_quantizer.py:139, .../weights_uniform_inferable_quantizer.py:153
+ *   mctq_lut_per_tensor_f32   lut_quantizer (pytorch/quantizer_utils.py:95-139) with a scalar threshold, called from
+ *                             .../activation_lut_pot_inferable_quantizer.py:86 and
+ *                             .../weights_lut_symmetric_inferable_quantizer.py:114 (per_channel=False)
+ *   mctq_lut_per_channel_f32  lut_quantizer with a per-channel threshold, .../weights_lut_symmetric_inferable_quantizer.py:114
+ *
+ * Conventions
+ *   - x, y, scales, zero_points, thresholds and lut are DEVICE pointers owned by the caller
+ *     (torch's caching allocator); the library never allocates, frees, copies or synchronises.
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ *     the call returns immediately; it is legal inside hipGraph stream capture.
+ *   - A tensor is addressed in its dense storage order as [outer][channels][inner], float32.
+ *     The channel of linear element i is (i / inner) % channels.
+ *   - Return value: 0 on success, a negative hipError_t on a HIP failure, MCTQ_E_ARG (-10001)
+ *     on an invalid argument.  mctq_last_error() gives the message for the calling thread.
+ *   - Arithmetic contract (bit exact with the reference on finite inputs, |x/scale| < 2^31):
+ *       affine: inv = 1.0f/scale (correctly rounded); q = clamp(rint(x*inv) + zp, qmin, qmax);
+ *               y = (q - zp) * scale           rint = round-half-to-even
+ *       lut   : t = clamp((x / thr_div) * mult, clip_min, clip_max)  (true IEEE division, NaN kept);
+ *               j = first index minimising fl32(|t - lut[j]|); y = (lut[j] / mult) * thr_mul
+ *     Outside that domain the kernels saturate: +inf -> qmax, -inf and NaN -> qmin.
+ */
+#ifndef MCTQ_HIP_H
+#define MCTQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCTQ_ABI_VERSION 1
+#define MCTQ_E_ARG (-10001)
+
+/* ABI version of the loaded library (== MCTQ_ABI_VERSION it was built with). */
+int mctq_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* mctq_last_error(void);
+
+/* y[i] = (clamp(rint(x[i] * (1/scale)) + zero_point, quant_min, quant_max) - zero_point) * scale, i < n. */
+int mctq_fq_per_tensor_f32(const float* x, float* y, int64_t n,
+                           float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,
+                           void* stream);
+
+/* Same, with scale/zero point taken per channel: scales[channels] float32, zero_points[channels] int32. */
+int mctq_fq_per_channel_f32(const float* x, float* y,
+                            int64_t outer, int64_t channels, int64_t inner,
+                            const float* scales, const int32_t* zero_points,
+                            int32_t quant_min, int32_t quant_max,
+                            void* stream);
+
+/*
+ * LUT (codebook) quantizer with one threshold for the whole tensor.
+ *   thr_div : float32(threshold + eps), the divisor of quantizer_utils.py:169
+ *   thr_mul : float32(threshold), the final multiplier of quantizer_utils.py:137
+ *   lut     : device float32[n_lut] codebook in the caller's list order (1 <= n_lut <= 4096)
+ *   mult    : 2^(lut_values_bitwidth - signed); clip_min/clip_max: the clamp range of :162-167
+ */
+int mctq_lut_per_tensor_f32(const float* x, float* y, int64_t n,
+                            float thr_div, float thr_mul,
+                            const float* lut, int32_t n_lut,
+                            float mult, float clip_min, float clip_max,
+                            void* stream);
+
+/* LUT quantizer with thresholds[channels] (device float32); the divisor is fl32(thresholds[c] + eps). */
+int mctq_lut_per_channel_f32(const float* x, float* y,
+                             int64_t outer, int64_t channels, int64_t inner,
+                             const float* thresholds, float eps,
+                             const float* lut, int32_t n_lut,
+                             float mult, float clip_min, float clip_max,
+                             void* stream);
+
+/*
+ * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.
+ *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default set in the library)
+ *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
+ * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
+ */
+int mctq_set_tuning(const char* key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCTQ_HIP_H */

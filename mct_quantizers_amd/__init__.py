@@ -1,0 +1,16 @@
+"""mct_quantizers_amd -- MI355X (gfx950) native inferable quantizers with the mct_quantizers API.
+
+Scope: the PyTorch inferable-quantizer hot path of sony/mct_quantizers; the public
+names below are the subset of mct_quantizers/__init__.py:16-34 that belongs to that path.
+"""
+__version__ = "0.1.0"
+
+from mct_quantizers_amd.common import constants
+from mct_quantizers_amd.common.registry import (BaseInferableQuantizer, QuantizationMethod, QuantizationTarget,
+                                               QuantizerID, get_inferable_quantizer_class, mark_quantizer)
+from mct_quantizers_amd.pytorch import quantizers as pytorch_quantizers
+from mct_quantizers_amd.pytorch.containers import (PytorchActivationQuantizationHolder,
+                                                   PytorchFLNActivationQuantizationHolder,
+                                                   PytorchPreservingActivationQuantizationHolder,
+                                                   PytorchQuantizationWrapper)
+from mct_quantizers_amd.pytorch.load_model import pytorch_load_quantized_model

@@ -1,0 +1,51 @@
+"""Build libmctq_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m mct_quantizers_amd.hip.build [--force]
+
+The library is written in-tree (mct_quantizers_amd/lib/) so it travels with the repository
+snapshot to the GPU machine; it is git-ignored.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(PKG)
+SOURCES = [os.path.join(PKG, "csrc", "mctq_kernels.hip")]
+HEADERS = [os.path.join(REPO, "include", "mctq_hip.h")]
+OUT = os.path.join(PKG, "lib", "libmctq_hip.so")
+
+# -ffp-contract=off / no fast-math: the kernels must reproduce IEEE float32 results bit for bit.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found; cannot build libmctq_hip.so")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    tmp = OUT + ".tmp"
+    cmd = [hipcc, *FLAGS, "-I", os.path.join(REPO, "include"), "-o", tmp, *SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

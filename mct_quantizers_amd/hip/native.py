@@ -1,0 +1,100 @@
+"""ctypes binding of libmctq_hip.so (C ABI declared in include/mctq_hip.h).
+
+The handle lives in a module global, never on a quantizer object, so quantizers and the
+modules that hold them stay picklable (torch.save(model) is how MCT ships models,
+reference pytorch/load_model.py:23-34).
+
+There is no fallback: if the shared library is missing or its ABI version does not match,
+every call raises.  Build it with ``python -m mct_quantizers_amd.hip.build`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+ABI_VERSION = 1
+LIB_NAME = "libmctq_hip.so"
+LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
+MCTQ_E_ARG = -10001
+
+_lock = threading.Lock()
+_lib = None
+
+_c_f32p = ctypes.c_void_p     # device pointers travel as integers
+_c_i32p = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/mctq_hip.h
+SIGNATURES = {
+    "mctq_abi_version": (ctypes.c_int, []),
+    "mctq_last_error": (ctypes.c_char_p, []),
+    "mctq_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
+    "mctq_fq_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "mctq_fq_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                               _c_f32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "mctq_lut_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                               _c_f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_float, ctypes.c_void_p]),
+    "mctq_lut_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("MCTQ_HIP_LIB", os.path.join(LIB_DIR, LIB_NAME))
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises NativeLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise NativeLibraryError(
+                f"{path} not found: the HIP kernels are not built. Run `python -m mct_quantizers_amd.hip.build` "
+                f"(needs hipcc, --offload-arch=gfx950). mct_quantizers_amd has no fallback for GPU tensors.")
+        try:
+            handle = ctypes.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise NativeLibraryError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.mctq_abi_version()
+        if got != ABI_VERSION:
+            raise NativeLibraryError(f"{path} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def is_available() -> bool:
+    try:
+        load()
+        return True
+    except NativeLibraryError:
+        return False
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mctq_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def set_tuning(key: str, value: int):
+    check(load().mctq_set_tuning(key.encode(), int(value)), f"mctq_set_tuning({key}={value})")

@@ -1,0 +1,256 @@
+"""Tensor-level entry points of the hot path.
+
+Each function stands where the reference calls the tensor runtime:
+
+* ``fq_per_tensor``  ~ ``torch.fake_quantize_per_tensor_affine``
+  (reference weights_symmetric_inferable_quantizer.py:147, activation_uniform_inferable_quantizer.py:124, ...)
+* ``fq_per_channel`` ~ ``torch.fake_quantize_per_channel_affine`` (weights_symmetric_inferable_quantizer.py:139)
+* ``lut_per_tensor`` / ``lut_per_channel`` ~ ``lut_quantizer`` (pytorch/quantizer_utils.py:95-139)
+
+Routing:
+  * GPU (HIP) float32 tensor  -> the gfx950 kernels through the C ABI, on torch's current stream.
+    No fallback: a missing library raises.
+  * CPU tensor                -> the very ATen ops the reference runs on a CPU tensor
+    (BASELINE config 1, "torch-cpu plumbing"); not a substitute for the GPU path.
+  * fx Proxy / FakeTensor     -> ``torch.ops.mctq_amd.*`` so tracing records one call_function node.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from mct_quantizers_amd.hip import native
+
+_LIBNAME = "mctq_amd"
+
+
+# ------------------------------------------------------------------------------------------
+# layout: view a tensor's storage as [outer][channels][inner]
+# ------------------------------------------------------------------------------------------
+
+def _is_dense(x: torch.Tensor) -> bool:
+    """True if x occupies numel contiguous elements in some dimension order (no gaps, no overlap)."""
+    if x.is_contiguous():
+        return True
+    dims = [(st, sz) for st, sz in zip(x.stride(), x.shape) if sz != 1]
+    dims.sort()
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def _dense_input(x: torch.Tensor) -> torch.Tensor:
+    return x if _is_dense(x) else x.contiguous()
+
+
+def _channel_view(x: torch.Tensor, axis: int) -> Tuple[int, int, int]:
+    """(outer, channels, inner) of a dense tensor in storage order for logical dimension ``axis``."""
+    n = x.numel()
+    c = x.shape[axis]
+    if x.is_contiguous():
+        inner = 1
+        for s in x.shape[axis + 1:]:
+            inner *= s
+    else:
+        inner = x.stride(axis) if c > 1 else 1
+    outer = n // (c * inner) if c * inner else 0
+    return outer, c, inner
+
+
+def _stream(x: torch.Tensor) -> int:
+    return torch._C._cuda_getCurrentRawStream(x.device.index)
+
+
+class _on_device:
+    """Make x's device current for the launch (no-op in the single-device case)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, x):
+        self.idx = x.device.index
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def _require_f32(x: torch.Tensor, what: str):
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"{what}: the gfx950 kernels take float32 tensors, got {x.dtype}")
+
+
+# ------------------------------------------------------------------------------------------
+# GPU launches
+# ------------------------------------------------------------------------------------------
+
+def _hip_fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
+    _require_f32(x, "fq_per_tensor")
+    lib = native.load()
+    x = _dense_input(x)
+    y = torch.empty_like(x)
+    with _on_device(x):
+        rc = lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), scale, zero_point, qmin, qmax,
+                                        _stream(x))
+    if rc:
+        native.check(rc, "mctq_fq_per_tensor_f32")
+    return y
+
+
+def _check_axis(x, n_params: int, axis: int):
+    if not 0 <= axis < x.dim():
+        raise RuntimeError("`axis` must be between 0 and number of dimensions of input")
+    if n_params != x.shape[axis]:
+        raise RuntimeError("dimensions of scale and zero-point are not consistent with input tensor")
+
+
+def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
+    _require_f32(x, "fq_per_channel")
+    _check_axis(x, scales.numel(), axis)
+    if scales.dtype != torch.float32 or zero_points.dtype != torch.int32:
+        raise RuntimeError("scales must be float32 and zero_points int32")
+    lib = native.load()
+    x = _dense_input(x)
+    y = torch.empty_like(x)
+    outer, c, inner = _channel_view(x, axis)
+    scales = scales.contiguous()
+    zero_points = zero_points.contiguous()
+    with _on_device(x):
+        rc = lib.mctq_fq_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, scales.data_ptr(),
+                                         zero_points.data_ptr(), qmin, qmax, _stream(x))
+    if rc:
+        native.check(rc, "mctq_fq_per_channel_f32")
+    return y
+
+
+def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float):
+    _require_f32(x, "lut_per_tensor")
+    lib = native.load()
+    x = _dense_input(x)
+    y = torch.empty_like(x)
+    lut = lut.contiguous()
+    with _on_device(x):
+        rc = lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, thr_mul, lut.data_ptr(),
+                                         lut.numel(), mult, cmin, cmax, _stream(x))
+    if rc:
+        native.check(rc, "mctq_lut_per_tensor_f32")
+    return y
+
+
+def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float):
+    _require_f32(x, "lut_per_channel")
+    _check_axis(x, thresholds.numel(), axis)
+    lib = native.load()
+    x = _dense_input(x)
+    y = torch.empty_like(x)
+    outer, c, inner = _channel_view(x, axis)
+    lut = lut.contiguous()
+    thresholds = thresholds.contiguous()
+    with _on_device(x):
+        rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(), eps,
+                                          lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
+    if rc:
+        native.check(rc, "mctq_lut_per_channel_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# CPU tensors: the ATen ops / op chain the reference itself executes on a CPU tensor
+# ------------------------------------------------------------------------------------------
+
+def _cpu_fq_per_tensor(x, scale, zero_point, qmin, qmax):
+    return torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)
+
+
+def _cpu_fq_per_channel(x, scales, zero_points, axis, qmin, qmax):
+    return torch.fake_quantize_per_channel_affine(x, scales, zero_points, axis, qmin, qmax)
+
+
+def _cpu_lut(x, lut, thr_div, thr_mul, mult, cmin, cmax):
+    # quantizer_utils.py:126-137 on CPU tensors: divide, scale, clip, first-min argmin, gather, rescale
+    t = torch.clip((x / thr_div) * mult, min=cmin, max=cmax).unsqueeze(-1)
+    idx = torch.argmin(torch.abs(t - lut.reshape([1] * (t.dim() - 1) + [-1])), dim=-1)
+    return (lut.flatten()[idx] / mult) * thr_mul
+
+
+def _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax):
+    return _cpu_lut(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+
+
+def _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax):
+    shape = [1] * x.dim()
+    shape[axis] = -1
+    thr = thresholds.reshape(shape)
+    return _cpu_lut(x, lut, thr + eps, thr, mult, cmin, cmax)
+
+
+# ------------------------------------------------------------------------------------------
+# torch.library registration (fx tracing / FakeTensor / torch.compile see one opaque op)
+# ------------------------------------------------------------------------------------------
+
+_lib_def = torch.library.Library(_LIBNAME, "DEF")
+_lib_def.define("fq_per_tensor(Tensor x, float scale, int zero_point, int quant_min, int quant_max) -> Tensor")
+_lib_def.define("fq_per_channel(Tensor x, Tensor scales, Tensor zero_points, int axis, int quant_min, "
+                "int quant_max) -> Tensor")
+_lib_def.define("lut_per_tensor(Tensor x, Tensor lut, float thr_div, float thr_mul, float mult, float clip_min, "
+                "float clip_max) -> Tensor")
+_lib_def.define("lut_per_channel(Tensor x, Tensor lut, Tensor thresholds, float eps, int axis, float mult, "
+                "float clip_min, float clip_max) -> Tensor")
+
+for _name, _gpu, _cpu in (("fq_per_tensor", _hip_fq_per_tensor, _cpu_fq_per_tensor),
+                          ("fq_per_channel", _hip_fq_per_channel, _cpu_fq_per_channel),
+                          ("lut_per_tensor", _hip_lut_per_tensor, _cpu_lut_per_tensor),
+                          ("lut_per_channel", _hip_lut_per_channel, _cpu_lut_per_channel)):
+    _lib_def.impl(_name, _gpu, "CUDA")
+    _lib_def.impl(_name, _cpu, "CPU")
+    _lib_def.impl(_name, (lambda x, *a: torch.empty_like(x)), "Meta")
+
+
+def _is_real(x) -> bool:
+    return type(x) is torch.Tensor or type(x) is torch.nn.Parameter
+
+
+def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
+    if _is_real(x):
+        if x.is_cuda:
+            return _hip_fq_per_tensor(x, scale, zero_point, qmin, qmax)
+        if x.device.type == "cpu":
+            return _cpu_fq_per_tensor(x, scale, zero_point, qmin, qmax)
+    return torch.ops.mctq_amd.fq_per_tensor(x, scale, zero_point, qmin, qmax)
+
+
+def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
+    if _is_real(x):
+        if x.is_cuda:
+            return _hip_fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
+        if x.device.type == "cpu":
+            return _cpu_fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
+    return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
+
+
+def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float):
+    if _is_real(x):
+        if x.is_cuda:
+            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+        if x.device.type == "cpu":
+            return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+    return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+
+
+def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float):
+    if _is_real(x):
+        if x.is_cuda:
+            return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
+        if x.device.type == "cpu":
+            return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
+    return torch.ops.mctq_amd.lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)

@@ -1,0 +1,186 @@
+"""nn.Module containers that CALL the quantizers every forward: the drop-in boundary, caller side.
+
+API-compatible with the reference containers (relative to /root/reference/mct_quantizers/pytorch/):
+  quantize_wrapper.py:29-270                              PytorchQuantizationWrapper
+  activation_quantization_holder.py:23-63                 PytorchActivationQuantizationHolder
+  fln_activation_quantization_holder.py:24-56             PytorchFLNActivationQuantizationHolder
+  preserving_activation_quantization_holder.py:24-56      PytorchPreservingActivationQuantizationHolder
+
+Attribute / parameter names (``layer``, ``weights_quantizers``, ``positional_weight_<i>``,
+``quantized_positional_weight_<i>``, ``activation_holder_quantizer``, ``quantization_bypass``) are kept
+because state dicts and pickles of MCT-exported models refer to them.  No kernels here.
+"""
+import inspect
+from typing import Any, Callable, Dict, List, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from mct_quantizers_amd.common.constants import (ACTIVATION_HOLDER_QUANTIZER, LAYER, POSITIONAL_WEIGHT,
+                                                 QUANTIZED_POSITIONAL_WEIGHT, TRAINING)
+from mct_quantizers_amd.common.registry import BaseInferableQuantizer
+from mct_quantizers_amd.logger import Logger
+
+
+def _takes_training_flag(quantizer) -> bool:
+    return TRAINING in inspect.signature(quantizer.__call__).parameters
+
+
+class PytorchQuantizationWrapper(nn.Module):
+    """Wrap a layer (or a function with constant inputs) and fake-quantize its weights on every forward.
+
+    ``weights_quantizers`` maps a weight attribute name (str) -- or, for functional ops with constant
+    operands, the operand position (int) -- to its quantizer.  ``weight_values`` maps positions to the
+    constant tensors.  ``op_call_args`` / ``op_call_kwargs`` are appended to every call of the wrapped
+    op; ``is_inputs_as_list`` passes the tensors as one list (torch.cat style).
+    """
+
+    def __init__(self,
+                 module: Union[nn.Module, Callable],
+                 weights_quantizers: Dict[Union[int, str], BaseInferableQuantizer],
+                 weight_values: Dict[int, torch.Tensor] = None,
+                 op_call_args: List = None,
+                 op_call_kwargs: Dict[str, Any] = None,
+                 is_inputs_as_list: bool = False):
+        super().__init__()
+        if isinstance(module, nn.Module):
+            self.add_module(LAYER, module)
+        else:
+            setattr(self, LAYER, module)          # plain callable (torch.add, torch.cat, ...)
+
+        self.weights_quantizers = weights_quantizers
+        self.weight_values = dict() if weight_values is None else weight_values
+        for pos, value in self.weight_values.items():
+            if not isinstance(value, torch.Tensor):
+                Logger.error(f'Positional weight at position {pos} should be a torch.Tensor, '
+                             f'but type is {type(value)}.')
+        self.op_call_args = [] if op_call_args is None else op_call_args
+        self.op_call_kwargs = {} if op_call_kwargs is None else op_call_kwargs
+        self.is_inputs_as_list = is_inputs_as_list
+
+        # Either every weight is a named attribute of the layer, or every weight is positional.
+        if len(self.weight_values) == 0:
+            if not all(isinstance(k, str) for k in self.weights_quantizers):
+                Logger.error('"weights_quantizers" keys should be all strings')
+            self.is_str_attr = True
+        else:
+            if not all(isinstance(k, int) for k in self.weight_values):
+                Logger.error('All "weight_values" keys should be integers')
+            if not all(a == b for a, b in zip(weights_quantizers, weight_values)):
+                Logger.error('Mismatch between "weights_quantizers" and "weight_values" keys')
+            self.is_str_attr = False
+
+        self._set_weights_vars(True)
+
+    @property
+    def is_weights_quantization(self) -> bool:
+        return self.num_weights_quantizers > 0
+
+    @property
+    def num_weights_quantizers(self) -> int:
+        return len(self.weights_quantizers)
+
+    def convert_to_inferable_quantizers(self):
+        """Swap trainable quantizers (objects with ``convert2inferable``) for their inferable form."""
+        if not self.is_weights_quantization:
+            return
+        converted = {}
+        for name, quantizer in self.weights_quantizers.items():
+            conv = getattr(quantizer, 'convert2inferable', None)
+            if callable(conv):
+                converted[name] = conv()
+        self.weights_quantizers = converted
+        self._set_weights_vars(False)
+
+    def _set_weights_vars(self, is_training: bool = True):
+        """Move the float weights under the wrapper and record (name, weight, quantizer) triples."""
+        self._weights_vars = []
+        for name, quantizer in self.weights_quantizers.items():
+            if self.is_str_attr:
+                source = self.layer if is_training else self
+                weight = getattr(source, name).detach()
+                delattr(self.layer, name)
+                setattr(self.layer, name, weight)             # plain tensor now, replaced every forward
+                if is_training:
+                    self.register_parameter(name, torch.nn.Parameter(weight, requires_grad=True))
+                weight_var = getattr(self, name)
+            else:
+                weight = self.weight_values[name]
+                self.register_parameter(f'{POSITIONAL_WEIGHT}_{name}', torch.nn.Parameter(weight, requires_grad=False))
+                setattr(self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{name}', weight)
+                weight_var = getattr(self, f'{POSITIONAL_WEIGHT}_{name}')
+            quantizer.initialize_quantization(weight.shape, name, self)
+            self._weights_vars.append((name, weight_var, quantizer))
+
+    def set_quantize_weights(self, quantized_weights: dict):
+        """Install freshly quantized weights where the wrapped op will read them."""
+        for key in self.weights_quantizers:
+            value = quantized_weights.get(key)
+            if self.is_str_attr:
+                setattr(self.layer, key, value)
+            else:
+                setattr(self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{key}', value)
+
+    def get_weights_vars(self) -> List[Tuple[str, Any, BaseInferableQuantizer]]:
+        return self._weights_vars
+
+    def forward(self, *args: List[Any], **kwargs: Dict[str, Any]) -> Union[torch.Tensor, List[torch.Tensor]]:
+        if self.is_weights_quantization:
+            fresh = {}
+            for name, weight, quantizer in self._weights_vars:
+                if _takes_training_flag(quantizer):
+                    fresh[name] = quantizer(weight, self.training)
+                else:
+                    fresh[name] = quantizer(weight)
+            self.set_quantize_weights(fresh)
+
+        if not self.is_str_attr:
+            # constants take their recorded operand positions among the runtime inputs
+            args = list(args)
+            for pos in sorted(w[0] for w in self._weights_vars):
+                args.insert(pos, getattr(self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{pos}'))
+
+        call_kwargs = {**self.op_call_kwargs, **kwargs}
+        if self.is_inputs_as_list:
+            return self.layer(args, *self.op_call_args, **call_kwargs)
+        return self.layer(*args, *self.op_call_args, **call_kwargs)
+
+    def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
+        return {name: quantizer(w) for name, w, quantizer in self.get_weights_vars()}
+
+
+class PytorchActivationQuantizationHolder(torch.nn.Module):
+    """Module that owns one activation quantizer and applies it to whatever flows through."""
+
+    def __init__(self, activation_holder_quantizer: BaseInferableQuantizer, **kwargs):
+        super().__init__(**kwargs)
+        self.activation_holder_quantizer = activation_holder_quantizer
+        self.activation_holder_quantizer.initialize_quantization(None, ACTIVATION_HOLDER_QUANTIZER + "_out", self)
+
+    def forward(self, inputs):
+        return self.activation_holder_quantizer(inputs)
+
+    def convert_to_inferable_quantizers(self):
+        conv = getattr(self.activation_holder_quantizer, 'convert2inferable', None)
+        if callable(conv):  # pragma: no cover
+            self.activation_holder_quantizer = conv()
+
+
+class _BypassableHolder(PytorchActivationQuantizationHolder):
+    def __init__(self, activation_holder_quantizer: BaseInferableQuantizer, quantization_bypass: bool = False,
+                 **kwargs):
+        super().__init__(activation_holder_quantizer=activation_holder_quantizer, **kwargs)
+        self.quantization_bypass = quantization_bypass
+
+    def forward(self, inputs):
+        if self.quantization_bypass:
+            return inputs
+        return super().forward(inputs)
+
+
+class PytorchFLNActivationQuantizationHolder(_BypassableHolder):
+    """Holder for activations inside fused-layer-norm style blocks; can be switched to pass-through."""
+
+
+class PytorchPreservingActivationQuantizationHolder(_BypassableHolder):
+    """Holder for quantization-preserving ops (reshape, pooling, ...); can be switched to pass-through."""

@@ -1,0 +1,260 @@
+"""Affine (round -> clamp -> dequant) inferable quantizers: symmetric, power-of-two and uniform,
+for weights (per-tensor / per-channel) and activations (per-tensor).
+
+Public contract mirrored from the reference (constructor signatures, attributes, assertion
+messages, reuse cache, side effects) -- see, relative to /root/reference/mct_quantizers/pytorch/quantizers/:
+  base_pytorch_inferable_quantizer.py:24-62      flags + enable_* methods
+  base_symmetric_inferable_quantizer.py:32-60    thresholds -> scales / clamp domain
+  base_uniform_inferable_quantizer.py:33-66      ranges -> adjusted ranges
+  weights_inferable_quantizers/weights_{symmetric,pot,uniform}_inferable_quantizer.py
+  activation_inferable_quantizers/activation_{symmetric,pot,uniform}_inferable_quantizer.py
+
+What differs is underneath ``__call__``: a GPU tensor goes through ONE fused gfx950 kernel
+(mct_quantizers_amd/csrc/mctq_kernels.hip) instead of ATen's fake_quantize_*_cachemask kernels.
+The ONNX-export branch of the reference (``_use_custom_impl and torch.jit.is_tracing()``) is out
+of scope; ``enable_custom_impl`` only records the flag.
+"""
+from typing import List
+
+import numpy as np
+import torch
+
+from mct_quantizers_amd.common.registry import (BaseInferableQuantizer, QuantizationMethod, QuantizationTarget,
+                                               QuantizerID, mark_quantizer)
+from mct_quantizers_amd.hip import ops
+from mct_quantizers_amd.pytorch.quantizer_utils import fix_range_to_include_zero, get_working_device, to_torch_tensor
+
+
+class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
+    """Base of all PyTorch inference-time quantizers: behaviour flags and the output-reuse cache."""
+
+    def __init__(self):
+        super().__init__()
+        self._use_custom_impl = False
+        # reuse: compute the quantized tensor once and hand the same object back afterwards
+        self.reuse = False
+        self.enable_reuse = False
+        self.quantizer_first_run = True
+        self.resue_outputs = None          # [sic] attribute name is part of the reference's surface
+
+    def enable_custom_impl(self):
+        self._use_custom_impl = True
+
+    def enable_reuse_quantizer(self):
+        self.enable_reuse = True
+        self.quantizer_first_run = True
+
+    def disable_reuse_quantizer(self):
+        self.enable_reuse = False
+
+    def __call__(self, inputs: torch.Tensor):
+        raise NotImplementedError(f'{self.__class__.__name__} did not implement __call__')  # pragma: no cover
+
+    # -- reuse cache helpers shared by the weights quantizers (weights_symmetric...py:128-129,153-155)
+    def _cached(self):
+        return self.enable_reuse and not self.quantizer_first_run
+
+    def _remember(self, outputs):
+        if self.enable_reuse and self.quantizer_first_run:
+            self.resue_outputs = outputs
+            self.quantizer_first_run = False
+        return outputs
+
+
+def _is_pot(values: np.ndarray) -> bool:
+    lg = np.log2(values.flatten())
+    return bool(np.all(np.round(lg) == lg))
+
+
+@mark_quantizer(quantization_target=None,
+                quantization_method=[QuantizationMethod.SYMMETRIC],
+                identifier=QuantizerID.INFERABLE)
+class BaseSymmetricInferableQuantizer(BasePyTorchInferableQuantizer):
+
+    def __init__(self, num_bits: int, threshold: List[float], signed: bool):
+        super().__init__()
+        assert isinstance(threshold, list), f'Threshold is expected to be a list, but is of type {type(threshold)}'
+        self.signed = signed
+        self.threshold_np = np.asarray(threshold)
+        self.num_bits = num_bits
+        levels = 2 ** (num_bits - 1) if signed else 2 ** num_bits
+        self.min_quantized_domain = -levels if signed else 0
+        self.max_quantized_domain = levels - 1
+        self.scales = self.threshold_np / levels          # float64 here; subclasses narrow it
+
+
+@mark_quantizer(quantization_target=None,
+                quantization_method=[QuantizationMethod.UNIFORM],
+                identifier=QuantizerID.INFERABLE)
+class BaseUniformInferableQuantizer(BasePyTorchInferableQuantizer):
+
+    def __init__(self, num_bits: int, min_range: List[float], max_range: List[float]):
+        super().__init__()
+        assert isinstance(min_range, list), f'min_range is expected to be a list, but is of type {type(min_range)}'
+        assert isinstance(max_range, list), f'max_range is expected to be a list, but is of type {type(max_range)}'
+        for _min, _max in zip(min_range, max_range):
+            assert _min < _max, f"Max range must be greater than min value but min is {_min} and max is {_max}"
+
+        dev = get_working_device()
+        lo = to_torch_tensor(np.asarray(min_range)).to(dev)
+        hi = to_torch_tensor(np.asarray(max_range)).to(dev)
+        self.min_range, self.max_range = fix_range_to_include_zero(lo, hi, num_bits)
+        self.num_bits = num_bits
+        self.min_quantized_domain = 0
+        self.max_quantized_domain = 2 ** num_bits - 1
+
+
+class _WeightsAffineMixin:
+    """Per-tensor / per-channel dispatch shared by the symmetric and the uniform weights quantizers.
+
+    Expects: self.scales (float32 device tensor [C]), self.zero_points (int32 device tensor [C]),
+    self.per_channel, self.channel_axis, the clamp domain, and host copies _scale0 / _zp0 of the
+    first entry (so the per-tensor launch needs no device->host read).
+    """
+
+    def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
+        inputs.requires_grad = False            # the reference flips this on the caller's tensor
+        if self.per_channel:
+            return ops.fq_per_channel(inputs, self.scales.flatten(), self.zero_points.flatten(), self.channel_axis,
+                                      self.min_quantized_domain, self.max_quantized_domain)
+        return ops.fq_per_tensor(inputs, self._scale0, self._zp0,
+                                 self.min_quantized_domain, self.max_quantized_domain)
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Weights,
+                quantization_method=[QuantizationMethod.SYMMETRIC],
+                identifier=QuantizerID.INFERABLE)
+class WeightsSymmetricInferableQuantizer(_WeightsAffineMixin, BaseSymmetricInferableQuantizer):
+    """Symmetric signed weights quantizer, per tensor or per channel."""
+
+    def __init__(self, num_bits: int, threshold: List[float], per_channel: bool, channel_axis: int = None):
+        super().__init__(num_bits=num_bits, threshold=threshold, signed=True)
+        if per_channel:
+            assert channel_axis is not None, 'Channel axis is missing in per channel quantization'
+            assert len(threshold) >= 1, \
+                f'In per-channel quantization threshold should be of length >= 1 but is {len(threshold)}'
+        else:
+            assert len(threshold) == 1, \
+                f'In per-tensor quantization threshold should be of length 1 but is {len(threshold)}'
+        self.per_channel = per_channel
+        self.channel_axis = channel_axis
+
+        scales_f32 = self.scales.astype(np.float32)
+        self._scale0 = float(scales_f32.reshape(-1)[0])
+        self._zp0 = 0
+        dev = get_working_device()
+        self.scales = to_torch_tensor(self.scales).to(dev)
+        self.zero_points = torch.zeros(len(threshold), dtype=torch.int32).to(dev)
+
+    def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
+        if self._cached():
+            return self.resue_outputs
+        return self._remember(self._quantize_weights(inputs))
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Weights,
+                quantization_method=[QuantizationMethod.POWER_OF_TWO],
+                identifier=QuantizerID.INFERABLE)
+class WeightsPOTInferableQuantizer(WeightsSymmetricInferableQuantizer):
+    """Symmetric weights quantizer whose thresholds must be powers of two."""
+
+    def __init__(self, num_bits: int, threshold: List[float], per_channel: bool, channel_axis: int = None):
+        super().__init__(num_bits=num_bits, threshold=threshold, per_channel=per_channel, channel_axis=channel_axis)
+        self.threshold = threshold
+        assert _is_pot(self.threshold_np), f'Expected threshold to be power of 2 but is {threshold}'
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Weights,
+                quantization_method=[QuantizationMethod.UNIFORM],
+                identifier=QuantizerID.INFERABLE)
+class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferableQuantizer):
+    """Unsigned uniform weights quantizer over [min_range, max_range] (adjusted to contain 0)."""
+
+    def __init__(self, num_bits: int, min_range: List[float], max_range: List[float], per_channel: bool,
+                 channel_axis: int = None):
+        super().__init__(num_bits=num_bits, min_range=min_range, max_range=max_range)
+        if per_channel:
+            assert channel_axis is not None, 'Channel axis is missing in per channel quantization'
+            assert len(min_range) >= 1, \
+                f'In per-channel quantization min_range should be of length >= 1 but is {len(min_range)}'
+            assert len(max_range) >= 1, \
+                f'In per-channel quantization max_range should be of length >= 1 but is {len(max_range)}'
+        else:
+            assert len(min_range) == 1, \
+                f'In per-tensor quantization min_range should be of length 1 but is {len(min_range)}'
+            assert len(max_range) == 1, \
+                f'In per-tensor quantization max_range should be of length 1 but is {len(max_range)}'
+        self.per_channel = per_channel
+        self.channel_axis = channel_axis
+
+        self.adjusted_min_range_np = self.min_range.cpu().numpy()
+        self.adjusted_max_range_np = self.max_range.cpu().numpy()
+
+        dev = get_working_device()
+        # step of the grid, and the (positive) zero point: TRUNCATION of min/scale, negated
+        self.scales = ((self.max_range - self.min_range) / (2 ** num_bits - 1)).to(dev)
+        self.zero_points = (-(self.min_range / self.scales).int()).to(dev)
+        self._scale0 = float(self.scales.reshape(-1)[0].item())
+        self._zp0 = int(self.zero_points.reshape(-1)[0].item())
+
+    def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
+        if self._cached():
+            return self.resue_outputs
+        return self._remember(self._quantize_weights(inputs))
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Activation,
+                quantization_method=[QuantizationMethod.SYMMETRIC],
+                identifier=QuantizerID.INFERABLE)
+class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
+    """Symmetric activation quantizer (per tensor only), signed or unsigned."""
+
+    def __init__(self, num_bits: int, threshold: List[float], signed: bool):
+        super().__init__(num_bits=num_bits, threshold=threshold, signed=signed)
+        assert len(threshold) == 1, ('For activation, only per-tensor quantization is supported. Thus, threshold '
+                                     f'should be of length 1 but is {len(threshold)}')
+        assert self.threshold_np.shape[0] == 1
+        self.threshold_np = self.threshold_np[0]
+        assert len(self.scales) == 1, ('For activation, quantization per channel is not supported and threshold '
+                                       f'should be of length 1 but is {len(threshold)}')
+        self.scales = float(self.scales[0])      # stays a Python double; narrowed to float32 at launch
+        self.zero_points = 0
+
+    def __call__(self, inputs: torch.Tensor):
+        with torch.no_grad():
+            return ops.fq_per_tensor(inputs, self.scales, self.zero_points,
+                                     self.min_quantized_domain, self.max_quantized_domain)
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Activation,
+                quantization_method=[QuantizationMethod.POWER_OF_TWO],
+                identifier=QuantizerID.INFERABLE)
+class ActivationPOTInferableQuantizer(ActivationSymmetricInferableQuantizer):
+    """Symmetric activation quantizer whose threshold must be a power of two."""
+
+    def __init__(self, num_bits: int, threshold: List[float], signed: bool):
+        super().__init__(num_bits=num_bits, signed=signed, threshold=threshold)
+        assert _is_pot(self.threshold_np), f'Expected threshold to be power of 2 but is {threshold}'
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Activation,
+                quantization_method=[QuantizationMethod.UNIFORM],
+                identifier=QuantizerID.INFERABLE)
+class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
+    """Unsigned uniform activation quantizer (per tensor only)."""
+
+    def __init__(self, num_bits: int, min_range: List[float], max_range: List[float]):
+        super().__init__(num_bits=num_bits, min_range=min_range, max_range=max_range)
+        assert len(min_range) == 1, ('For activation, only per-tensor quantization is supported. Thus, min_range '
+                                     f'should be of length 1 but is {len(min_range)}')
+        assert len(max_range) == 1, ('For activation, only per-tensor quantization is supported. Thus, max_range '
+                                     f'should be of length 1 but is {len(max_range)}')
+        self.min_range = self.min_range[0].cpu().item()
+        self.max_range = self.max_range[0].cpu().item()
+        self.scale = float((self.max_range - self.min_range) / ((2 ** num_bits) - 1))
+        self.zero_point = int(-np.round(self.min_range / self.scale))   # round half even, in double
+
+    def __call__(self, inputs: torch.Tensor):
+        with torch.no_grad():
+            return ops.fq_per_tensor(inputs, self.scale, self.zero_point,
+                                     self.min_quantized_domain, self.max_quantized_domain)

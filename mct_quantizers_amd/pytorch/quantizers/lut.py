@@ -1,0 +1,146 @@
+"""LUT (codebook) inferable quantizers: weights LUT-symmetric / LUT-POT and activation LUT-POT.
+
+Public contract mirrored from, relative to /root/reference/mct_quantizers/pytorch/quantizers/:
+  base_lut_symmetric_inferable_quantizer.py:32-94               validation + attributes
+  weights_inferable_quantizers/weights_lut_symmetric_inferable_quantizer.py:42-128
+  weights_inferable_quantizers/weights_lut_pot_inferable_quantizer.py:40-104
+  activation_inferable_quantizers/activation_lut_pot_inferable_quantizer.py:38-91
+
+``__call__`` replaces the reference's ~10-kernel op chain (quantizer_utils.py:95-139, two N x L
+temporaries) by one fused gfx950 kernel at 8 algorithmic bytes per element.
+"""
+import warnings
+from typing import List
+
+import numpy as np
+import torch
+
+from mct_quantizers_amd.common.constants import EPS, LUT_VALUES_BITWIDTH
+from mct_quantizers_amd.common.registry import QuantizationMethod, QuantizationTarget, QuantizerID, mark_quantizer
+from mct_quantizers_amd.hip import ops
+from mct_quantizers_amd.pytorch.quantizer_utils import get_working_device, lut_domain, to_torch_tensor
+from mct_quantizers_amd.pytorch.quantizers.affine import BasePyTorchInferableQuantizer, _is_pot
+
+
+@mark_quantizer(quantization_target=None,
+                quantization_method=[QuantizationMethod.LUT_SYM_QUANTIZER],
+                identifier=QuantizerID.INFERABLE)
+class BaseLUTSymmetricInferableQuantizer(BasePyTorchInferableQuantizer):
+
+    def __init__(self, num_bits: int, lut_values: List[float], threshold: List[float], signed: bool,
+                 lut_values_bitwidth: int, eps: float):
+        super().__init__()
+        assert isinstance(threshold, list), f'Threshold is expected to be a list, but is of type {type(threshold)}'
+        assert isinstance(lut_values, list), f'lut_values is expected to be a list, but is of type {type(lut_values)}'
+
+        self._threshold_np = np.asarray(threshold)
+        self._lut_values_np = np.asarray(lut_values)
+        lut = self._lut_values_np
+
+        assert len(np.unique(lut)) <= 2 ** num_bits, \
+            f'Expected num of lut values to be less or equal than {2 ** num_bits} but got {len(lut)}'
+        assert not np.any(lut - lut.astype(int)), 'Expected lut values to be integers'
+        if signed:
+            bound = 2 ** (lut_values_bitwidth - 1)
+            assert np.all((-bound <= lut) & (lut <= bound - 1)), 'Expected lut values in the quantization range'
+        else:
+            assert np.all(lut <= 2 ** lut_values_bitwidth), 'Expected lut values in the quantization range'
+            assert np.all(lut >= 0), 'Expected unsigned lut values in unsigned activation quantization'
+        assert num_bits <= lut_values_bitwidth, \
+            f'Look-Up-Table bit configuration has {num_bits} bits. It must be less then {lut_values_bitwidth}'
+        if num_bits == lut_values_bitwidth:
+            warnings.warn("Num of bits equal to multiplier n bits, Please be aware LUT quantizier may be "
+                          "inefficient in that case, consider using SymmetricInferableQuantizer instead")
+
+        self.threshold = threshold
+        self.lut_values = lut_values
+        self.signed = signed
+        self.num_bits = num_bits
+        self.lut_values_bitwidth = lut_values_bitwidth
+        self.eps = eps
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Weights,
+                quantization_method=[QuantizationMethod.LUT_SYM_QUANTIZER],
+                identifier=QuantizerID.INFERABLE)
+class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
+    """Signed codebook quantizer for weights, one threshold per tensor or per channel."""
+
+    def __init__(self, num_bits: int, lut_values: List[float], threshold: List[float], per_channel: bool,
+                 channel_axis: int = None, input_rank: int = None, lut_values_bitwidth: int = LUT_VALUES_BITWIDTH,
+                 eps: float = EPS):
+        super().__init__(threshold=threshold, num_bits=num_bits, lut_values=lut_values, signed=True,
+                         lut_values_bitwidth=lut_values_bitwidth, eps=eps)
+        self.per_channel = per_channel
+        self.channel_axis = channel_axis
+        self.input_rank = input_rank
+        if per_channel:
+            assert channel_axis is not None, 'Channel axis is missing in per channel quantization'
+            assert input_rank is not None, 'input_rank is missing in per channel quantization'
+            assert len(threshold) >= 1, \
+                f'In per-channel quantization threshold should be of length >= 1 but is {len(threshold)}'
+        else:
+            assert len(threshold) == 1, \
+                f'In per-tensor quantization threshold should be of length 1 but is {len(threshold)}'
+
+        dev = get_working_device()
+        self._threshold_torch = to_torch_tensor(self._threshold_np).to(dev)
+        self._lut_values_torch = to_torch_tensor(self._lut_values_np).to(dev)
+        # host copies for the per-tensor launch: tensor + python-scalar is a float32 add
+        thr0 = np.float32(self._threshold_np.reshape(-1)[0])
+        self._thr_mul0 = float(thr0)
+        self._thr_div0 = float(thr0 + np.float32(eps))
+
+    def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
+        if self._cached():
+            return self.resue_outputs
+        inputs.requires_grad = False
+        mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, True)
+        if self.per_channel:
+            if self.input_rank != inputs.dim():
+                raise RuntimeError(f'input_rank={self.input_rank} does not match a tensor of rank {inputs.dim()}')
+            axis = self.channel_axis % inputs.dim()
+            out = ops.lut_per_channel(inputs, self._lut_values_torch, self._threshold_torch, float(self.eps), axis,
+                                      mult, cmin, cmax)
+        else:
+            out = ops.lut_per_tensor(inputs, self._lut_values_torch, self._thr_div0, self._thr_mul0, mult, cmin, cmax)
+        return self._remember(out)
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Weights,
+                quantization_method=[QuantizationMethod.LUT_POT_QUANTIZER],
+                identifier=QuantizerID.INFERABLE)
+class WeightsLUTPOTInferableQuantizer(WeightsLUTSymmetricInferableQuantizer):
+    """Weights codebook quantizer whose thresholds must be powers of two."""
+
+    def __init__(self, num_bits: int, lut_values: List[float], threshold: List[float], per_channel: bool,
+                 channel_axis: int = None, input_rank: int = None, lut_values_bitwidth: int = LUT_VALUES_BITWIDTH,
+                 eps: float = EPS):
+        super().__init__(num_bits=num_bits, threshold=threshold, lut_values=lut_values, per_channel=per_channel,
+                         channel_axis=channel_axis, input_rank=input_rank, lut_values_bitwidth=lut_values_bitwidth,
+                         eps=eps)
+        assert _is_pot(self._threshold_np), f'Expected threshold to be power of 2 but is {threshold}'
+
+
+@mark_quantizer(quantization_target=QuantizationTarget.Activation,
+                quantization_method=[QuantizationMethod.LUT_POT_QUANTIZER],
+                identifier=QuantizerID.INFERABLE)
+class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
+    """Activation codebook quantizer (per tensor, power-of-two threshold), signed or unsigned."""
+
+    def __init__(self, num_bits: int, lut_values: List[float], threshold: List[float], signed: bool,
+                 lut_values_bitwidth: int = LUT_VALUES_BITWIDTH, eps: float = EPS):
+        super().__init__(num_bits=num_bits, lut_values=lut_values, threshold=threshold, signed=signed,
+                         lut_values_bitwidth=lut_values_bitwidth, eps=eps)
+        assert _is_pot(self._threshold_np), f'Expected threshold to be power of 2 but is {threshold}'
+        assert len(self.threshold) == 1, ('For activation, quantization per channel is not supported and threshold '
+                                          f'should be of length 1 but is {len(threshold)}')
+        self.threshold = self.threshold[0]
+        self.lut_values = to_torch_tensor(self._lut_values_np).to(get_working_device())
+        # Python-float threshold: threshold + eps is a DOUBLE add, narrowed to float32 at the division
+        self._thr_mul0 = float(np.float32(self.threshold))
+        self._thr_div0 = float(np.float32(float(self.threshold) + eps))
+
+    def __call__(self, inputs: torch.Tensor):
+        mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
+        return ops.lut_per_tensor(inputs, self.lut_values, self._thr_div0, self._thr_mul0, mult, cmin, cmax)

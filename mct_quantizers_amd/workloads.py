@@ -1,0 +1,123 @@
+"""Synthetic workloads for the five BASELINE.json configurations.
+
+The generator is *portable*: a splitmix64 counter hash turned into float32 by
+exact integer steps plus IEEE float32 multiplies, so every machine that runs
+numpy produces the same bits.  It is used by ``bench.py``, by
+the parity tests and by ``tools/gen_golden.py`` (which records SHA-256 digests
+of the reference's full-size outputs for these inputs).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, Tuple
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(idx: np.ndarray, seed: int) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def bell_f32(n: int, seed: int, start: int = 0) -> np.ndarray:
+    """n float32 samples, bell shaped (sum of four 16-bit uniforms), unit variance, zero mean.
+
+    Exact steps: four 16-bit fields of one 64-bit hash are summed (integer < 2**18),
+    centred, converted to float32 exactly, then scaled by one float32 multiply.
+    """
+    out = np.empty(n, dtype=np.float32)
+    step = 1 << 22
+    # std of a sum of four U{0..65535} = sqrt(4 * (65536**2 - 1) / 12)
+    k = np.float32(1.0 / 37837.22)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        h = _splitmix64(np.arange(start + lo, start + hi, dtype=np.uint64), seed)
+        s = (h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF)) \
+            + ((h >> np.uint64(32)) & np.uint64(0xFFFF)) + (h >> np.uint64(48))
+        out[lo:hi] = (s.astype(np.int64) - 131070).astype(np.float32) * k
+    return out
+
+
+def uniform_f32(n: int, seed: int, lo: float, hi: float, start: int = 0) -> np.ndarray:
+    """n float32 samples uniform on [lo, hi) with 24-bit resolution."""
+    h = _splitmix64(np.arange(start, start + n, dtype=np.uint64), seed)
+    u = (h >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+    return (np.float32(lo) + u * np.float32(hi - lo)).astype(np.float32)
+
+
+CFG4_LUT = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+
+
+@dataclass
+class Workload:
+    name: str
+    quantizer: str                      # class name in mct_quantizers_amd.pytorch.quantizers
+    kwargs: Dict[str, Any]              # constructor arguments
+    shape: Tuple[int, ...]
+    seed: int
+    bytes_per_elem: int = 8             # algorithmic: 4 read + 4 written
+    extra: Dict[str, Any] = field(default_factory=dict)
+
+    @property
+    def numel(self) -> int:
+        return int(np.prod(self.shape))
+
+
+def _row_gain(rows: int, seed: int) -> np.ndarray:
+    return uniform_f32(rows, seed + 7919, 0.5, 2.0)
+
+
+def make_input(cfg: str, shape=None, batch: int = 8) -> np.ndarray:
+    """The float32 input tensor of a BASELINE configuration (optionally at a reduced shape)."""
+    if cfg == "cfg1":
+        shape = shape or (256, 256)
+        return bell_f32(int(np.prod(shape)), 1001).reshape(shape)
+    if cfg == "cfg2":
+        shape = shape or (4096, 4096)
+        x = bell_f32(int(np.prod(shape)), 1002).reshape(shape)
+        return (x * _row_gain(shape[0], 1002)[:, None]).astype(np.float32)
+    if cfg == "cfg3":
+        shape = shape or (batch, 3, 224, 224)
+        return (bell_f32(int(np.prod(shape)), 1003) * np.float32(2.0)).reshape(shape)
+    if cfg == "cfg4":
+        shape = shape or (4096, 11008)
+        return bell_f32(int(np.prod(shape)), 1004).reshape(shape)
+    if cfg == "cfg5":
+        shape = shape or (8192, 8192)
+        x = bell_f32(int(np.prod(shape)), 1005).reshape(shape)
+        return (x * _row_gain(shape[0], 1005)[:, None]).astype(np.float32)
+    raise KeyError(cfg)
+
+
+def make_workload(cfg: str, x: np.ndarray) -> Workload:
+    """Quantizer class + constructor arguments for a configuration, derived from its input."""
+    if cfg == "cfg1":
+        thr = [float(np.max(np.abs(x)))]
+        return Workload("cfg1 WeightsSymmetric per-tensor 8b", "WeightsSymmetricInferableQuantizer",
+                        dict(num_bits=8, threshold=thr, per_channel=False), x.shape, 1001)
+    if cfg == "cfg2":
+        thr = [float(v) for v in np.max(np.abs(x), axis=1)]
+        return Workload("cfg2 WeightsSymmetric per-channel(axis0) 8b", "WeightsSymmetricInferableQuantizer",
+                        dict(num_bits=8, threshold=thr, per_channel=True, channel_axis=0), x.shape, 1002)
+    if cfg == "cfg3":
+        return Workload("cfg3 ActivationUniform per-tensor 8b", "ActivationUniformInferableQuantizer",
+                        dict(num_bits=8, min_range=[-2.5], max_range=[3.1]), x.shape, 1003)
+    if cfg == "cfg4":
+        thr = [float(v) for v in np.max(np.abs(x), axis=1)]
+        return Workload("cfg4 WeightsLUTSymmetric 16 codes per-channel(axis0)",
+                        "WeightsLUTSymmetricInferableQuantizer",
+                        dict(num_bits=4, lut_values=list(CFG4_LUT), threshold=thr, per_channel=True,
+                             channel_axis=0, input_rank=2), x.shape, 1004)
+    if cfg == "cfg5":
+        mant, exp = np.frexp(np.max(np.abs(x), axis=1).astype(np.float64))   # exact: v = mant * 2**exp
+        thr = [float(np.ldexp(1.0, int(e) - 1 if f == 0.5 else int(e))) for f, e in zip(mant, exp)]
+        return Workload("cfg5 WeightsPOT per-channel(axis0) 4b", "WeightsPOTInferableQuantizer",
+                        dict(num_bits=4, threshold=thr, per_channel=True, channel_axis=0), x.shape, 1005)
+    raise KeyError(cfg)

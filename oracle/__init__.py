@@ -1,0 +1,39 @@
+"""CPU oracle package (test infrastructure only; see mctq_oracle.py's header).
+
+``oracle_call`` maps a reference quantizer class name + constructor kwargs + input
+to the oracle's output, the way the reference's ``Cls(**kwargs)(x)`` would.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import mctq_oracle as O
+
+
+def oracle_call(cls_name: str, kwargs: dict, x: np.ndarray, return_index: bool = False):
+    kw = dict(kwargs)
+    nb = kw["num_bits"]
+    if cls_name in ("WeightsSymmetricInferableQuantizer", "WeightsPOTInferableQuantizer"):
+        s, z, qmin, qmax = O.weights_symmetric_params(nb, kw["threshold"])
+        axis = kw.get("channel_axis") if kw["per_channel"] else None
+        return O.fake_quant_affine(x, s, z, qmin, qmax, axis=axis, return_index=return_index)
+    if cls_name == "WeightsUniformInferableQuantizer":
+        s, z, qmin, qmax, _, _ = O.weights_uniform_params(nb, kw["min_range"], kw["max_range"])
+        axis = kw.get("channel_axis") if kw["per_channel"] else None
+        return O.fake_quant_affine(x, s, z, qmin, qmax, axis=axis, return_index=return_index)
+    if cls_name in ("ActivationSymmetricInferableQuantizer", "ActivationPOTInferableQuantizer"):
+        s, z, qmin, qmax = O.activation_symmetric_params(nb, kw["threshold"], kw["signed"])
+        return O.fake_quant_affine(x, s, z, qmin, qmax, return_index=return_index)
+    if cls_name == "ActivationUniformInferableQuantizer":
+        s, z, qmin, qmax, _, _ = O.activation_uniform_params(nb, kw["min_range"], kw["max_range"])
+        return O.fake_quant_affine(x, s, z, qmin, qmax, return_index=return_index)
+    if cls_name in ("WeightsLUTSymmetricInferableQuantizer", "WeightsLUTPOTInferableQuantizer"):
+        return O.lut_quantize(x, kw["lut_values"], np.asarray(kw["threshold"], dtype=np.float64).astype(np.float32),
+                              True, kw.get("lut_values_bitwidth", O.LUT_VALUES_BITWIDTH), kw.get("eps", O.EPS),
+                              per_channel=kw["per_channel"], channel_axis=kw.get("channel_axis"),
+                              return_index=return_index)
+    if cls_name == "ActivationLutPOTInferableQuantizer":
+        return O.lut_quantize(x, kw["lut_values"], float(kw["threshold"][0]), kw["signed"],
+                              kw.get("lut_values_bitwidth", O.LUT_VALUES_BITWIDTH), kw.get("eps", O.EPS),
+                              return_index=return_index)
+    raise KeyError(cls_name)

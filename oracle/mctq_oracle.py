@@ -1,0 +1,243 @@
+"""CPU oracle for the inferable-quantizer hot path (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+This file restates, in plain numpy float32 arithmetic, what sony/mct_quantizers'
+PyTorch inferable quantizers compute on a CPU tensor.  It exists so the HIP
+kernels can be checked bit for bit.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it; the shipped package
+(``mct_quantizers_amd``) never does.
+
+Parity pin: PINNED.  Every function below is compared bit-exactly with the
+reference imported from ``/root/reference`` (torch 2.10 CPU) by
+``tools/gen_golden.py`` and against the committed fixtures under
+``tests/golden/`` by ``tests/test_oracle_golden.py``.
+
+Third-party arithmetic: six of the nine quantizers delegate to torch ATen
+``fake_quantize_per_tensor_affine`` / ``fake_quantize_per_channel_affine``
+(not under /root/reference; the reference does not pin torch,
+requirements.txt:1-2; fixtures were produced with torch 2.10.0).  The published
+ATen CPU algorithm restated here is
+
+    inv = 1.0f / scale
+    q   = clamp(nearbyint(x * inv) + zero_point, quant_min, quant_max)
+    y   = (q - zero_point) * scale
+
+Citations ``<file>:<line>`` are relative to /root/reference/mct_quantizers/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+EPS = 1e-8                 # common/constants.py:83
+LUT_VALUES_BITWIDTH = 8    # common/constants.py:84
+
+
+# --------------------------------------------------------------------------
+# parameter derivation (constructors)
+# --------------------------------------------------------------------------
+
+def symmetric_domain(num_bits: int, signed: bool):
+    """Integer clamp domain, pytorch/quantizers/base_symmetric_inferable_quantizer.py:53-60."""
+    if signed:
+        return -2 ** (num_bits - 1), 2 ** (num_bits - 1) - 1
+    return 0, 2 ** num_bits - 1
+
+
+def symmetric_scales_f64(num_bits: int, threshold, signed: bool) -> np.ndarray:
+    """float64 scales, base_symmetric_inferable_quantizer.py:56,60."""
+    thr = np.asarray(threshold)
+    return thr / 2 ** (num_bits - 1) if signed else thr / 2 ** num_bits
+
+
+def weights_symmetric_params(num_bits: int, threshold):
+    """(scales fp32[C], zero_points int32[C], qmin, qmax).
+
+    weights_symmetric_inferable_quantizer.py:114-115: float64 scales are cast to
+    float32 by to_torch_tensor (quantizer_utils.py:50-51); zero points are zeros.
+    """
+    scales = symmetric_scales_f64(num_bits, threshold, True).astype(F32)
+    zps = np.zeros(len(threshold), dtype=np.int32)
+    qmin, qmax = symmetric_domain(num_bits, True)
+    return scales, zps, qmin, qmax
+
+
+def activation_symmetric_params(num_bits: int, threshold, signed: bool):
+    """(scale python float, zero_point 0, qmin, qmax).
+
+    activation_symmetric_inferable_quantizer.py:92-94: the scale stays a Python
+    double; ATen casts it to float32 when the kernel is launched.
+    """
+    scale = float(symmetric_scales_f64(num_bits, threshold, signed)[0])
+    qmin, qmax = symmetric_domain(num_bits, signed)
+    return scale, 0, qmin, qmax
+
+
+def fix_range_to_include_zero(range_min, range_max, n_bits: int):
+    """float32 restatement of pytorch/quantizer_utils.py:60-92 (torch fp32 ops).
+
+    Note there is no final clamp to <=0 / >=0, unlike the numpy twin in
+    common/quant_utils.py:47-48.
+    """
+    rmin = np.asarray(range_min, dtype=F32)
+    rmax = np.asarray(range_max, dtype=F32)
+    min_positive = rmin > 0
+    max_negative = rmax < 0
+    mid_range = np.logical_and(~min_positive, ~max_negative).astype(F32)
+    min_positive = min_positive.astype(F32)
+    max_negative = max_negative.astype(F32)
+
+    levels = F32(2 ** n_bits - 1)
+    with np.errstate(all="ignore"):
+        scale = (rmax - rmin) / levels
+        min_adj = scale * np.rint(rmin / scale)
+        max_adj = rmax - rmin + min_adj
+        min_adj = min_adj * mid_range + max_negative * rmin
+        max_adj = max_adj * mid_range + min_positive * rmax
+    return min_adj.astype(F32), max_adj.astype(F32)
+
+
+def weights_uniform_params(num_bits: int, min_range, max_range):
+    """(scales fp32[C], zero_points int32[C], qmin, qmax, adj_min fp32, adj_max fp32).
+
+    weights_uniform_inferable_quantizer.py:123-124: the zero point is the
+    TRUNCATION toward zero of min/scale, negated (torch ``.int()``).
+    """
+    a, b = fix_range_to_include_zero(min_range, max_range, num_bits)
+    scales = ((b - a) / F32(2 ** num_bits - 1)).astype(F32)
+    with np.errstate(all="ignore"):
+        zps = (-np.trunc(a / scales)).astype(np.int32)
+    return scales, zps, 0, 2 ** num_bits - 1, a, b
+
+
+def activation_uniform_params(num_bits: int, min_range, max_range):
+    """(scale python float, zero_point int, qmin, qmax, adj_min float, adj_max float).
+
+    activation_uniform_inferable_quantizer.py:104-108: the adjusted range is read
+    back as Python floats (exact float32 values), the scale is formed in double
+    and the zero point is round-half-even of min/scale in double.
+    """
+    a, b = fix_range_to_include_zero(min_range, max_range, num_bits)
+    a = float(a[0])
+    b = float(b[0])
+    scale = float((b - a) / ((2 ** num_bits) - 1))
+    zp = int(-np.round(a / scale))
+    return scale, zp, 0, 2 ** num_bits - 1, a, b
+
+
+def validate_lut(num_bits, lut_values, threshold, signed, lut_values_bitwidth):
+    """Constructor asserts of base_lut_symmetric_inferable_quantizer.py:53-86 (messages verbatim)."""
+    assert isinstance(threshold, list), f'Threshold is expected to be a list, but is of type {type(threshold)}'
+    assert isinstance(lut_values, list), f'lut_values is expected to be a list, but is of type {type(lut_values)}'
+    lut = np.asarray(lut_values)
+    assert len(np.unique(lut)) <= 2 ** num_bits, \
+        f'Expected num of lut values to be less or equal than {2 ** num_bits} but got {len(lut)}'
+    assert not np.any(lut - lut.astype(int)), 'Expected lut values to be integers'
+    if signed:
+        k = lut_values_bitwidth - 1
+        assert np.all((-(2 ** k) <= lut) & (lut <= 2 ** k - 1)), 'Expected lut values in the quantization range'
+    else:
+        assert np.all(lut <= 2 ** lut_values_bitwidth), 'Expected lut values in the quantization range'
+        assert np.all(lut >= 0), 'Expected unsigned lut values in unsigned activation quantization'
+    assert num_bits <= lut_values_bitwidth, \
+        f'Look-Up-Table bit configuration has {num_bits} bits. It must be less then {lut_values_bitwidth}'
+
+
+# --------------------------------------------------------------------------
+# element arithmetic (__call__)
+# --------------------------------------------------------------------------
+
+def _channel_shape(ndim: int, axis: int):
+    shape = [1] * ndim
+    shape[axis] = -1
+    return shape
+
+
+def fake_quant_affine(x: np.ndarray, scale, zero_point, qmin: int, qmax: int,
+                      axis=None, return_index: bool = False):
+    """ATen fake_quantize_per_{tensor,channel}_affine on CPU, float32.
+
+    Call sites: weights_symmetric_inferable_quantizer.py:139-151,
+    weights_uniform_inferable_quantizer.py:153-165,
+    activation_symmetric_inferable_quantizer.py:113-117,
+    activation_uniform_inferable_quantizer.py:124-128.
+
+    ``scale`` is a float32 vector (per-channel, ``axis`` given), a 1-element
+    vector or a Python float (per-tensor; cast to float32 first, as ATen does).
+    Returns y (and the integer clamp index q when ``return_index``).
+    Defined for finite inputs with |x/scale| < 2**31 (see DESIGN.md for the
+    saturation rule outside that domain).
+    """
+    x = np.asarray(x, dtype=F32)
+    s = np.asarray(scale, dtype=F32).reshape(-1)
+    z = np.asarray(zero_point).reshape(-1).astype(F32)
+    if axis is not None:
+        shape = _channel_shape(x.ndim, axis)
+        s = s.reshape(shape)
+        z = z.reshape(shape)
+    else:
+        assert s.size == 1 and z.size == 1
+        s = s[0]
+        z = z[0]
+    with np.errstate(all="ignore"):
+        inv = F32(1.0) / s                       # NOT x / s
+        q = np.rint(x * inv) + z                 # ties to even, float add of the zero point
+        q = np.minimum(np.maximum(q, F32(qmin)), F32(qmax))
+        y = ((q - z) * s).astype(F32)
+    if return_index:
+        return y, q.astype(np.int64)
+    return y
+
+
+def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
+                 lut_values_bitwidth: int = LUT_VALUES_BITWIDTH, eps: float = EPS,
+                 per_channel: bool = False, channel_axis=None,
+                 return_index: bool = False, chunk_elems: int = 1 << 20):
+    """pytorch/quantizer_utils.py:95-139 (lut_quantizer) + :142-170, float32.
+
+    ``threshold`` is a float32 vector (weights, per-channel or 1 element) or a
+    Python float (ActivationLutPOT, activation_lut_pot_inferable_quantizer.py:72):
+    in that case ``threshold + eps`` is formed in double and then used as a
+    float32 scalar.  The codebook scan is the literal first-minimum argmin over
+    float32 |t - lut[j]| in list order (quantizer_utils.py:131-134).
+    Processes the tensor in chunks so the N x L temporaries stay small.
+    """
+    x = np.asarray(x, dtype=F32)
+    lut = np.asarray(lut_values, dtype=F32).reshape(-1)
+    k = lut_values_bitwidth - int(signed)
+    m = F32(2 ** k)
+    if signed:
+        cmin, cmax = F32(-2 ** (lut_values_bitwidth - 1)), F32(2 ** (lut_values_bitwidth - 1) - 1)
+    else:
+        cmin, cmax = F32(0), F32(2 ** lut_values_bitwidth - 1)
+
+    if isinstance(threshold, (float, int)):
+        thr_mul = np.broadcast_to(F32(threshold), x.shape)
+        thr_div = np.broadcast_to(F32(float(threshold) + eps), x.shape)   # double add, then fp32
+    else:
+        thr = np.asarray(threshold, dtype=F32).reshape(-1)
+        if per_channel:
+            thr = thr.reshape(_channel_shape(x.ndim, channel_axis))
+        thr_mul = np.broadcast_to(thr, x.shape)
+        thr_div = np.broadcast_to((thr + F32(eps)).astype(F32), x.shape)   # fp32 add
+
+    xf = x.reshape(-1)
+    tm = thr_mul.reshape(-1)
+    td = thr_div.reshape(-1)
+    y = np.empty(xf.shape, dtype=F32)
+    idx_out = np.empty(xf.shape, dtype=np.int64) if return_index else None
+    with np.errstate(all="ignore"):
+        for lo in range(0, xf.size, chunk_elems):
+            hi = min(lo + chunk_elems, xf.size)
+            t = (xf[lo:hi] / td[lo:hi]) * m
+            t = np.where(np.isnan(t), t, np.minimum(np.maximum(t, cmin), cmax))  # torch.clip keeps NaN
+            d = np.abs(t[:, None] - lut[None, :])
+            # torch.argmin: first minimum, NaN counts as the minimum -> index 0 for an all-NaN row
+            idx = np.where(np.isnan(t), 0, np.argmin(d, axis=1))
+            y[lo:hi] = (lut[idx] / m) * tm[lo:hi]
+            if return_index:
+                idx_out[lo:hi] = idx
+    y = y.reshape(x.shape)
+    if return_index:
+        return y, idx_out.reshape(x.shape)
+    return y
