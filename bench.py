@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the inferable-quantizer hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--nt 0|1] [--unroll U] [--no-cpu]
+
+A *step* is one call of the configuration's quantizer (through the public class, hence through the
+C ABI and the gfx950 kernel) on one device-resident synthetic tensor.  Default workload: BASELINE
+config 2, WeightsSymmetricInferableQuantizer per-channel (axis 0) 8-bit on 4096x4096 float32.
+
+Cache protocol: the 128 MiB in+out working set of config 2 fits the 256 MiB Infinity Cache, so the
+steps rotate over RING distinct (input, output) buffer pairs whose total footprint exceeds it; every
+launch therefore streams from/to HBM ("cold").  ``--ring 1`` measures the warm case.
+
+With N > 1 (launched by torch.distributed.run, one process per GPU) every rank runs the same per-GPU
+workload (weak scaling; the path needs no collective); the value is the sum over ranks divided by
+the slowest rank's time.  ``--gather`` additionally times the dim-0 all-gather of the shards (RCCL).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (guide MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--batch", type=int, default=64, help="N of config 3")
+    ap.add_argument("--ring", type=int, default=0, help="buffer pairs to rotate over (0 = enough to exceed 512 MiB)")
+    ap.add_argument("--nt", type=int, default=None)
+    ap.add_argument("--unroll", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather", action="store_true", help="also time the all-gather of dim-0 shards (N > 1)")
+    ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd import workloads
+    from mct_quantizers_amd.hip import native
+    native.load()
+    if args.nt is not None:
+        native.set_tuning("nt", args.nt)
+    if args.unroll is not None:
+        native.set_tuning("unroll", args.unroll)
+
+    # ---- workload -------------------------------------------------------------------------
+    x_np = workloads.make_input(args.config, batch=args.batch)
+    wl = workloads.make_workload(args.config, x_np)
+    quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
+    elems = wl.numel
+    alg_bytes = elems * wl.bytes_per_elem
+    ring = args.ring or max(2, -(-(512 << 20) // alg_bytes) + 1)
+    x0 = torch.from_numpy(x_np).cuda()
+    xs = [x0] + [x0.clone() for _ in range(ring - 1)]
+    ys = [None] * ring
+
+    def step(i):
+        ys[i % ring] = quantizer(xs[i % ring])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    graph = None
+    if args.graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(args.steps):
+                step(i)
+        torch.cuda.synchronize()
+
+    # ---- timed region ---------------------------------------------------------------------
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        for i in range(args.steps):
+            step(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)            # events on the stream the kernels were launched on
+    if dist:
+        tt = torch.tensor([wall, dev_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tt[0]), float(tt[1])
+
+    value = elems * args.steps * world / wall
+    launch_us = dev_ms * 1e3 / args.steps
+    achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+
+    # parity spot check inside the bench (cheap): last output vs the oracle on rank 0
+    result = {
+        "metric": "elems/s + achieved HBM GB/s, per-channel symmetric 4096×4096 fp32",
+        "value": value,
+        "unit": "elems/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (portable splitmix64 generator, mct_quantizers_amd/workloads.py)",
+        "config": {"workload": wl.name, "shape": list(wl.shape), "quantizer": wl.quantizer,
+                   "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
+                   "launch": "hipGraph" if graph is not None else "eager",
+                   "parallelism": f"replicated x{world} (weak, no collective)"},
+        "achieved_gbs": achieved,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                     "traffic": None, "kernel_us": launch_us, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+    if args.gather and dist:
+        shard = ys[(args.steps - 1) % ring]
+        full = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), device="cuda", dtype=shard.dtype)
+        for _ in range(3):
+            dist.all_gather_into_tensor(full, shard)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, shard)
+        torch.cuda.synchronize()
+        g = (time.perf_counter() - g0) / reps
+        result["allgather"] = {"ms": g * 1e3, "bytes_received_per_rank": shard.numel() * 4 * (world - 1),
+                               "gbs_per_rank": shard.numel() * 4 * (world - 1) / g / 1e9}
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import torch_cpu
+        f = torch_cpu.prepare(wl.quantizer, wl.kwargs)
+        x_cpu = torch.from_numpy(x_np)
+        threads = os.cpu_count() or 1
+        torch.set_num_threads(threads)
+        y_cpu = f(x_cpu)                                   # warm-up + parity reference
+        same = bool(torch.equal(ys[(args.steps - 1) % ring].cpu(), y_cpu))
+        n, c0 = 0, time.perf_counter()
+        while True:
+            f(x_cpu)
+            n += 1
+            el = time.perf_counter() - c0
+            if el >= args.cpu_seconds or n >= 200:
+                break
+        result["cpu_baseline"] = {"value": elems * n / el, "unit": "elems/s", "cores": torch.get_num_threads(),
+                                  "kind": "port",
+                                  "sample": f"{n} calls of the same {wl.name} tensor through the ATen CPU operator the "
+                                            f"reference calls (oracle/torch_cpu.py), {el:.1f} s",
+                                  "ms_per_call": el * 1e3 / n, "gpu_output_bit_equal": same}
+        if not same:
+            result["parity_error"] = "GPU output differs from the CPU oracle"
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist:
+        dist.destroy_process_group()
+    if rank == 0 and result.get("parity_error"):
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -95,10 +95,15 @@ class BaseUniformInferableQuantizer(BasePyTorchInferableQuantizer):
         for _min, _max in zip(min_range, max_range):
             assert _min < _max, f"Max range must be greater than min value but min is {_min} and max is {_max}"
 
+        # Parameter math runs in float32 on the HOST and only the results move to the working device:
+        # ATen's GPU kernels evaluate tensor / python_scalar as tensor * (1 / scalar), which can differ
+        # from the CPU result by one ulp, and the parameters must not depend on the machine.
+        lo = torch.from_numpy(np.asarray(min_range).astype(np.float32))
+        hi = torch.from_numpy(np.asarray(max_range).astype(np.float32))
+        lo, hi = fix_range_to_include_zero(lo, hi, num_bits)
+        self._min_range_host, self._max_range_host = lo, hi
         dev = get_working_device()
-        lo = to_torch_tensor(np.asarray(min_range)).to(dev)
-        hi = to_torch_tensor(np.asarray(max_range)).to(dev)
-        self.min_range, self.max_range = fix_range_to_include_zero(lo, hi, num_bits)
+        self.min_range, self.max_range = lo.to(dev), hi.to(dev)
         self.num_bits = num_bits
         self.min_quantized_domain = 0
         self.max_quantized_domain = 2 ** num_bits - 1
@@ -187,15 +192,18 @@ class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferable
         self.per_channel = per_channel
         self.channel_axis = channel_axis
 
-        self.adjusted_min_range_np = self.min_range.cpu().numpy()
-        self.adjusted_max_range_np = self.max_range.cpu().numpy()
+        lo, hi = self._min_range_host, self._max_range_host
+        self.adjusted_min_range_np = lo.numpy()
+        self.adjusted_max_range_np = hi.numpy()
 
+        # step of the grid, and the (positive) zero point: TRUNCATION of min/scale, negated (host float32)
+        scales = (hi - lo) / (2 ** num_bits - 1)
+        zero_points = -(lo / scales).int()
+        self._scale0 = float(scales.reshape(-1)[0].item())
+        self._zp0 = int(zero_points.reshape(-1)[0].item())
         dev = get_working_device()
-        # step of the grid, and the (positive) zero point: TRUNCATION of min/scale, negated
-        self.scales = ((self.max_range - self.min_range) / (2 ** num_bits - 1)).to(dev)
-        self.zero_points = (-(self.min_range / self.scales).int()).to(dev)
-        self._scale0 = float(self.scales.reshape(-1)[0].item())
-        self._zp0 = int(self.zero_points.reshape(-1)[0].item())
+        self.scales = scales.to(dev)
+        self.zero_points = zero_points.to(dev)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached():
@@ -249,8 +257,8 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
                                      f'should be of length 1 but is {len(min_range)}')
         assert len(max_range) == 1, ('For activation, only per-tensor quantization is supported. Thus, max_range '
                                      f'should be of length 1 but is {len(max_range)}')
-        self.min_range = self.min_range[0].cpu().item()
-        self.max_range = self.max_range[0].cpu().item()
+        self.min_range = self._min_range_host[0].item()
+        self.max_range = self._max_range_host[0].item()
         self.scale = float((self.max_range - self.min_range) / ((2 ** num_bits) - 1))
         self.zero_point = int(-np.round(self.min_range / self.scale))   # round half even, in double
 

@@ -1,0 +1,352 @@
+"""Parity of the gfx950 kernels with the oracle / the reference goldens.  Needs an MI355X: -m gpu.
+
+Bar: bit-exact float32 outputs (hence bit-exact integer clamp indices and LUT indices) on finite
+inputs with |x/scale| < 2**31.  Everything here reaches the kernels through the C ABI
+(ctypes -> libmctq_hip.so), either directly or via the quantizer classes.
+"""
+import ctypes
+import hashlib
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal, first_mismatch, load_json
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mct_quantizers_amd.hip import native
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return native.load()          # raises if the .so is missing: no silent fallback
+
+
+def _dev(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------
+# 1. golden fixtures (generated from the reference) through the public quantizer classes
+# ---------------------------------------------------------------------------------------------
+
+def test_golden_cases_via_quantizer_classes(lib, golden_cases):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    cases, arrays = golden_cases
+    for c in cases:
+        x_np = arrays[c["id"] + "_x"]
+        want = arrays[c["id"] + "_y"]
+        x = _dev(x_np)
+        if c["memory_format"] == "channels_last":
+            x = x.contiguous(memory_format=torch.channels_last)
+        elif c["memory_format"] == "transposed":
+            x = x.transpose(0, -1).contiguous().transpose(0, -1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(Q, c["cls"])(**c["kwargs"])
+        y = q(x)
+        assert y.is_cuda and y.shape == x.shape and y.dtype == torch.float32
+        if "LUT" not in c["cls"] and "Lut" not in c["cls"]:
+            assert y.stride() == x.stride(), c["id"]           # ATen keeps the input's strides
+        got = y.cpu().numpy()
+        assert bits_equal(got, want), f'{c["id"]} {c["cls"]} {c["shape"]} {c["memory_format"]}: ' \
+                                      f'{first_mismatch(got, want, x_np)}'
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. raw C-ABI calls vs the oracle: every launch shape, alignment and tail
+# ---------------------------------------------------------------------------------------------
+
+def _tie_heavy(rng, shape, s_b, zp_b, qmin, qmax):
+    """Inputs dense in round-half ties and clamp edges of their own channel's grid."""
+    n = int(np.prod(shape))
+    x = (rng.standard_normal(n).astype(np.float32).reshape(shape) * s_b * np.float32(0.4 * (qmax - qmin)))
+    k = rng.integers(qmin - 2, qmax + 3, size=shape).astype(np.float32) - zp_b
+    kind = rng.integers(0, 6, size=shape)
+    x = np.where(kind == 0, (k + np.float32(0.5)) * s_b, x)
+    x = np.where(kind == 1, k * s_b, x)
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 1024, 4096 + 7, 256 * 4 * 4 * 3 + 1, 1 << 20])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_abi_per_tensor_vs_oracle(lib, n, offset):
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(n * 2 + offset)
+    scale, zp, qmin, qmax = np.float32(0.0371), 17, 0, 255
+    x_np = _tie_heavy(rng, (n + offset,), scale, np.float32(zp), qmin, qmax)
+    xb = _dev(x_np)
+    yb = torch.full_like(xb, 777.0)
+    x = xb[offset:]
+    y = yb[offset:]
+    rc = lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), n, float(scale), zp, qmin, qmax, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want = O.fake_quant_affine(x_np[offset:], scale, zp, qmin, qmax)
+    got = yb.cpu().numpy()
+    assert bits_equal(got[offset:], want), first_mismatch(got[offset:], want, x_np[offset:])
+    if offset:
+        assert got[0] == 777.0                                   # nothing written outside [offset, offset+n)
+
+
+CHANNEL_SHAPES = [
+    # (outer, C, inner)
+    (1, 1, 1), (1, 3, 1), (7, 3, 1), (1000, 3, 1), (33, 5, 2), (9, 4, 3), (2, 16, 4), (5, 7, 5),
+    (3, 64, 12), (2, 8, 100), (1, 300, 576), (4, 6, 1020), (2, 6, 1024), (3, 5, 1028), (1, 64, 4096),
+    (2, 3, 11008), (1, 5000, 7), (1, 20000, 1), (3, 1, 5000), (1, 2, 70000), (1, 1, 4099),
+]
+
+
+@pytest.mark.parametrize("outer,C,inner", CHANNEL_SHAPES)
+@pytest.mark.parametrize("offset", [0, 3])
+def test_abi_per_channel_vs_oracle(lib, outer, C, inner, offset):
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(outer * 1315423911 % 100003 + C * 7 + inner + offset)
+    bits = int(rng.choice([2, 4, 8]))
+    qmin, qmax = 0, 2 ** bits - 1
+    scales = rng.uniform(0.01, 0.9, size=C).astype(np.float32)
+    zps = rng.integers(qmin, qmax + 1, size=C).astype(np.int32)
+    shape = (outer, C, inner)
+    x_np = _tie_heavy(rng, shape, scales.reshape(1, C, 1), zps.reshape(1, C, 1).astype(np.float32), qmin, qmax)
+    n = x_np.size
+    xb = torch.empty(n + offset, dtype=torch.float32, device="cuda")
+    xb[offset:] = _dev(x_np.reshape(-1))
+    yb = torch.full_like(xb, 777.0)
+    s_d, z_d = _dev(scales), _dev(zps)
+    rc = lib.mctq_fq_per_channel_f32(xb[offset:].data_ptr(), yb[offset:].data_ptr(), outer, C, inner,
+                                     s_d.data_ptr(), z_d.data_ptr(), qmin, qmax, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want, q_want = O.fake_quant_affine(x_np, scales, zps, qmin, qmax, axis=1, return_index=True)
+    got = yb.cpu().numpy()
+    assert bits_equal(got[offset:].reshape(shape), want), first_mismatch(got[offset:], want, x_np)
+    if offset:
+        assert np.all(got[:offset] == 777.0)
+    # integer clamp index recovered from the output equals the oracle's index
+    q_got = np.rint(got[offset:].reshape(shape) / scales.reshape(1, C, 1)).astype(np.int64) + zps.reshape(1, C, 1)
+    assert np.array_equal(q_got, q_want)
+
+
+LUTS = {
+    "l2": [-5.0, 5.0],
+    "l3dup": [3.0, 3.0, -8.0],
+    "l8": [22.0, -53.0, 62.0, 0.0, -66.0, -21.0, 44.0, -40.0],
+    "l16": [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0],
+    "l40": [float(v) for v in np.random.default_rng(5).permutation(np.arange(-128, 128))[:40]],
+    "l256": [float(v) for v in np.random.default_rng(6).permutation(np.arange(-128, 128))],
+}
+
+
+def _lut_inputs(rng, shape, thr_b):
+    x = rng.standard_normal(int(np.prod(shape))).astype(np.float32).reshape(shape) * thr_b * np.float32(0.6)
+    mid = (rng.integers(-130, 130, size=shape).astype(np.float32) + np.float32(0.5)) / np.float32(128.0) * thr_b
+    x = np.where(rng.integers(0, 4, size=shape) == 0, mid, x).astype(np.float32)
+    flat = x.reshape(-1)
+    if flat.size >= 8:
+        flat[:8] = np.asarray([0.0, -0.0, 1e-9, -1e-9, 1e-39, 3e5, -3e5, 1e30], dtype=np.float32)
+    return x
+
+
+@pytest.mark.parametrize("lut_name", list(LUTS))
+@pytest.mark.parametrize("n,offset", [(0, 0), (5, 0), (4096 + 3, 0), (100000, 1)])
+def test_abi_lut_per_tensor_vs_oracle(lib, lut_name, n, offset):
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(n + len(lut_name))
+    lut = LUTS[lut_name]
+    thr = 2.0
+    x_np = _lut_inputs(rng, (n + offset,), np.float32(thr))
+    xb, lut_d = _dev(x_np), _dev(np.asarray(lut, dtype=np.float32))
+    yb = torch.full_like(xb, 777.0)
+    thr_div = float(np.float32(thr + 1e-8))
+    rc = lib.mctq_lut_per_tensor_f32(xb[offset:].data_ptr(), yb[offset:].data_ptr(), n, thr_div, thr,
+                                     lut_d.data_ptr(), len(lut), 128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want = O.lut_quantize(x_np[offset:], lut, thr, True, 8, 1e-8)
+    got = yb.cpu().numpy()
+    assert bits_equal(got[offset:], want), first_mismatch(got[offset:], want, x_np[offset:])
+
+
+@pytest.mark.parametrize("lut_name", ["l3dup", "l16", "l40", "l256"])
+@pytest.mark.parametrize("outer,C,inner", [(1, 3, 1), (50, 3, 1), (4, 6, 5), (2, 8, 100), (2, 6, 1024), (3, 5, 1028),
+                                           (1, 16, 11008), (1, 3000, 3)])
+def test_abi_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(C * 31 + inner)
+    lut = LUTS[lut_name]
+    thr = rng.uniform(0.05, 4.0, size=C).astype(np.float32)
+    shape = (outer, C, inner)
+    x_np = _lut_inputs(rng, shape, thr.reshape(1, C, 1))
+    x, t_d, lut_d = _dev(x_np), _dev(thr), _dev(np.asarray(lut, dtype=np.float32))
+    y = torch.empty_like(x)
+    rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, C, inner, t_d.data_ptr(), 1e-8,
+                                      lut_d.data_ptr(), len(lut), 128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want, idx_want = O.lut_quantize(x_np, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=1,
+                                    return_index=True)
+    got = y.cpu().numpy()
+    assert bits_equal(got, want), first_mismatch(got, want, x_np)
+    # LUT index parity: the chosen centre is lut[idx_want] for every element
+    centres = np.asarray(lut, dtype=np.float32)[idx_want] / np.float32(128.0) * thr.reshape(1, C, 1)
+    assert bits_equal(got, centres.astype(np.float32))
+
+
+def test_abi_argument_errors(lib):
+    x = torch.zeros(16, device="cuda")
+    y = torch.zeros(16, device="cuda")
+    assert lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), -1, 1.0, 0, 0, 255, None) == -10001
+    assert b"n < 0" in lib.mctq_last_error()
+    assert lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), 16, 1.0, 0, 5, 4, None) == -10001
+    assert lib.mctq_fq_per_tensor_f32(None, y.data_ptr(), 16, 1.0, 0, 0, 255, None) == -10001
+    assert lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), 16, 1.0, 1.0, None, 4, 128.0, -128.0, 127.0,
+                                       None) == -10001
+    assert lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), 16, 1.0, 1.0, x.data_ptr(), 4, 100.0, -128.0,
+                                       127.0, None) == -10001
+    assert lib.mctq_set_tuning(b"bogus", 1) == -10001
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. the five BASELINE configurations at full size: SHA-256 equals the REFERENCE's output digest
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_full_size_config_matches_reference_digest(lib, cfg):
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd import workloads
+    rec = load_json("full_sha.json")["configs"][cfg]
+    x_np = workloads.make_input(cfg, batch=8)
+    assert list(x_np.shape) == rec["shape"]
+    assert hashlib.sha256(x_np.tobytes()).hexdigest() == rec["x_sha256"]
+    wl = workloads.make_workload(cfg, x_np)
+    q = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
+    x = _dev(x_np)
+    y = q(x)
+    y_np = y.cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(y_np).tobytes()).hexdigest() == rec["y_sha256"]
+    # size-independent properties
+    if "LUT" not in wl.quantizer:
+        y2 = q(y.clone())
+        assert torch.equal(y2, y), "fake-quant must be idempotent"
+        row = y_np.reshape(y_np.shape[0], -1)[0]
+        assert np.unique(row).size <= 2 ** wl.kwargs["num_bits"]
+    else:
+        row = y_np[0]
+        thr0 = np.float32(wl.kwargs["threshold"][0])
+        allowed = np.asarray(wl.kwargs["lut_values"], dtype=np.float32) / np.float32(128.0) * thr0
+        assert np.all(np.isin(row, allowed))
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. behaviour around the kernels: tuning variants, streams, graphs, side effects, errors
+# ---------------------------------------------------------------------------------------------
+
+def test_tuning_variants_do_not_change_results(lib):
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(11)
+    C, inner = 37, 2052
+    scales = rng.uniform(0.01, 0.5, size=C).astype(np.float32)
+    zps = np.zeros(C, dtype=np.int32)
+    x_np = _tie_heavy(rng, (C, inner), scales.reshape(C, 1), np.float32(0), -128, 127)
+    want = O.fake_quant_affine(x_np, scales, zps, -128, 127, axis=0)
+    x, s_d, z_d = _dev(x_np), _dev(scales), _dev(zps)
+    try:
+        for nt in (0, 1):
+            for unroll in (1, 2, 4, 8):
+                native.set_tuning("nt", nt)
+                native.set_tuning("unroll", unroll)
+                y = torch.empty_like(x)
+                rc = lib.mctq_fq_per_channel_f32(x.data_ptr(), y.data_ptr(), 1, C, inner, s_d.data_ptr(),
+                                                 z_d.data_ptr(), -128, 127, _stream())
+                assert rc == 0
+                assert bits_equal(y.cpu().numpy(), want), (nt, unroll)
+                y = torch.empty_like(x)
+                rc = lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(scales[0]), 3, 0, 255,
+                                                _stream())
+                assert rc == 0
+                assert bits_equal(y.cpu().numpy(), O.fake_quant_affine(x_np, scales[0], 3, 0, 255)), (nt, unroll)
+    finally:
+        native.set_tuning("nt", 1)
+        native.set_tuning("unroll", 4)
+
+
+def test_side_stream_and_graph_capture(lib):
+    import mct_quantizers_amd as mq
+    q = mq.pytorch_quantizers.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    ref = q(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y = q(x)
+    side.synchronize()
+    assert torch.equal(y, ref)
+    # hipGraph: capture once, replay on new data
+    static_x = x.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_y = q(static_x)
+    x2 = torch.randn_like(x)
+    static_x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_y, q(x2))
+
+
+def test_weights_quantizer_side_effects_and_reuse(lib):
+    import mct_quantizers_amd as mq
+    q = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0, 0.5], True, 0)
+    w = torch.nn.Parameter(torch.randn(3, 50, device="cuda"))
+    assert w.requires_grad
+    y = q(w)
+    assert not w.requires_grad and not y.requires_grad        # reference flips requires_grad on the input
+    q.enable_reuse_quantizer()
+    a = q(w)
+    b = q(torch.zeros_like(w))
+    assert b is a and q.resue_outputs is a and not q.quantizer_first_run
+    q.disable_reuse_quantizer()
+    assert q(torch.zeros_like(w)).abs().sum().item() == 0.0
+
+
+def test_activation_quantizer_runs_without_grad(lib):
+    import mct_quantizers_amd as mq
+    q = mq.pytorch_quantizers.ActivationSymmetricInferableQuantizer(8, [4.0], True)
+    x = torch.randn(4, 16, device="cuda", requires_grad=True)
+    y = q(x)
+    assert not y.requires_grad and x.requires_grad
+
+
+def test_non_dense_and_permuted_inputs(lib):
+    import mct_quantizers_amd as mq
+    from oracle import oracle_call
+    kw = dict(num_bits=4, threshold=[0.5, 1.0, 2.0, 4.0], per_channel=True, channel_axis=1)
+    q = mq.pytorch_quantizers.WeightsPOTInferableQuantizer(**kw)
+    base = torch.randn(6, 4, 10, 12, device="cuda")
+    want = oracle_call("WeightsPOTInferableQuantizer", kw, base.cpu().numpy())
+    for x in (base, base.contiguous(memory_format=torch.channels_last), base.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)):
+        y = q(x.clone(memory_format=torch.preserve_format))
+        assert y.stride() == x.stride()
+        assert bits_equal(y.cpu().numpy(), want)
+    sliced = base[:, :, ::2, :]                                # gaps: not dense -> compacted
+    want_s = oracle_call("WeightsPOTInferableQuantizer", kw, sliced.cpu().numpy())
+    assert bits_equal(q(sliced).cpu().numpy(), want_s)
+
+
+def test_loud_failures(lib, monkeypatch):
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    q = mq.pytorch_quantizers.ActivationSymmetricInferableQuantizer(8, [4.0], True)
+    with pytest.raises(NotImplementedError):
+        q(torch.zeros(8, device="cuda", dtype=torch.float64))
+    qc = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0], True, 0)
+    with pytest.raises(RuntimeError):
+        qc(torch.zeros(3, 4, device="cuda"))                   # 2 scales for 3 channels
+    # a missing library is an error, never a silent fallback
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setenv("MCTQ_HIP_LIB", "/nonexistent/libmctq_hip.so")
+    with pytest.raises(native.NativeLibraryError):
+        q(torch.zeros(8, device="cuda"))

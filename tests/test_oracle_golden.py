@@ -1,0 +1,141 @@
+"""The oracle (oracle/mctq_oracle.py) against the fixtures generated from the reference.
+
+This pins the oracle: every case in tests/golden/cases.* was produced by importing
+sony/mct_quantizers from /root/reference (tools/gen_golden.py).  CPU only.
+"""
+import hashlib
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, first_mismatch, load_json
+from oracle import mctq_oracle as O
+from oracle import oracle_call
+
+
+def test_every_golden_case_bit_exact(golden_cases):
+    cases, arrays = golden_cases
+    assert len(cases) >= 100
+    for c in cases:
+        x = arrays[c["id"] + "_x"]
+        want = arrays[c["id"] + "_y"]
+        got = oracle_call(c["cls"], c["kwargs"], x)
+        assert bits_equal(got, want), f'{c["id"]} {c["cls"]} {c["kwargs"].get("num_bits")}b: ' \
+                                      f'{first_mismatch(got, want, x)}'
+
+
+def test_constructor_goldens():
+    for rec in load_json("ctor.json")["ctor"]:
+        cls, kw, attrs = rec["cls"], rec["kwargs"], rec["attrs"]
+        nb = kw["num_bits"]
+        if cls in ("WeightsSymmetricInferableQuantizer", "WeightsPOTInferableQuantizer"):
+            s, z, qmin, qmax = O.weights_symmetric_params(nb, kw["threshold"])
+            assert np.array_equal(s, np.asarray(attrs["scales"]["values"], dtype=np.float32))
+            assert np.array_equal(z, np.asarray(attrs["zero_points"]["values"], dtype=np.int32))
+            assert (qmin, qmax) == (attrs["min_quantized_domain"], attrs["max_quantized_domain"])
+        elif cls == "ActivationSymmetricInferableQuantizer":
+            s, z, qmin, qmax = O.activation_symmetric_params(nb, kw["threshold"], kw["signed"])
+            assert s == attrs["scales"] and z == attrs["zero_points"]
+            assert (qmin, qmax) == (attrs["min_quantized_domain"], attrs["max_quantized_domain"])
+        elif cls == "WeightsUniformInferableQuantizer":
+            s, z, qmin, qmax, a, b = O.weights_uniform_params(nb, kw["min_range"], kw["max_range"])
+            assert bits_equal(s, np.asarray(attrs["scales"]["values"], dtype=np.float32))
+            assert np.array_equal(z, np.asarray(attrs["zero_points"]["values"], dtype=np.int32))
+            assert bits_equal(a, np.asarray(attrs["adjusted_min_range_np"]["values"], dtype=np.float32))
+            assert bits_equal(b, np.asarray(attrs["adjusted_max_range_np"]["values"], dtype=np.float32))
+            assert (qmin, qmax) == (0, 2 ** nb - 1)
+        elif cls == "ActivationUniformInferableQuantizer":
+            s, z, qmin, qmax, a, b = O.activation_uniform_params(nb, kw["min_range"], kw["max_range"])
+            assert (s, z, a, b) == (attrs["scale"], attrs["zero_point"], attrs["min_range"], attrs["max_range"])
+        else:
+            raise AssertionError(cls)
+
+
+def test_weights_uniform_zero_point_is_truncation_not_rounding():
+    # -trunc(a/s) != rint(-a/s) for a few percent of random channels
+    differ = 0
+    for rec in load_json("ctor.json")["ctor"]:
+        if rec["cls"] != "WeightsUniformInferableQuantizer":
+            continue
+        s, z, _, _, a, _ = O.weights_uniform_params(rec["kwargs"]["num_bits"], rec["kwargs"]["min_range"],
+                                                    rec["kwargs"]["max_range"])
+        differ += int(np.sum(z != np.rint(-a / s).astype(np.int32)))
+    assert differ > 0
+
+
+def test_known_answer_range_fix_constants():
+    # literal constants of the reference tests (test_fln_activation_quantizer_holder.py:42,45)
+    s, z, _, _, a, b = O.activation_uniform_params(7, [-4.0], [4.0])
+    assert np.isclose(a, -4.03149606299213, atol=1e-6) and np.isclose(b, 3.96850393700787, atol=1e-6)
+    assert np.isclose(s, 0.062992125984252, atol=1e-8)
+    s, z, _, _, a, b = O.activation_uniform_params(5, [-3.0], [3.0])
+    assert np.isclose(a, -3.09677419354839, atol=1e-6) and np.isclose(b, 2.90322580645161, atol=1e-6)
+    assert np.isclose(s, 0.193548387096774, atol=1e-7)
+    # SURVEY §8(d) cfg3 probe
+    s, z, _, _, a, b = O.activation_uniform_params(8, [-2.5], [3.1])
+    assert z == 114 and np.isclose(s, 0.021960784, atol=1e-9)
+
+
+def test_half_to_even_and_reciprocal_multiply():
+    # ties go to the even integer: x/s = 0.5, 1.5, 2.5, ...
+    x = np.asarray([0.25, 0.75, 1.25, -0.25, -0.75, -1.25], dtype=np.float32)
+    y, q = O.fake_quant_affine(x, 0.5, 0, -128, 127, return_index=True)
+    assert q.tolist() == [0, 2, 2, 0, -2, -2]
+    # x*(1/s) and x/s disagree on some tie inputs at s = 1/127: the oracle must follow the reciprocal form
+    s = np.float32(1.0 / 127.0)
+    xs = ((np.arange(-5000, 5000, dtype=np.float32) + np.float32(0.5)) * s).astype(np.float32)
+    inv = np.float32(1.0) / s
+    assert np.any(np.rint(xs * inv) != np.rint(xs / s))
+    _, q = O.fake_quant_affine(xs, s, 0, -2 ** 20, 2 ** 20, return_index=True)
+    assert np.array_equal(q, np.rint(xs * inv).astype(np.int64))
+
+
+def test_lut_first_minimum_and_specials():
+    lut = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+    # threshold 128 -> t == x: App. A.4 probes
+    x = np.asarray([8.5, -8.5, 200.0, np.nan], dtype=np.float32)
+    y, idx = O.lut_quantize(x, lut, np.asarray([128.0], dtype=np.float32), True, 8, 0.0, return_index=True)
+    assert y[:3].tolist() == [5.0, -12.0, 127.0]
+    assert idx[3] == 0 and y[3] == -128.0
+    # rounding-dependent tie: both distances round to 5.0 -> first index
+    y, idx = O.lut_quantize(np.asarray([1e-9], dtype=np.float32), [-5.0, 5.0], np.asarray([128.0], np.float32),
+                            True, 8, 0.0, return_index=True)
+    assert idx[0] == 0
+
+
+def test_error_messages_match_reference():
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    for rec in load_json("errors.json")["errors"]:
+        kw = rec["kwargs"]
+        if not isinstance(kw, dict):
+            continue
+        with pytest.raises(AssertionError) as e, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            getattr(Q, rec["cls"])(**kw)
+        assert str(e.value) == rec["msg"], (rec["cls"], kw)
+    # non-list arguments
+    expect = {r["kwargs"]: r["msg"] for r in load_json("errors.json")["errors"] if isinstance(r["kwargs"], str)}
+    with pytest.raises(AssertionError) as e:
+        Q.WeightsSymmetricInferableQuantizer(num_bits=8, threshold=np.asarray([2.0]), per_channel=False)
+    assert str(e.value) == expect["threshold=np.asarray([2.0])"]
+    with pytest.raises(AssertionError) as e:
+        Q.ActivationUniformInferableQuantizer(num_bits=8, min_range=np.asarray([0.0]), max_range=[1.0])
+    assert str(e.value) == expect["min_range=np.asarray([0.0]), max_range=[1.0]"]
+    with pytest.raises(AssertionError) as e:
+        Q.WeightsLUTSymmetricInferableQuantizer(num_bits=3, lut_values=np.asarray([-25.0, 25.0]), threshold=[2.0],
+                                                per_channel=False)
+    assert str(e.value) == expect["lut_values=np.asarray([-25, 25])"]
+
+
+def test_portable_generator_digests():
+    """The synthetic inputs are the same bits everywhere (digests recorded next to the reference outputs)."""
+    from mct_quantizers_amd import workloads
+    full = load_json("full_sha.json")["configs"]
+    for cfg in ("cfg1", "cfg3"):
+        x = workloads.make_input(cfg, batch=8)
+        assert hashlib.sha256(x.tobytes()).hexdigest() == full[cfg]["x_sha256"]
+        wl = workloads.make_workload(cfg, x)
+        y = oracle_call(wl.quantizer, wl.kwargs, x)
+        assert hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest() == full[cfg]["y_sha256"]
