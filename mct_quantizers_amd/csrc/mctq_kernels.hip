@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void flat_kernel(Op op, typename Op::Para
   f4* __restrict__ y = reinterpret_cast<f4*>(ys);
   const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
   f4 v[U];
-  if (base - threadIdx.x + kThreads * U <= n4) {          // full tile: no per-lane guards
+  if (((int64_t)blockIdx.x + 1) * (kThreads * U) <= n4) {   // full tile (wave-uniform test): no per-lane guards
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = ld4<NT>(x + base + u * kThreads);
 #pragma unroll
@@ -236,26 +236,38 @@ template <class Op, int U, bool NT>
 __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const float* __restrict__ xs, float* __restrict__ ys,
                                                         uint32_t tiles_per_row, uint32_t inner4, uint32_t channels) {
   extern __shared__ float smem[];
-  const typename Op::Book book = op.setup(smem);
-  const uint32_t row = blockIdx.x / tiles_per_row;
-  const uint32_t tile = blockIdx.x - row * tiles_per_row;
-  const typename Op::Param p = op.fetch(row % channels);
+  uint32_t row = blockIdx.x, tile = 0;
+  if (tiles_per_row != 1) {                                // uniform branch: skip the division for 1 tile/row
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x - row * tiles_per_row;
+  }
   const int64_t rbase = (int64_t)row * inner4;
   const f4* __restrict__ x = reinterpret_cast<const f4*>(xs) + rbase;
   f4* __restrict__ y = reinterpret_cast<f4*>(ys) + rbase;
   const uint32_t col = tile * (kThreads * U) + threadIdx.x;
+  const bool full = (tile + 1) * (kThreads * U) <= inner4;     // wave-uniform
   f4 v[U];
-  if (col - threadIdx.x + kThreads * U <= inner4) {
+  // Issue the data loads FIRST; the parameter fetch (two dependent scalar loads + an IEEE divide)
+  // and the codebook set-up then run in the shadow of the HBM latency.
+  if (full) {
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = ld4<NT>(x + col + u * kThreads);
-#pragma unroll
-    for (int u = 0; u < U; ++u) st4<NT>(y + col + u * kThreads, apply4(op, v[u], p, book));
   } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = col + u * kThreads;
       if (i < inner4) v[u] = ld4<NT>(x + i);
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);                       // keep the loads above the fetch in the schedule
+  const typename Op::Book book = op.setup(smem);
+  uint32_t c = row;
+  if (c >= channels) c = row % channels;                   // uniform; outer == 1 needs no modulo
+  const typename Op::Param p = op.fetch(c);
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) st4<NT>(y + col + u * kThreads, apply4(op, v[u], p, book));
+  } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = col + u * kThreads;

@@ -1,0 +1,232 @@
+"""Host-side behaviour of the drop-in API on CPU tensors (no GPU): constructors, registry, reuse
+cache, containers, fx trace + pickle round trips.  Modelled on the reference's own unit tests
+(tests/pytorch_tests/**), with the golden fixtures supplying the expected numbers."""
+import io
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import mct_quantizers_amd as mq
+from conftest import bits_equal, first_mismatch, load_json
+from mct_quantizers_amd import (PytorchActivationQuantizationHolder, PytorchFLNActivationQuantizationHolder,
+                                PytorchPreservingActivationQuantizationHolder, PytorchQuantizationWrapper,
+                                QuantizationMethod, QuantizationTarget, get_inferable_quantizer_class)
+
+Q = mq.pytorch_quantizers
+
+
+def test_cpu_tensors_take_the_aten_route_and_match_goldens(golden_cases):
+    """BASELINE config 1 plumbing: a CPU tensor gets exactly what the reference gives it."""
+    cases, arrays = golden_cases
+    for c in cases:
+        x = torch.from_numpy(arrays[c["id"] + "_x"])
+        if c["memory_format"] == "channels_last":
+            x = x.contiguous(memory_format=torch.channels_last)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(Q, c["cls"])(**c["kwargs"])
+        got = q(x).numpy()
+        want = arrays[c["id"] + "_y"]
+        assert bits_equal(got, want), f'{c["id"]} {c["cls"]}: {first_mismatch(got, want)}'
+
+
+def test_constructor_attributes_match_reference():
+    for rec in load_json("ctor.json")["ctor"]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(Q, rec["cls"])(**rec["kwargs"])
+        for name, want in rec["attrs"].items():
+            got = getattr(q, name)
+            if isinstance(want, dict):
+                vals = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+                assert str(vals.dtype) in want["dtype"], (rec["cls"], name, vals.dtype, want["dtype"])
+                assert np.array_equal(vals.reshape(-1).astype(np.float64), np.asarray(want["values"])), (rec["cls"], name)
+            else:
+                assert got == want, (rec["cls"], name, got, want)
+
+
+def test_registry_finds_exactly_one_class_per_target_and_method():
+    base = Q.BasePyTorchInferableQuantizer
+    expect = {
+        (QuantizationTarget.Weights, QuantizationMethod.SYMMETRIC): Q.WeightsSymmetricInferableQuantizer,
+        (QuantizationTarget.Weights, QuantizationMethod.POWER_OF_TWO): Q.WeightsPOTInferableQuantizer,
+        (QuantizationTarget.Weights, QuantizationMethod.UNIFORM): Q.WeightsUniformInferableQuantizer,
+        (QuantizationTarget.Weights, QuantizationMethod.LUT_SYM_QUANTIZER): Q.WeightsLUTSymmetricInferableQuantizer,
+        (QuantizationTarget.Weights, QuantizationMethod.LUT_POT_QUANTIZER): Q.WeightsLUTPOTInferableQuantizer,
+        (QuantizationTarget.Activation, QuantizationMethod.SYMMETRIC): Q.ActivationSymmetricInferableQuantizer,
+        (QuantizationTarget.Activation, QuantizationMethod.POWER_OF_TWO): Q.ActivationPOTInferableQuantizer,
+        (QuantizationTarget.Activation, QuantizationMethod.UNIFORM): Q.ActivationUniformInferableQuantizer,
+        (QuantizationTarget.Activation, QuantizationMethod.LUT_POT_QUANTIZER): Q.ActivationLutPOTInferableQuantizer,
+    }
+    for (target, method), cls in expect.items():
+        assert get_inferable_quantizer_class(target, method, base) is cls
+    with pytest.raises(Exception):
+        get_inferable_quantizer_class(QuantizationTarget.Activation, QuantizationMethod.LUT_SYM_QUANTIZER, base)
+
+
+def test_reuse_cache_returns_the_same_object():
+    for q in (Q.WeightsSymmetricInferableQuantizer(8, [1.0], False),
+              Q.WeightsPOTInferableQuantizer(8, [2.0], False),
+              Q.WeightsUniformInferableQuantizer(8, [-1.0], [1.0], False),
+              Q.WeightsLUTSymmetricInferableQuantizer(2, [-25.0, 25.0], [1.0], False),
+              Q.WeightsLUTPOTInferableQuantizer(2, [-25.0, 25.0], [1.0], False)):
+        assert q.resue_outputs is None and q.quantizer_first_run and not q.enable_reuse
+        a = q(torch.randn(4, 4))
+        assert q.resue_outputs is None                      # reuse is off by default
+        q.enable_reuse_quantizer()
+        b = q(torch.randn(4, 4))
+        c = q(torch.randn(4, 4))
+        assert c is b and q.resue_outputs is b and not q.quantizer_first_run
+        q.disable_reuse_quantizer()
+        assert q(torch.randn(4, 4)) is not b
+        assert a is not b
+
+
+def test_weights_quantizers_flip_requires_grad_and_activations_do_not():
+    w = torch.nn.Parameter(torch.randn(3, 8))
+    Q.WeightsSymmetricInferableQuantizer(8, [1.0, 1.0, 1.0], True, 0)(w)
+    assert not w.requires_grad
+    x = torch.randn(3, 8, requires_grad=True)
+    y = Q.ActivationUniformInferableQuantizer(8, [-1.0], [1.0])(x)
+    assert x.requires_grad and not y.requires_grad
+
+
+class _ZeroWeightsQuantizer(mq.BaseInferableQuantizer):
+    def __call__(self, inputs):
+        return inputs * 0
+
+
+def test_wrapper_named_weights():
+    conv = torch.nn.Conv2d(3, 20, 3)
+    wrapper = PytorchQuantizationWrapper(conv, {"weight": _ZeroWeightsQuantizer()})
+    assert wrapper.is_weights_quantization and wrapper.num_weights_quantizers == 1
+    (name, weight, quantizer), = wrapper.get_weights_vars()
+    assert name == "weight" and isinstance(weight, torch.nn.Parameter) and isinstance(quantizer, _ZeroWeightsQuantizer)
+    assert isinstance(wrapper.layer, torch.nn.Conv2d)
+    out = wrapper(torch.randn(1, 3, 8, 8))
+    bias = conv.bias.detach().reshape(1, -1, 1, 1)
+    assert torch.allclose(out, bias.expand_as(out))          # all weights quantized to zero
+    assert torch.all(wrapper.get_quantized_weights()["weight"] == 0)
+
+
+def test_wrapper_positional_weights_and_list_inputs():
+    # torch.sub(const, x)
+    wrapper = PytorchQuantizationWrapper(torch.sub, {0: _ZeroWeightsQuantizer()}, {0: torch.ones(3)})
+    x = torch.tensor([1.0, 2.0, 3.0])
+    assert torch.equal(wrapper(x), -x)
+    assert "positional_weight_0" in dict(wrapper.named_parameters())
+    # torch.cat([c0, x, c2], dim=1)
+    wrapper = PytorchQuantizationWrapper(torch.cat, {0: _ZeroWeightsQuantizer(), 2: _ZeroWeightsQuantizer()},
+                                         {0: torch.ones(2, 1), 2: torch.ones(2, 2)}, op_call_kwargs={"dim": 1},
+                                         is_inputs_as_list=True)
+    out = wrapper(torch.full((2, 3), 7.0))
+    assert out.shape == (2, 6) and torch.all(out[:, 0] == 0) and torch.all(out[:, 1:4] == 7) and torch.all(out[:, 4:] == 0)
+
+
+def test_wrapper_argument_checks_raise():
+    with pytest.raises(Exception, match="should be a torch.Tensor"):
+        PytorchQuantizationWrapper(torch.sub, {0: _ZeroWeightsQuantizer()}, {0: [1.0]})
+    with pytest.raises(Exception, match="keys should be all strings"):
+        PytorchQuantizationWrapper(torch.nn.Linear(2, 2), {0: _ZeroWeightsQuantizer()})
+    with pytest.raises(Exception, match="Mismatch"):
+        PytorchQuantizationWrapper(torch.sub, {1: _ZeroWeightsQuantizer()}, {0: torch.ones(1)})
+
+
+def test_wrapper_with_a_real_quantizer_requantizes_every_forward():
+    lin = torch.nn.Linear(16, 4, bias=False)
+    thr = [float(v) for v in lin.weight.detach().abs().max(dim=1).values]
+    q = Q.WeightsSymmetricInferableQuantizer(4, thr, True, 0)
+    wrapper = PytorchQuantizationWrapper(lin, {"weight": q})
+    x = torch.randn(2, 16)
+    y1 = wrapper(x)
+    wq = wrapper.layer.weight
+    assert torch.unique(wq[0]).numel() <= 16
+    assert torch.equal(y1, x @ wq.t())
+    with torch.no_grad():
+        wrapper.weight.mul_(0.5)                              # float weight changes -> next forward re-quantizes
+    y2 = wrapper(x)
+    assert not torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("holder_cls", [PytorchActivationQuantizationHolder, PytorchFLNActivationQuantizationHolder,
+                                        PytorchPreservingActivationQuantizationHolder])
+def test_holders_quantize_and_bypass(holder_cls):
+    q = Q.ActivationPOTInferableQuantizer(num_bits=3, threshold=[4.0], signed=True)
+    holder = holder_cls(q)
+    x = torch.randn(1, 3, 16, 16) * 3
+    y = holder(x)
+    assert torch.unique(y).numel() <= 8 and y.min() >= -4 and y.max() <= 3
+    assert torch.equal(y, q(x))
+    if holder_cls is not PytorchActivationQuantizationHolder:
+        assert holder.quantization_bypass is False
+        bypass = holder_cls(q, quantization_bypass=True)
+        assert bypass(x) is x
+
+
+@pytest.mark.parametrize("make", [
+    lambda: Q.ActivationUniformInferableQuantizer(3, [-2.0], [2.0]),
+    lambda: Q.ActivationSymmetricInferableQuantizer(8, [3.0], True),
+    lambda: Q.ActivationLutPOTInferableQuantizer(3, [-25.0, 25.0, 100.0], [4.0], True),
+])
+def test_fx_trace_then_pickle_round_trip(make):
+    """reference tests/pytorch_tests/test_activation_quantizer_holder.py:67-90."""
+    holder = PytorchActivationQuantizationHolder(make())
+    x = torch.randn(2, 3, 8, 8)
+    want = holder(x)
+    traced = torch.fx.symbolic_trace(holder)
+    targets = [n.target for n in traced.graph.nodes if n.op == "call_function"]
+    assert any("mctq_amd" in str(t) for t in targets), targets     # one opaque op, routed per device at run time
+    assert torch.equal(traced(x), want)
+    buf = io.BytesIO()
+    torch.save(traced, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    assert torch.equal(loaded(x), want)
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        conv = torch.nn.Conv2d(3, 4, 3)
+        thr = [float(v) for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+        self.conv = PytorchQuantizationWrapper(conv, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)})
+        self.act = PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-1.0], [3.0]))
+        lin = torch.nn.Linear(4, 2)
+        self.lin = PytorchQuantizationWrapper(lin, {"weight": Q.WeightsLUTSymmetricInferableQuantizer(
+            3, [-100.0, -50.0, -10.0, 0.0, 10.0, 50.0, 100.0, 127.0], [1.0], False)})
+
+    def forward(self, x):
+        return self.lin(self.act(self.conv(x)).mean(dim=(2, 3)))
+
+
+def test_whole_module_pickle_round_trip(tmp_path):
+    """reference tests/pytorch_tests/test_pytorch_load_model.py: torch.save(module) / load / same output."""
+    net = _Net()
+    x = torch.randn(2, 3, 10, 10)
+    want = net(x)
+    path = tmp_path / "model.pth"
+    torch.save(net, path)
+    loaded = mq.pytorch_load_quantized_model(path)
+    assert torch.equal(loaded(x), want)
+    pickle.loads(pickle.dumps(net.act.activation_holder_quantizer))        # quantizers hold no ctypes handles
+
+
+def test_utils_surface():
+    from mct_quantizers_amd.pytorch import quantizer_utils as U
+    assert U.get_working_device().type in ("cpu", "cuda")
+    t = U.to_torch_tensor(np.asarray([1.0, 2.0]))
+    assert t.dtype == torch.float32
+    assert U.to_torch_tensor(3).dtype == torch.int32 and U.to_torch_tensor(3.0).dtype == torch.float32
+    assert isinstance(U.to_torch_tensor([np.zeros(2), 1.0]), list)
+    with pytest.raises(Exception):
+        U.to_torch_tensor("nope")
+    lo, hi = U.fix_range_to_include_zero(torch.tensor([-4.0, 3.0, -7.0]), torch.tensor([4.0, 10.0, -1.0]), 7)
+    assert np.isclose(lo[0].item(), -4.03149606299213, atol=1e-6) and np.isclose(hi[0].item(), 3.96850393700787, atol=1e-6)
+    assert lo[1].item() == 0.0 and hi[1].item() == 10.0 and lo[2].item() == -7.0 and hi[2].item() == 0.0
+    # lut_quantizer keeps the reference signature
+    lut = torch.tensor([-25.0, 25.0])
+    y = U.lut_quantizer(torch.tensor([[-1.0, 0.3]]), lut, True, torch.tensor([2.0]), 8, 1e-8)
+    assert torch.allclose(y, torch.tensor([[-25.0 / 128 * 2, 25.0 / 128 * 2]]))
