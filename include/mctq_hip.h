@@ -85,12 +85,59 @@ int mctq_lut_per_channel_f32(const float* x, float* y,
                              void* stream);
 
 /*
+ * Decision-table form of the LUT quantizer (integer codebooks, clip range of at most 1023.5 units).
+ *
+ * The literal scan above costs ~4 VALU ops per codebook entry per element.  For an integer codebook the
+ * result of that scan, as a function of the scaled value t, is a staircase whose steps sit within a few
+ * ulps of the half-integer points clip_min + k/2.  mctq_lut_build_table() -- host code, no GPU -- runs the
+ * literal scan in float32 and records for every point the exact threshold of its step and the dequantized
+ * centres on both sides; the mctq_lutt_* kernels stage that table in LDS and decide each element with one
+ * LDS read, one compare and one select, bit-identically to the literal scan for every float32 input.
+ *
+ *   mctq_lut_table_entries : number K of table points for a clip range (= 2*(clip_max-clip_min)+1), or
+ *                            MCTQ_E_ARG if the range is not integral or too large for LDS.
+ *   mctq_lut_build_table   : lut_host[n_lut] is a HOST array in the caller's list order; table_host receives
+ *                            2*(K+1) 32-bit words: K entries {T_k (float32), half2(q_below, q_above)} and one
+ *                            trailer {q for NaN input (float32), K}.  Fails (MCTQ_E_ARG) for a non-integer
+ *                            codebook; callers then use the literal kernels.
+ *   mctq_lutt_per_tensor_f32 / mctq_lutt_per_channel_f32 : as mctq_lut_per_*_f32, with `table` (DEVICE copy
+ *                            of table_host) and `entries` = K in place of the codebook.
+ */
+int32_t mctq_lut_table_entries(float clip_min, float clip_max);
+
+int mctq_lut_build_table(const float* lut_host, int32_t n_lut, float mult, float clip_min, float clip_max,
+                         float* table_host);
+
+int mctq_lutt_per_tensor_f32(const float* x, float* y, int64_t n,
+                             float thr_div, float thr_mul,
+                             const float* table, int32_t entries,
+                             float mult, float clip_min, float clip_max,
+                             void* stream);
+
+int mctq_lutt_per_channel_f32(const float* x, float* y,
+                              int64_t outer, int64_t channels, int64_t inner,
+                              const float* thresholds, float eps,
+                              const float* table, int32_t entries,
+                              float mult, float clip_min, float clip_max,
+                              void* stream);
+
+/*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.
  *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default set in the library)
  *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
+ *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */
 int mctq_set_tuning(const char* key, int32_t value);
+
+/*
+ * Diagnostic: checks the LUT kernels' shared-divisor division (reciprocal + two exact FMA residual
+ * corrections) against the compiler's IEEE division for ALL 2^32 float32 numerators, for each of
+ * divisors[n_div] (device float32).  mismatches[n_div] (device uint64, zeroed by the caller) receives the
+ * number of numerators whose quotient differs inside the domain where the last bit can matter
+ * (2^-40 <= |x/d| < 2^59); outside it the two results must agree on NaN-ness, sign and saturation.
+ */
+int mctq_selftest_division(const float* divisors, int32_t n_div, uint64_t* mismatches, void* stream);
 
 #ifdef __cplusplus
 }

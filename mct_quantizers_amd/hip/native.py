@@ -30,6 +30,7 @@ SIGNATURES = {
     "mctq_abi_version": (ctypes.c_int, []),
     "mctq_last_error": (ctypes.c_char_p, []),
     "mctq_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
+    "mctq_selftest_division": (ctypes.c_int, [_c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mctq_fq_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mctq_fq_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -40,6 +41,15 @@ SIGNATURES = {
     "mctq_lut_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                 _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+    "mctq_lut_table_entries": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float]),
+    "mctq_lut_build_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_void_p]),
+    "mctq_lutt_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                                _c_f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_void_p]),
+    "mctq_lutt_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                 _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
 }
 
 
@@ -98,3 +108,20 @@ def check(rc: int, what: str):
 
 def set_tuning(key: str, value: int):
     check(load().mctq_set_tuning(key.encode(), int(value)), f"mctq_set_tuning({key}={value})")
+
+
+def build_lut_table(lut_values, mult: float, clip_min: float, clip_max: float):
+    """Host-side decision table for an integer codebook (numpy float32 [K+1, 2]: see include/mctq_hip.h;
+    the second word of an entry is a packed half2 bit pattern), or None when the
+    codebook / clip range does not qualify (the literal kernels are used then)."""
+    import numpy as np
+    lib = load()
+    k = lib.mctq_lut_table_entries(clip_min, clip_max)
+    if k < 0:
+        return None
+    lut = np.ascontiguousarray(np.asarray(lut_values, dtype=np.float32).reshape(-1))
+    table = np.zeros((k + 1, 2), dtype=np.float32)
+    rc = lib.mctq_lut_build_table(lut.ctypes.data, lut.size, mult, clip_min, clip_max, table.ctypes.data)
+    if rc != 0:
+        return None
+    return table

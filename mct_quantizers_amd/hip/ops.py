@@ -133,35 +133,58 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int)
     return y
 
 
-def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float):
+def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None):
     _require_f32(x, "lut_per_tensor")
     lib = native.load()
     x = _dense_input(x)
     y = torch.empty_like(x)
-    lut = lut.contiguous()
     with _on_device(x):
-        rc = lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, thr_mul, lut.data_ptr(),
-                                         lut.numel(), mult, cmin, cmax, _stream(x))
+        if table is not None:
+            rc = lib.mctq_lutt_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, thr_mul,
+                                              table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
+        else:
+            lut = lut.contiguous()
+            rc = lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, thr_mul, lut.data_ptr(),
+                                             lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
         native.check(rc, "mctq_lut_per_tensor_f32")
     return y
 
 
-def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float):
+def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float,
+                         table=None):
     _require_f32(x, "lut_per_channel")
     _check_axis(x, thresholds.numel(), axis)
     lib = native.load()
     x = _dense_input(x)
     y = torch.empty_like(x)
     outer, c, inner = _channel_view(x, axis)
-    lut = lut.contiguous()
     thresholds = thresholds.contiguous()
     with _on_device(x):
-        rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(), eps,
-                                          lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
+        if table is not None:
+            rc = lib.mctq_lutt_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(),
+                                               eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax,
+                                               _stream(x))
+        else:
+            lut = lut.contiguous()
+            rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(),
+                                              eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
         native.check(rc, "mctq_lut_per_channel_f32")
     return y
+
+
+def make_lut_table(lut_values, mult: float, cmin: float, cmax: float, device):
+    """Device copy of the codebook's decision table (see include/mctq_hip.h), or None.
+
+    Built once per quantizer at construction; needs the native library only when a GPU is the
+    working device."""
+    if torch.device(device).type != "cuda":
+        return None
+    table = native.build_lut_table(lut_values, mult, cmin, cmax)
+    if table is None:
+        return None
+    return torch.from_numpy(table).to(device)
 
 
 # ------------------------------------------------------------------------------------------
@@ -238,19 +261,19 @@ def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
     return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
 
 
-def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float):
+def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None):
     if _is_real(x):
         if x.is_cuda:
-            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table)
         if x.device.type == "cpu":
             return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
     return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
 
 
-def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float):
+def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float, table=None):
     if _is_real(x):
         if x.is_cuda:
-            return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
+            return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, table)
         if x.device.type == "cpu":
             return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
     return torch.ops.mctq_amd.lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)

@@ -90,6 +90,8 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         thr0 = np.float32(self._threshold_np.reshape(-1)[0])
         self._thr_mul0 = float(thr0)
         self._thr_div0 = float(thr0 + np.float32(eps))
+        # codebook compiled once into an LDS decision table (None -> literal scan kernels)
+        self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(lut_values_bitwidth, True), dev)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached():
@@ -101,9 +103,10 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
                 raise RuntimeError(f'input_rank={self.input_rank} does not match a tensor of rank {inputs.dim()}')
             axis = self.channel_axis % inputs.dim()
             out = ops.lut_per_channel(inputs, self._lut_values_torch, self._threshold_torch, float(self.eps), axis,
-                                      mult, cmin, cmax)
+                                      mult, cmin, cmax, self._lut_table_torch)
         else:
-            out = ops.lut_per_tensor(inputs, self._lut_values_torch, self._thr_div0, self._thr_mul0, mult, cmin, cmax)
+            out = ops.lut_per_tensor(inputs, self._lut_values_torch, self._thr_div0, self._thr_mul0, mult, cmin, cmax,
+                                     self._lut_table_torch)
         return self._remember(out)
 
 
@@ -140,7 +143,10 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         # Python-float threshold: threshold + eps is a DOUBLE add, narrowed to float32 at the division
         self._thr_mul0 = float(np.float32(self.threshold))
         self._thr_div0 = float(np.float32(float(self.threshold) + eps))
+        self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(lut_values_bitwidth, signed),
+                                                   get_working_device())
 
     def __call__(self, inputs: torch.Tensor):
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
-        return ops.lut_per_tensor(inputs, self.lut_values, self._thr_div0, self._thr_mul0, mult, cmin, cmax)
+        return ops.lut_per_tensor(inputs, self.lut_values, self._thr_div0, self._thr_mul0, mult, cmin, cmax,
+                                  self._lut_table_torch)

@@ -49,3 +49,30 @@ def test_missing_library_is_loud(monkeypatch):
     with pytest.raises(native.NativeLibraryError):
         native.load()
     assert not native.is_available()
+
+
+def test_decision_table_builder_matches_the_oracle_scan():
+    """Host-only: the LDS decision table reproduces the literal first-minimum scan around every boundary."""
+    import numpy as np
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(0)
+    luts = [[-5.0, 5.0], [3.0, 3.0, -8.0], [22.0, -53.0, 62.0, 0.0, -66.0, -21.0, 44.0, -40.0],
+            [float(v) for v in rng.permutation(np.arange(-128, 128))], [7.0], [-1.0, 0.0, 1.0, 2.0, 3.0]]
+    for lut in luts:
+        tab = native.build_lut_table(lut, 128.0, -128.0, 127.0)
+        assert tab is not None and tab.shape == (512, 2)
+        k = rng.integers(-256, 255, size=100000).astype(np.float32) * np.float32(0.5)
+        off = rng.integers(-40, 41, size=k.size).astype(np.int64)
+        b = k.view(np.int32).astype(np.int64)
+        b = np.where(k > 0, b + off, np.where(k < 0, b - off, b))          # walk +-40 ulps around each point
+        t = np.concatenate([b.astype(np.int32).view(np.float32), rng.uniform(-128, 127, 50000).astype(np.float32)])
+        t = np.clip(t, -128, 127).astype(np.float32)
+        want = O.lut_quantize(t, lut, np.asarray([128.0], np.float32), True, 8, 0.0)   # thr=128, eps=0: t == x
+        e = tab[(t * np.float32(2) + np.float32(256.5)).astype(np.int32)]
+        halves = np.ascontiguousarray(e[:, 1]).view(np.float16).reshape(-1, 2).astype(np.float32)   # (below, above)
+        got = np.where(t >= e[:, 0], halves[:, 1], halves[:, 0]) * np.float32(128.0)
+        assert np.array_equal(got, want)
+        assert tab[511, 0] == np.float32(lut[0]) / np.float32(128.0)        # NaN input -> codebook entry 0
+    assert native.build_lut_table([0.5, 1.0], 128.0, -128.0, 127.0) is None          # non-integer codebook
+    assert native.build_lut_table([1.0], 2.0 ** 12, -2048.0, 2047.0) is None         # too wide for LDS

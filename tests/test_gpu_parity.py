@@ -195,6 +195,96 @@ def test_abi_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
     assert bits_equal(got, centres.astype(np.float32))
 
 
+def _table(lut, mult=128.0, cmin=-128.0, cmax=127.0):
+    from mct_quantizers_amd.hip import native
+    tab = native.build_lut_table(lut, mult, cmin, cmax)
+    assert tab is not None
+    return _dev(tab)
+
+
+@pytest.mark.parametrize("lut_name", list(LUTS))
+def test_decision_table_equals_literal_scan_for_every_float(lib, lut_name):
+    """All 2^32 float32 inputs: the LDS decision-table kernel == the literal first-minimum scan kernel."""
+    lut = LUTS[lut_name]
+    lut_d, tab = _dev(np.asarray(lut, dtype=np.float32)), _table(lut)
+    chunk = 1 << 28
+    y_lit = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    y_tab = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    for c in range(16):
+        bits = torch.arange(c * chunk - (1 << 31), (c + 1) * chunk - (1 << 31), dtype=torch.int64, device="cuda")
+        x = bits.to(torch.int32).view(torch.float32)
+        del bits
+        # thr_div = 1, mult = 128: t = clamp(x * 128) sweeps every float in the clip range
+        assert lib.mctq_lut_per_tensor_f32(x.data_ptr(), y_lit.data_ptr(), chunk, 1.0, 1.0, lut_d.data_ptr(),
+                                           len(lut), 128.0, -128.0, 127.0, _stream()) == 0
+        assert lib.mctq_lutt_per_tensor_f32(x.data_ptr(), y_tab.data_ptr(), chunk, 1.0, 1.0, tab.data_ptr(),
+                                            tab.shape[0] - 1, 128.0, -128.0, 127.0, _stream()) == 0
+        same = torch.equal(y_lit.view(torch.int32), y_tab.view(torch.int32))
+        if not same:
+            i = int(torch.nonzero(y_lit.view(torch.int32) != y_tab.view(torch.int32))[0])
+            raise AssertionError(f"chunk {c}: x={x[i].item()!r} literal={y_lit[i].item()!r} table={y_tab[i].item()!r}")
+        del x
+
+
+def test_decision_table_unsigned_and_wide_codebooks(lib):
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(3)
+    cases = [([0.0, 13.0, 50.0, 90.0, 128.0, 200.0, 255.0, 256.0], False, 8),
+             ([float(v) for v in range(-512, 512, 64)], True, 10),
+             ([-8.0, -3.0, 2.0, 7.0], True, 4)]
+    for lut, signed, B in cases:
+        mult = float(2 ** (B - int(signed)))
+        cmin, cmax = (float(-2 ** (B - 1)), float(2 ** (B - 1) - 1)) if signed else (0.0, float(2 ** B - 1))
+        tab = _table(lut, mult, cmin, cmax)
+        thr = 1.7
+        x_np = (rng.standard_normal(200003).astype(np.float32) * np.float32(1.2))
+        mid = (rng.integers(int(2 * cmin) - 4, int(2 * cmax) + 4, size=x_np.size).astype(np.float32) * np.float32(0.5)
+               / np.float32(mult) * np.float32(thr))
+        x_np = np.where(rng.integers(0, 3, size=x_np.size) == 0, mid, x_np).astype(np.float32)
+        x = _dev(x_np)
+        y = torch.empty_like(x)
+        thr_div = float(np.float32(thr) + np.float32(1e-8))
+        assert lib.mctq_lutt_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, float(np.float32(thr)),
+                                            tab.data_ptr(), tab.shape[0] - 1, mult, cmin, cmax, _stream()) == 0
+        want = O.lut_quantize(x_np, lut, np.asarray([thr], dtype=np.float32), signed, B, 1e-8)
+        assert bits_equal(y.cpu().numpy(), want), first_mismatch(y.cpu().numpy(), want, x_np)
+
+
+@pytest.mark.parametrize("lut_name", ["l3dup", "l16", "l256"])
+@pytest.mark.parametrize("outer,C,inner", [(1, 3, 1), (50, 3, 1), (4, 6, 5), (2, 8, 100), (2, 6, 1024), (3, 5, 1028),
+                                           (1, 16, 11008), (1, 3000, 3), (1, 2, 70000)])
+def test_abi_table_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(C * 31 + inner + 1)
+    lut = LUTS[lut_name]
+    thr = rng.uniform(0.05, 4.0, size=C).astype(np.float32)
+    shape = (outer, C, inner)
+    x_np = _lut_inputs(rng, shape, thr.reshape(1, C, 1))
+    x, t_d, tab = _dev(x_np), _dev(thr), _table(lut)
+    y = torch.empty_like(x)
+    rc = lib.mctq_lutt_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, C, inner, t_d.data_ptr(), 1e-8,
+                                       tab.data_ptr(), tab.shape[0] - 1, 128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want = O.lut_quantize(x_np, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=1)
+    assert bits_equal(y.cpu().numpy(), want), first_mismatch(y.cpu().numpy(), want, x_np)
+
+
+def test_fast_division_is_exact(lib):
+    """Every float32 numerator x 48 divisors: the shared-divisor division equals IEEE '/' bit for bit."""
+    rng = np.random.default_rng(99)
+    special = [1.0, 2.0, 0.5, 3.0, 1.0 / 3.0, 0.1, 1e-8, 1.00000001e-8, 127.0, 1.9999999, 1.0000001, 0.99999994,
+               3.4028235e10, 2.0 ** -59, 2.0 ** 59, 1e-20, 7.0, 1.5, 4.7683716e-07 + 1e-8, 0.33, 11.3, 5e-5]
+    rand = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), size=48 - len(special)))
+    div = np.asarray(special + list(rand), dtype=np.float32)
+    d = _dev(div)
+    bad = torch.zeros(div.size, dtype=torch.int64, device="cuda")
+    rc = lib.mctq_selftest_division(d.data_ptr(), div.size, bad.data_ptr(), _stream())
+    assert rc == 0, lib.mctq_last_error()
+    torch.cuda.synchronize()
+    bad = bad.cpu().numpy()
+    assert not bad.any(), {float(div[i]): int(bad[i]) for i in np.flatnonzero(bad)}
+
+
 def test_abi_argument_errors(lib):
     x = torch.zeros(16, device="cuda")
     y = torch.zeros(16, device="cuda")
