@@ -50,6 +50,19 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
     def __call__(self, inputs: torch.Tensor):
         raise NotImplementedError(f'{self.__class__.__name__} did not implement __call__')  # pragma: no cover
 
+    # -- pickles: objects saved by the reference (or by an older build) carry only the public attributes;
+    #    the private launch state (host copies of scalars, decision tables) is rebuilt on load.
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._rebuild_launch_state()
+
+    def _rebuild_launch_state(self):
+        """Recreate private, derived attributes from the public ones (idempotent)."""
+
+    @staticmethod
+    def _to_working_device(t):
+        return t.to(get_working_device()) if isinstance(t, torch.Tensor) else t
+
     # -- reuse cache helpers shared by the weights quantizers (weights_symmetric...py:128-129,153-155)
     def _cached(self):
         return self.enable_reuse and not self.quantizer_first_run
@@ -116,6 +129,13 @@ class _WeightsAffineMixin:
     self.per_channel, self.channel_axis, the clamp domain, and host copies _scale0 / _zp0 of the
     first entry (so the per-tensor launch needs no device->host read).
     """
+
+    def _rebuild_launch_state(self):
+        self.scales = self._to_working_device(self.scales)
+        self.zero_points = self._to_working_device(self.zero_points)
+        if "_scale0" not in self.__dict__ or "_zp0" not in self.__dict__:
+            self._scale0 = float(self.scales.reshape(-1)[0].item())
+            self._zp0 = int(self.zero_points.reshape(-1)[0].item())
 
     def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
         inputs.requires_grad = False            # the reference flips this on the caller's tensor

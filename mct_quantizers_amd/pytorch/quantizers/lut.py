@@ -83,15 +83,19 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
             assert len(threshold) == 1, \
                 f'In per-tensor quantization threshold should be of length 1 but is {len(threshold)}'
 
+        self._rebuild_launch_state()
+
+    def _rebuild_launch_state(self):
         dev = get_working_device()
         self._threshold_torch = to_torch_tensor(self._threshold_np).to(dev)
         self._lut_values_torch = to_torch_tensor(self._lut_values_np).to(dev)
         # host copies for the per-tensor launch: tensor + python-scalar is a float32 add
         thr0 = np.float32(self._threshold_np.reshape(-1)[0])
         self._thr_mul0 = float(thr0)
-        self._thr_div0 = float(thr0 + np.float32(eps))
+        self._thr_div0 = float(thr0 + np.float32(self.eps))
         # codebook compiled once into an LDS decision table (None -> literal scan kernels)
-        self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(lut_values_bitwidth, True), dev)
+        self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(self.lut_values_bitwidth, True),
+                                                   dev)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached():
@@ -139,12 +143,16 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         assert len(self.threshold) == 1, ('For activation, quantization per channel is not supported and threshold '
                                           f'should be of length 1 but is {len(threshold)}')
         self.threshold = self.threshold[0]
-        self.lut_values = to_torch_tensor(self._lut_values_np).to(get_working_device())
+        self._rebuild_launch_state()
+
+    def _rebuild_launch_state(self):
+        dev = get_working_device()
+        self.lut_values = to_torch_tensor(self._lut_values_np).to(dev)
         # Python-float threshold: threshold + eps is a DOUBLE add, narrowed to float32 at the division
         self._thr_mul0 = float(np.float32(self.threshold))
-        self._thr_div0 = float(np.float32(float(self.threshold) + eps))
-        self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(lut_values_bitwidth, signed),
-                                                   get_working_device())
+        self._thr_div0 = float(np.float32(float(self.threshold) + self.eps))
+        self._lut_table_torch = ops.make_lut_table(self._lut_values_np,
+                                                   *lut_domain(self.lut_values_bitwidth, self.signed), dev)
 
     def __call__(self, inputs: torch.Tensor):
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)

@@ -385,6 +385,7 @@ def gen_full_sha():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--pickles-only", action="store_true")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     gen_affine_cases()
@@ -404,5 +405,47 @@ def main():
     print(f"{len(cases)} cases, {sum(a.nbytes for a in arrays.values())} array bytes")
 
 
+
+
+def gen_pickled_reference_models():
+    """Pickles of REFERENCE objects (class paths + state only, no source) for the unpickle-compat tests:
+    a small module tree built from the reference's wrapper/holders/quantizers, and an fx-traced holder."""
+    import torch.nn as nn
+    torch.manual_seed(7)
+
+    conv = nn.Conv2d(3, 4, 3)
+    lin = nn.Linear(4, 3)
+    thr_c = [float(v) for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+    net = nn.Sequential()
+    net.add_module("conv", ref.PytorchQuantizationWrapper(
+        conv, {"weight": refq.WeightsSymmetricInferableQuantizer(8, thr_c, True, 0)}))
+    net.add_module("act", ref.PytorchActivationQuantizationHolder(
+        refq.ActivationUniformInferableQuantizer(8, [-1.0], [3.0])))
+    net.add_module("pool", nn.AdaptiveAvgPool2d(1))
+    net.add_module("flat", nn.Flatten())
+    net.add_module("fln", ref.PytorchFLNActivationQuantizationHolder(
+        refq.ActivationPOTInferableQuantizer(4, [2.0], True)))
+    net.add_module("lin", ref.PytorchQuantizationWrapper(
+        lin, {"weight": refq.WeightsLUTSymmetricInferableQuantizer(
+            3, [-100.0, -50.0, -10.0, 0.0, 10.0, 50.0, 100.0, 127.0], [1.0], False),
+            "bias": refq.WeightsUniformInferableQuantizer(8, [-1.0], [1.0], False)}))
+    net.add_module("keep", ref.PytorchPreservingActivationQuantizationHolder(
+        refq.ActivationLutPOTInferableQuantizer(2, [-100.0, 0.0, 60.0, 127.0], [4.0], True), quantization_bypass=False))
+    x = torch.randn(2, 3, 10, 10)
+    y = net(x)
+    torch.save(net, os.path.join(OUT, "ref_model.pth"))
+    traced = torch.fx.symbolic_trace(ref.PytorchActivationQuantizationHolder(
+        refq.ActivationUniformInferableQuantizer(3, [-2.0], [2.0])))
+    yt = traced(x)
+    torch.save(traced, os.path.join(OUT, "ref_traced_holder.pth"))
+    np.savez_compressed(os.path.join(OUT, "ref_model_io.npz"), x=x.numpy(), y=y.detach().numpy(), y_traced=yt.numpy())
+    print("pickled reference model:", os.path.getsize(os.path.join(OUT, "ref_model.pth")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--pickles-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        gen_pickled_reference_models()
+    else:
+        main()
+        gen_pickled_reference_models()
