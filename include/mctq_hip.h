@@ -42,8 +42,13 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 1
+#define MCTQ_ABI_VERSION 2
 #define MCTQ_E_ARG (-10001)
+
+/* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
+#define MCTQ_DT_F32 0
+#define MCTQ_DT_F16 1
+#define MCTQ_DT_BF16 2
 
 /* ABI version of the loaded library (== MCTQ_ABI_VERSION it was built with). */
 int mctq_abi_version(void);
@@ -62,6 +67,20 @@ int mctq_fq_per_channel_f32(const float* x, float* y,
                             const float* scales, const int32_t* zero_points,
                             int32_t quant_min, int32_t quant_max,
                             void* stream);
+
+/*
+ * The same two operations for x and y stored as float32, float16 or bfloat16 (dtype = MCTQ_DT_*; y has x's
+ * type, as ATen's fake_quantize kernels: float32 arithmetic, one round-to-nearest-even narrowing at the store).
+ */
+int mctq_fq_per_tensor(const void* x, void* y, int64_t n, int32_t dtype,
+                       float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,
+                       void* stream);
+
+int mctq_fq_per_channel(const void* x, void* y,
+                        int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
+                        const float* scales, const int32_t* zero_points,
+                        int32_t quant_min, int32_t quant_max,
+                        void* stream);
 
 /*
  * LUT (codebook) quantizer with one threshold for the whole tensor.
@@ -83,6 +102,28 @@ int mctq_lut_per_channel_f32(const float* x, float* y,
                              const float* lut, int32_t n_lut,
                              float mult, float clip_min, float clip_max,
                              void* stream);
+
+/*
+ * LUT quantizers for x stored as float32 / float16 / bfloat16 (dtype); y is ALWAYS float32, as the
+ * reference's op chain promotes to float32 once the float32 codebook enters (quantizer_utils.py:131-137).
+ * step_round (per-tensor only): 0, or MCTQ_DT_F16 / MCTQ_DT_BF16 to round the quotient x/thr_div and the
+ * scaled value to that type, which is what the reference's chain does to a half-precision activation
+ * divided by a Python-float threshold (activation_lut_pot_inferable_quantizer.py:86-91); thr_div must then
+ * already be rounded to that type by the caller.  The literal-scan entry points (mctq_lut_*) accept
+ * MCTQ_DT_F32 only; the decision-table ones (mctq_lutt_*) accept all three.
+ */
+int mctq_lut_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32_t step_round,
+                        float thr_div, float thr_mul,
+                        const float* lut, int32_t n_lut,
+                        float mult, float clip_min, float clip_max,
+                        void* stream);
+
+int mctq_lut_per_channel(const void* x, float* y,
+                         int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
+                         const float* thresholds, float eps,
+                         const float* lut, int32_t n_lut,
+                         float mult, float clip_min, float clip_max,
+                         void* stream);
 
 /*
  * Decision-table form of the LUT quantizer (integer codebooks, clip range of at most 1023.5 units).
@@ -120,6 +161,19 @@ int mctq_lutt_per_channel_f32(const float* x, float* y,
                               const float* table, int32_t entries,
                               float mult, float clip_min, float clip_max,
                               void* stream);
+
+int mctq_lutt_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32_t step_round,
+                         float thr_div, float thr_mul,
+                         const float* table, int32_t entries,
+                         float mult, float clip_min, float clip_max,
+                         void* stream);
+
+int mctq_lutt_per_channel(const void* x, float* y,
+                          int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
+                          const float* thresholds, float eps,
+                          const float* table, int32_t entries,
+                          float mult, float clip_min, float clip_max,
+                          void* stream);
 
 /*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.

@@ -1,0 +1,51 @@
+// mctq_affine.hip -- part of libmctq_hip.so (C ABI: include/mctq_hip.h); kernels: mctq_kernels.hpp
+#include "mctq_kernels.hpp"
+
+using namespace mctq;
+
+extern "C" {
+
+// ---- affine ---------------------------------------------------------------------------------------
+
+int mctq_fq_per_tensor(const void* x, void* y, int64_t n, int32_t dtype, float scale, int32_t zero_point,
+                       int32_t quant_min, int32_t quant_max, void* stream) {
+  if (n < 0) return fail_arg("n < 0");
+  if (n > 0 && (!x || !y)) return fail_arg("x or y is NULL");
+  if (quant_min > quant_max) return fail_arg("quant_min > quant_max");
+  AffineOp op;
+  op.scales = nullptr; op.zps = nullptr;
+  op.lo = (float)quant_min; op.hi = (float)quant_max;
+  const AffineOp::Param p = AffineOp::make(scale, zero_point);   // host IEEE division == ATen's 1.0f / scale
+  return with_affine_types(dtype, [&](auto ti, auto to) {
+    return launch_flat<decltype(ti), decltype(to)>(op, p, x, y, n, 0, (hipStream_t)stream);
+  });
+}
+
+int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
+                        const float* scales, const int32_t* zero_points, int32_t quant_min, int32_t quant_max,
+                        void* stream) {
+  if (outer < 0 || channels < 0 || inner < 0) return fail_arg("negative extent");
+  if (quant_min > quant_max) return fail_arg("quant_min > quant_max");
+  const int64_t n = outer * channels * inner;
+  if (n > 0 && (!x || !y || !scales || !zero_points)) return fail_arg("NULL pointer");
+  AffineOp op;
+  op.scales = scales; op.zps = zero_points;
+  op.lo = (float)quant_min; op.hi = (float)quant_max;
+  return with_affine_types(dtype, [&](auto ti, auto to) {
+    return launch_channels<decltype(ti), decltype(to)>(op, x, y, outer, channels, inner, 0, (hipStream_t)stream);
+  });
+}
+
+int mctq_fq_per_tensor_f32(const float* x, float* y, int64_t n, float scale, int32_t zero_point, int32_t quant_min,
+                           int32_t quant_max, void* stream) {
+  return mctq_fq_per_tensor(x, y, n, MCTQ_DT_F32, scale, zero_point, quant_min, quant_max, stream);
+}
+
+int mctq_fq_per_channel_f32(const float* x, float* y, int64_t outer, int64_t channels, int64_t inner,
+                            const float* scales, const int32_t* zero_points, int32_t quant_min, int32_t quant_max,
+                            void* stream) {
+  return mctq_fq_per_channel(x, y, outer, channels, inner, MCTQ_DT_F32, scales, zero_points, quant_min, quant_max,
+                             stream);
+}
+
+}  // extern "C"

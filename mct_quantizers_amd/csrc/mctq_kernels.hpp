@@ -1,0 +1,953 @@
+// mctq_kernels.hpp -- gfx950 (MI355X / CDNA4) kernels and launch helpers of libmctq_hip.so.
+// Included by the translation units that hold the C ABI (mctq_affine.hip, mctq_lut_scan.hip,
+// mctq_lut_table.hip, mctq_misc.hip); they are compiled in parallel and linked into one library.
+//
+// Hot path of sony/mct_quantizers' PyTorch inferable quantizers, written for CDNA4:
+// one fused load -> scale -> round-half-even -> clamp -> dequant -> store pass (8 algorithmic
+// bytes per float32 element) for the affine quantizers, and one fused divide -> clamp -> codebook
+// decision -> dequant pass for the LUT quantizers.  The work is elementwise and HBM-bound, so
+// there is no MFMA here; what matters is 16-byte-per-lane coalesced traffic (1 KiB per wave
+// instruction), enough loads in flight per lane, and keeping the per-channel parameters out of the
+// vector memory pipe (SGPR broadcast or an LDS window).
+//
+// Launch shapes (each templated on the op and on the storage types TI -> TO):
+//   flat          per-tensor parameters in kernel arguments (SGPRs).
+//   rows          per-channel, long vector-divisible rows: one block = one tile of one
+//                 (outer, channel) row; data loads are issued first, then the channel's parameters
+//                 arrive through scalar loads (wave-uniform index) -> SGPR broadcast.
+//   window        per-channel, any inner (channel-last, conv kernels, ragged, unaligned): one
+//                 block = one contiguous tile; the parameters of the rows that tile touches are
+//                 staged in LDS once per block and looked up per element without any per-element
+//                 division.
+//   flat_loop /   "heavy" ops (LUT): persistent blocks stride over tiles, prefetch the next tile
+//   rows_persist  while computing the current one, stage the codebook table in LDS once per block.
+//
+// Storage types: float32, float16, bfloat16 in; the affine ops write the input type (as ATen
+// does), the LUT ops always write float32 (the reference's op chain promotes).  All arithmetic is
+// float32.  Arithmetic contract: include/mctq_hip.h.  Compile with -ffp-contract=off, no fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "mctq_hip.h"
+
+namespace mctq {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------
+// Storage: N elements per lane access, N = 16 B / max(sizeof in, sizeof out)
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+
+template <class T, int N> struct VecT;
+template <> struct VecT<float, 4> { typedef f32x4 type; };
+template <> struct VecT<_Float16, 8> { typedef f16x8 type; };
+template <> struct VecT<_Float16, 4> { typedef f16x4 type; };
+template <> struct VecT<__bf16, 8> { typedef b16x8 type; };
+template <> struct VecT<__bf16, 4> { typedef b16x4 type; };
+
+template <class TI, class TO>
+struct IO {
+  static constexpr int N = 16 / (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
+  typedef typename VecT<TI, N>::type VI;
+  typedef typename VecT<TO, N>::type VO;
+
+  template <bool NT>
+  __device__ __forceinline__ static VI load(const TI* p) {
+    const VI* q = reinterpret_cast<const VI*>(p);
+    if (NT) return __builtin_nontemporal_load(q);
+    return *q;
+  }
+  template <bool NT>
+  __device__ __forceinline__ static void store(TO* p, VO v) {
+    VO* q = reinterpret_cast<VO*>(p);
+    if (NT) __builtin_nontemporal_store(v, q);
+    else *q = v;
+  }
+  __device__ __forceinline__ static void unpack(VI v, float* f) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = (float)v[i];            // exact widening
+  }
+  __device__ __forceinline__ static VO pack(const float* f) {
+    VO o;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = (TO)f[i];               // round-to-nearest-even narrowing
+    return o;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Ops.  An Op describes: per-channel Param (kWords floats when staged in LDS), fetch(c) that
+// builds it from the device tables, an optional Book (codebook / table) set up once per block,
+// apply<FAST>(x, param, book) and optionally a batched tile<FAST, NE>().
+// ------------------------------------------------------------------------------------------
+
+struct NoBook {};
+
+struct AffineOp {
+  const float* __restrict__ scales;    // [C] (per-channel launches only)
+  const int32_t* __restrict__ zps;     // [C]
+  float lo, hi;                        // clamp domain as floats (exact: |q| < 2^24)
+
+  struct Param { float s, inv, zf; };
+  typedef NoBook Book;
+  static constexpr int kWords = 3;
+  static constexpr bool kHeavy = false;       // a few VALU ops per element: pure streaming
+
+  __host__ __device__ __forceinline__ static Param make(float s, int32_t zp) {
+    Param p;
+    p.s = s;
+    p.inv = 1.0f / s;                  // correctly rounded IEEE division, as ATen's 1.0f / scale
+    p.zf = (float)zp;
+    return p;
+  }
+  __device__ __forceinline__ Param fetch(uint32_t c) const { return make(scales[c], zps[c]); }
+  __device__ __forceinline__ static void put(float* lds, uint32_t i, uint32_t stride, const Param& p) {
+    lds[i] = p.s; lds[stride + i] = p.inv; lds[2 * stride + i] = p.zf;
+  }
+  __device__ __forceinline__ static Param get(const float* lds, uint32_t i, uint32_t stride) {
+    Param p; p.s = lds[i]; p.inv = lds[stride + i]; p.zf = lds[2 * stride + i]; return p;
+  }
+  __device__ __forceinline__ uint32_t book_words() const { return 0; }
+  __device__ __forceinline__ Book setup(float*) const { return Book(); }
+  __device__ __forceinline__ static bool can_fast(const Param&) { return true; }
+
+  template <bool FAST = true>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book&) const {
+    float q = __builtin_rintf(x * p.inv) + p.zf;      // v_rndne_f32: ties to even
+    q = fminf(fmaxf(q, lo), hi);                      // NaN -> lo, +inf -> hi, -inf -> lo
+    return (q - p.zf) * p.s;
+  }
+};
+
+// Shared by the two LUT ops: per-channel parameters and the shared-divisor division.
+struct LutCommon {
+  const float* __restrict__ thr;       // [C] thresholds (per-channel launches only)
+  float eps;
+  float mult, inv_mult, cmin, cmax;
+  int step_round;                      // 0, or MCTQ_DT_F16 / MCTQ_DT_BF16: round the quotient and the scaled
+                                       // value to that type (half-precision activations, per-tensor only)
+
+  // divisor fl32(thr + eps), multiplier thr, and r = RN(1/d) when the fast exact division below
+  // is valid for this divisor (r == 0 selects the plain IEEE division).
+  struct Param { float d, t, r; };
+  static constexpr int kWords = 3;
+  static constexpr bool kHeavy = true;         // blocks loop over tiles (set-up paid once per block)
+
+  __host__ __device__ __forceinline__ static Param make(float d, float t) {
+    Param p; p.d = d; p.t = t;
+    const float a = fabsf(d);
+    p.r = (a > 0x1p-60f && a < 0x1p60f) ? 1.0f / d : 0.0f;
+    return p;
+  }
+  __device__ __forceinline__ Param fetch(uint32_t c) const {
+    const float t = thr[c];
+    return make(t + eps, t);
+  }
+  __device__ __forceinline__ static void put(float* lds, uint32_t i, uint32_t stride, const Param& p) {
+    lds[i] = p.d; lds[stride + i] = p.t; lds[2 * stride + i] = p.r;
+  }
+  __device__ __forceinline__ static Param get(const float* lds, uint32_t i, uint32_t stride) {
+    Param p; p.d = lds[i]; p.t = lds[stride + i]; p.r = lds[2 * stride + i]; return p;
+  }
+
+  // x / d, correctly rounded, for a divisor shared by many elements.  FAST: with r = RN(1/d),
+  // q0 = x*r followed by two residual corrections with exact FMA residuals -- the same recurrence
+  // the compiler's IEEE expansion runs after its v_rcp/Newton steps, minus the per-element
+  // reciprocal and scaling (7 VALU ops instead of ~11, and no v_div_* wait states).  Outside
+  // |q| < 2^60 (and for inf/NaN) q0 is returned: there the result is clamped anyway, and below
+  // |q| ~ 2^-31 the codebook decision does not depend on the last bits (every |t - c| with c != 0
+  // rounds to |c|).  Verified exhaustively against '/' on the GPU
+  // (tests/test_gpu_parity.py::test_fast_division_is_exact).  Kernels pick FAST per block (rows,
+  // flat: the divisor is wave-uniform) when p.r != 0; FAST = false is the plain IEEE division.
+  template <bool FAST>
+  __device__ __forceinline__ static float divide(float x, const Param& p) {
+    if constexpr (!FAST) {
+      return x / p.d;
+    } else {
+      const float q0 = x * p.r;
+      const float e0 = __builtin_fmaf(-q0, p.d, x);
+      const float q1 = __builtin_fmaf(e0, p.r, q0);
+      const float e1 = __builtin_fmaf(-q1, p.d, x);
+      const float q2 = __builtin_fmaf(e1, p.r, q1);
+      return (fabsf(q0) < 0x1p60f) ? q2 : q0;
+    }
+  }
+  __device__ __forceinline__ static bool can_fast(const Param& p) { return p.r != 0.0f; }
+
+  __device__ __forceinline__ float narrow(float v) const {
+    if (step_round == MCTQ_DT_F16) return (float)(_Float16)v;
+    if (step_round == MCTQ_DT_BF16) return (float)(__bf16)v;
+    return v;
+  }
+  // (x / d) * mult as the reference's op chain computes it (quantizer_utils.py:169), incl. the
+  // per-op roundings of a half-precision activation tensor.
+  template <bool FAST>
+  __device__ __forceinline__ float scaled(float x, const Param& p) const {
+    if (step_round == 0) return divide<FAST>(x, p) * mult;
+    return narrow(narrow(divide<false>(x, p)) * mult);
+  }
+};
+
+// Literal codebook scan (any codebook, any bit width): the reference's first-minimum argmin.
+template <int LP>
+struct RegBook { float c[LP]; };
+struct LdsBook { const float* c; int n; };
+
+template <int LP>   // LP > 0: codebook broadcast into LP scalar registers; LP == 0: codebook in LDS
+struct LutOp : LutCommon {
+  const float* __restrict__ lut;       // [n_lut] device codebook, caller's order
+  int n_lut;
+
+  typedef typename std::conditional<(LP > 0), RegBook<(LP > 0 ? LP : 1)>, LdsBook>::type Book;
+
+  __device__ __forceinline__ uint32_t book_words() const { return LP > 0 ? 0u : (uint32_t)((n_lut + 3) & ~3); }
+
+  // Called by every thread of the block before any apply().
+  __device__ __forceinline__ Book setup(float* lds) const {
+    if constexpr (LP > 0) {
+      // One coalesced load per wave: lane j holds lut[j]; every entry is then broadcast to a
+      // scalar register with v_readlane (wave-level shuffle), so the scan below reads SGPRs.
+      const int lane = threadIdx.x & 63;
+      float v = INFINITY;                              // padding never wins a strict '<'
+      if (lane < n_lut) v = lut[lane];
+      Book b;
+#pragma unroll
+      for (int j = 0; j < LP; ++j)
+        b.c[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+      return b;
+    } else {
+      for (int j = threadIdx.x; j < n_lut; j += kThreads) lds[j] = lut[j];
+      __syncthreads();
+      Book b; b.c = lds; b.n = n_lut;
+      return b;
+    }
+  }
+
+  template <bool FAST = false>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
+    const float v = scaled<FAST>(x, p);
+    float t = fminf(fmaxf(v, cmin), cmax);
+    t = (v != v) ? v : t;                              // torch.clip keeps NaN
+    float best_c = b.c[0];
+    float best_d = fabsf(t - best_c);
+    if constexpr (LP > 0) {
+#pragma unroll
+      for (int j = 1; j < LP; ++j) {
+        const float c = b.c[j];
+        const float d = fabsf(t - c);
+        const bool lt = d < best_d;                    // strict: first minimum wins; NaN never wins
+        best_d = lt ? d : best_d;
+        best_c = lt ? c : best_c;
+      }
+    } else {
+      for (int j = 1; j < b.n; ++j) {
+        const float c = b.c[j];                        // same address in every lane: LDS broadcast
+        const float d = fabsf(t - c);
+        const bool lt = d < best_d;
+        best_d = lt ? d : best_d;
+        best_c = lt ? c : best_c;
+      }
+    }
+    return (best_c * inv_mult) * p.t;                  // mult is a power of two: * (1/mult) == / mult
+  }
+};
+
+// Decision-table codebook quantizer.  For integer codebooks every decision boundary of the literal
+// scan lies within a few ulps of a half-integer point P_k = clip_min + k/2 of the scaled value t
+// (midpoints of integers), and around each P_k the literal result is a single monotone step
+// (fl(t - a) is non-decreasing and fl(b - t) non-increasing in t).  mctq_lut_build_table() evaluates
+// the literal scan on the host and records, per point, the exact float32 threshold T_k of that
+// step and the dequantized centres c/mult below/above it (exact in fp16: |c| <= 2^10, mult = 2^j).
+// The kernel then needs one 8-byte LDS read, one compare and one select per element, whatever the
+// codebook size: entry k = {T_k, half2(q_below, q_above)}, k = trunc(2*(t - clip_min) + 0.5);
+// entry `entries` holds {q for NaN inputs (float32), K}.
+struct LutTableBook { const f32x2* tab; float nan_q; };
+
+struct LutTableOp : LutCommon {
+  const float* __restrict__ table;     // device, (entries + 1) x 2 words
+  int entries;
+  float koff;                          // 0.5 - 2*clip_min
+
+  typedef LutTableBook Book;
+  __device__ __forceinline__ uint32_t book_words() const { return ((uint32_t)(entries + 1) * 2u + 3u) & ~3u; }
+
+  __device__ __forceinline__ Book setup(float* lds) const {
+    const f32x2* src = reinterpret_cast<const f32x2*>(table);
+    f32x2* dst = reinterpret_cast<f32x2*>(lds);
+    for (int j = threadIdx.x; j <= entries; j += kThreads) dst[j] = src[j];
+    __syncthreads();
+    Book b; b.tab = dst; b.nan_q = dst[entries].x;
+    return b;
+  }
+
+  // stage 1: scaled, clamped value and its table index
+  template <bool FAST>
+  __device__ __forceinline__ void locate(float x, const Param& p, float& v, float& t, int& k) const {
+    v = scaled<FAST>(x, p);
+    t = fminf(fmaxf(v, cmin), cmax);                  // NaN -> cmin here, overridden in decide()
+    k = (int)__builtin_fmaf(t, 2.0f, koff);           // nearest half-integer point (any tie is fine)
+  }
+  // stage 3: pick the side of the step, dequantize
+  __device__ __forceinline__ float decide(float v, float t, f32x2 e, const Param& p, const Book& b) const {
+    const uint32_t pair = __float_as_uint(e.y);
+    const uint32_t h = (t >= e.x) ? (pair >> 16) : (pair & 0xffffu);
+    float q = __half2float(__ushort_as_half((unsigned short)h));
+    q = (v != v) ? b.nan_q : q;                       // all-NaN distances: argmin is index 0
+    return q * p.t;
+  }
+
+  template <bool FAST = false>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
+    float v, t; int k;
+    locate<FAST>(x, p, v, t, k);
+    return decide(v, t, b.tab[k], p, b);
+  }
+
+  // A whole tile: all indices first, then all LDS reads back to back, then all selects, so one
+  // s_waitcnt covers NE lookups instead of one per element.
+  template <bool FAST, int NE>
+  __device__ __forceinline__ void tile(const float* in, float* out, const Param& p, const Book& b) const {
+    float v[NE], t[NE];
+    int k[NE];
+    f32x2 e[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], t[i], k[i]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) e[i] = b.tab[k[i]];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) out[i] = decide(v[i], t[i], e[i], p, b);
+  }
+};
+
+template <class Op, class = void>
+struct HasTile : std::false_type {};
+template <class Op>
+struct HasTile<Op, std::void_t<decltype(&Op::template tile<true, 4>)>> : std::true_type {};
+
+// NE elements with one Param (all in the same channel).
+template <bool FAST, int NE, class Op>
+__device__ __forceinline__ void run(const Op& op, const float* in, float* out, const typename Op::Param& p,
+                                    const typename Op::Book& b) {
+  if constexpr (HasTile<Op>::value) {
+    op.template tile<FAST, NE>(in, out, p, b);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) out[i] = op.template apply<FAST>(in[i], p, b);
+  }
+}
+
+// U lane-vectors: unpack, run, pack.
+template <bool FAST, class Op, class TI, class TO, int U>
+__device__ __forceinline__ void run_vectors(const Op& op, const typename IO<TI, TO>::VI (&v)[U],
+                                            typename IO<TI, TO>::VO (&r)[U], const typename Op::Param& p,
+                                            const typename Op::Book& b) {
+  typedef IO<TI, TO> io;
+  float in[U * io::N], out[U * io::N];
+#pragma unroll
+  for (int u = 0; u < U; ++u) io::unpack(v[u], in + u * io::N);
+  run<FAST, U * io::N>(op, in, out, p, b);
+#pragma unroll
+  for (int u = 0; u < U; ++u) r[u] = io::pack(out + u * io::N);
+}
+
+// ------------------------------------------------------------------------------------------
+// flat: per-tensor parameters.  Block b owns lane-vectors [b*256*U, (b+1)*256*U); lane accesses
+// are 16 B (8 B for a 16-bit input widened to float32), consecutive lanes consecutive addresses,
+// U independent loads in flight per lane.
+// ------------------------------------------------------------------------------------------
+template <class Op, class TI, class TO, int U, bool NT>
+__global__ __launch_bounds__(kThreads) void flat_kernel(Op op, typename Op::Param p,
+                                                        const TI* __restrict__ xs, TO* __restrict__ ys, int64_t n) {
+  typedef IO<TI, TO> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const typename Op::Book book = op.setup(smem);
+  const int64_t nv = n / io::N;
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+  typename io::VI v[U];
+  if (((int64_t)blockIdx.x + 1) * (kThreads * U) <= nv) {   // full tile (wave-uniform test): no per-lane guards
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(xs + (base + u * kThreads) * io::N);
+    typename io::VO r[U];
+    run_vectors<false, Op, TI, TO, U>(op, v, r, p, book);
+#pragma unroll
+    for (int u = 0; u < U; ++u) io::template store<NT>(ys + (base + u * kThreads) * io::N, r[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * kThreads;
+      if (i < nv) {
+        typename io::VI one[1] = {io::template load<NT>(xs + i * io::N)};
+        typename io::VO res[1];
+        run_vectors<false, Op, TI, TO, 1>(op, one, res, p, book);
+        io::template store<NT>(ys + i * io::N, res[0]);
+      }
+    }
+  }
+  if (blockIdx.x == 0) {                                   // n % N trailing elements
+    const int64_t i = nv * io::N + threadIdx.x;
+    if (i < n) ys[i] = (TO)op.template apply<false>((float)xs[i], p, book);
+  }
+}
+
+// flat, one element per lane: used when x or y is not vector-aligned.
+template <class Op, class TI, class TO>
+__global__ __launch_bounds__(kThreads) void flat_scalar_kernel(Op op, typename Op::Param p, const TI* __restrict__ x,
+                                                               TO* __restrict__ y, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const typename Op::Book book = op.setup(smem);
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+    y[i] = (TO)op.template apply<false>((float)x[i], p, book);
+}
+
+// ------------------------------------------------------------------------------------------
+// rows: tensor viewed as [rows = outer*C][innerv] lane-vectors.  blockIdx -> (row, tile); the
+// row's channel index is wave-uniform, so fetch() compiles to scalar loads and the parameters sit
+// in SGPRs for the whole block.
+// ------------------------------------------------------------------------------------------
+template <class Op, class TI, class TO, int U, bool NT>
+__global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
+                                                        uint32_t tiles_per_row, uint32_t innerv, uint32_t channels) {
+  typedef IO<TI, TO> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint32_t row = blockIdx.x, tile = 0;
+  if (tiles_per_row != 1) {                                // uniform branch: skip the division for 1 tile/row
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x - row * tiles_per_row;
+  }
+  const int64_t rbase = (int64_t)row * innerv;
+  const uint32_t col = tile * (kThreads * U) + threadIdx.x;
+  const bool full = (tile + 1) * (kThreads * U) <= innerv;     // wave-uniform
+  typename io::VI v[U];
+  // Issue the data loads FIRST; the parameter fetch (two dependent scalar loads + an IEEE divide)
+  // then runs in the shadow of the HBM latency.
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(xs + (rbase + col + u * kThreads) * io::N);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (col + u * kThreads < innerv) v[u] = io::template load<NT>(xs + (rbase + col + u * kThreads) * io::N);
+  }
+  __builtin_amdgcn_sched_barrier(0);                       // keep the loads above the fetch in the schedule
+  const typename Op::Book book = op.setup(smem);
+  uint32_t c = row;
+  if (c >= channels) c = row % channels;                   // uniform; outer == 1 needs no modulo
+  const typename Op::Param p = op.fetch(c);
+  if (full) {
+    typename io::VO r[U];
+    run_vectors<false, Op, TI, TO, U>(op, v, r, p, book);
+#pragma unroll
+    for (int u = 0; u < U; ++u) io::template store<NT>(ys + (rbase + col + u * kThreads) * io::N, r[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (col + u * kThreads < innerv) {
+        typename io::VI one[1] = {v[u]};
+        typename io::VO res[1];
+        run_vectors<false, Op, TI, TO, 1>(op, one, res, p, book);
+        io::template store<NT>(ys + (rbase + col + u * kThreads) * io::N, res[0]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Heavy ops: persistent blocks.  The work is cut into tiles of 256*U lane-vectors (tiles never
+// cross a row); block b takes tiles b, b+grid, b+2*grid, ... so every CU finishes at the same time
+// (a one-block-per-row grid leaves the last round of blocks mostly empty), prefetches the next
+// tile's loads before it computes the current one, and pays the table / codebook staging once.
+// Full tiles run straight-line code so the LDS table reads of a tile are issued back to back.
+// ------------------------------------------------------------------------------------------
+template <class TI, class TO, int U, bool NT>
+__device__ __forceinline__ void load_tile(typename IO<TI, TO>::VI (&v)[U], const TI* __restrict__ x, int64_t first,
+                                          int64_t limit, bool full /* wave-uniform */) {
+  typedef IO<TI, TO> io;
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(x + (first + u * kThreads) * io::N);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (first + u * kThreads < limit) v[u] = io::template load<NT>(x + (first + u * kThreads) * io::N);
+  }
+}
+
+template <bool FAST, class Op, class TI, class TO, int U, bool NT>
+__device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Param& p, const typename Op::Book& book,
+                                            const typename IO<TI, TO>::VI (&w)[U], TO* __restrict__ y, int64_t first,
+                                            int64_t limit, bool full) {
+  typedef IO<TI, TO> io;
+  if (full) {
+    typename io::VO r[U];
+    run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
+#pragma unroll
+    for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (first + u * kThreads < limit) {
+        typename io::VI one[1] = {w[u]};
+        typename io::VO res[1];
+        run_vectors<FAST, Op, TI, TO, 1>(op, one, res, p, book);
+        io::template store<NT>(y + (first + u * kThreads) * io::N, res[0]);
+      }
+  }
+}
+
+template <class Op, class TI, class TO, int U, bool NT>
+__global__ __launch_bounds__(kThreads) void rows_persist_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
+                                                                uint32_t tiles_per_row, uint32_t total_tiles,
+                                                                uint32_t innerv, uint32_t channels) {
+  typedef IO<TI, TO> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr uint32_t TILE = kThreads * U;
+  uint32_t item = blockIdx.x;                                // grid <= total_tiles
+  typename io::VI v[U];
+  {
+    const uint32_t row = item / tiles_per_row, tile = item - row * tiles_per_row;
+    const int64_t rbase = (int64_t)row * innerv;
+    load_tile<TI, TO, U, NT>(v, xs, rbase + tile * TILE + threadIdx.x, rbase + innerv, (tile + 1) * TILE <= innerv);
+  }
+  const typename Op::Book book = op.setup(smem);
+  uint32_t cur_row = 0xffffffffu;
+  typename Op::Param p;
+  bool fast = false;
+  for (; item < total_tiles; item += gridDim.x) {
+    const uint32_t row = item / tiles_per_row;
+    const uint32_t tile = item - row * tiles_per_row;
+    if (row != cur_row) {                                    // wave-uniform
+      uint32_t c = row;
+      if (c >= channels) c = row % channels;
+      p = op.fetch(c);
+      fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;
+      cur_row = row;
+    }
+    typename io::VI w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = v[u];
+    const uint32_t next = item + gridDim.x;
+    if (next < total_tiles) {
+      const uint32_t nrow = next / tiles_per_row, ntile = next - nrow * tiles_per_row;
+      const int64_t nbase = (int64_t)nrow * innerv;
+      load_tile<TI, TO, U, NT>(v, xs, nbase + ntile * TILE + threadIdx.x, nbase + innerv, (ntile + 1) * TILE <= innerv);
+    }
+    const int64_t rbase = (int64_t)row * innerv;
+    const int64_t first = rbase + tile * TILE + threadIdx.x;
+    const bool full = (tile + 1) * TILE <= innerv;
+    if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, w, ys, first, rbase + innerv, full);
+    else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, w, ys, first, rbase + innerv, full);
+  }
+}
+
+template <class Op, class TI, class TO, int U, bool NT>
+__global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op::Param p, const TI* __restrict__ xs,
+                                                             TO* __restrict__ ys, int64_t n) {
+  typedef IO<TI, TO> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int64_t TILE = (int64_t)kThreads * U;
+  const int64_t nv = n / io::N;
+  const int64_t tiles = (nv + TILE - 1) / TILE;
+  typename io::VI v[U];
+  load_tile<TI, TO, U, NT>(v, xs, (int64_t)blockIdx.x * TILE + threadIdx.x, nv, ((int64_t)blockIdx.x + 1) * TILE <= nv);
+  const typename Op::Book book = op.setup(smem);
+  const bool fast = Op::can_fast(p);                        // kernel argument: uniform
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    typename io::VI w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = v[u];
+    const int64_t tn = t + gridDim.x;
+    if (tn < tiles) load_tile<TI, TO, U, NT>(v, xs, tn * TILE + threadIdx.x, nv, (tn + 1) * TILE <= nv);
+    const bool full = (t + 1) * TILE <= nv;
+    if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, w, ys, t * TILE + threadIdx.x, nv, full);
+    else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, w, ys, t * TILE + threadIdx.x, nv, full);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = nv * io::N + threadIdx.x;
+    if (i < n) ys[i] = (TO)op.template apply<false>((float)xs[i], p, book);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// window: block b owns elements [b*TILE, (b+1)*TILE), TILE = 256*U*V (V = lane-vector width, or
+// 1 for unaligned tensors).  The tile touches rows row0 .. row0+nrows-1 of the [outer*C][inner]
+// view; their parameters are staged in LDS (structure-of-arrays, so lanes that read different rows
+// hit different banks) and a lane finds its row with ONE 32-bit division per access, then walks
+// row boundaries incrementally.  If the whole table is smaller than the tile's row span
+// (channel-last layouts: inner == 1, C small) the whole table is staged instead and indexed
+// modulo C.
+// ------------------------------------------------------------------------------------------
+template <class Op, class TI, class TO, int U, bool VEC, bool NT, typename IdxT>
+__global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT n,
+                                                          uint32_t inner, uint32_t channels,
+                                                          uint32_t stride /* LDS entries per param word */) {
+  typedef IO<TI, TO> io;
+  constexpr uint32_t V = VEC ? io::N : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr uint32_t TILE = kThreads * U * V;
+  const typename Op::Book book = op.setup(smem);
+  float* tab = smem + op.book_words();
+
+  const IdxT e0 = (IdxT)blockIdx.x * TILE;
+  const IdxT row0 = e0 / inner;                            // uniform, once per block
+  const uint32_t rem0 = (uint32_t)(e0 - row0 * inner);
+  const IdxT left = n - e0;
+  const uint32_t count = left < (IdxT)TILE ? (uint32_t)left : TILE;
+  const uint32_t nrows = (rem0 + count - 1) / inner + 1;
+  const bool whole = channels <= nrows;
+  const uint32_t c0 = (uint32_t)(row0 % channels);
+  if (whole) {
+    for (uint32_t i = threadIdx.x; i < channels; i += kThreads) Op::put(tab, i, stride, op.fetch(i));
+  } else {
+    for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+      uint32_t c = c0 + i;                                 // nrows < channels here: at most one wrap
+      if (c >= channels) c -= channels;
+      Op::put(tab, i, stride, op.fetch(c));
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t off = (u * kThreads + threadIdx.x) * V;
+    if (off >= count) continue;
+    const uint32_t pos = rem0 + off;
+    uint32_t lrow = pos / inner;
+    uint32_t lrem = pos - lrow * inner;
+    uint32_t li = lrow;
+    if (whole) li = (c0 + lrow) % channels;
+    if (VEC && off + V <= count) {
+      float in[V], out[V];
+      io::unpack(io::template load<NT>(xs + e0 + off), in);
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) {
+        out[j] = op.template apply<false>(in[j], Op::get(tab, li, stride), book);
+        if (++lrem == inner) {
+          lrem = 0;
+          ++li;
+          if (whole && li == channels) li = 0;
+        }
+      }
+      io::template store<NT>(ys + e0 + off, io::pack(out));
+    } else {
+      for (uint32_t j = 0; j < V && off + j < count; ++j) {
+        ys[e0 + off + j] = (TO)op.template apply<false>((float)xs[e0 + off + j], Op::get(tab, li, stride), book);
+        if (++lrem == inner) {
+          lrem = 0;
+          ++li;
+          if (whole && li == channels) li = 0;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------
+// shared state and helpers, defined in mctq_misc.hip
+extern thread_local char g_err[256];
+extern int g_nt;             // non-temporal loads/stores: +7% on the cold 4096x4096 stream (profiles/)
+extern int g_unroll;
+extern int g_heavy_unroll;   // 0 = automatic
+int fail_arg(const char* msg);
+int check_launch(const char* what);
+int cu_count();
+template <class TI, class TO>
+static bool vec_aligned(const void* x, const void* y) {
+  typedef IO<TI, TO> io;
+  return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % (io::N * sizeof(TO))) == 0;
+}
+
+// (U, NT) variants are instantiated for float32 -> float32 only (that is where tuning is done);
+// the 16-bit storage types use U = 4 with the library's non-temporal default.
+#define MCTQ_DISPATCH_U_NT(U_, NT_, ...)                                                    \
+  do {                                                                                      \
+    if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {      \
+      if (NT_) {                                                                            \
+        switch (U_) {                                                                       \
+          case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;           \
+          case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;           \
+          case 8: { constexpr int U = 8; constexpr bool NT = true; __VA_ARGS__; } break;           \
+          default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;          \
+        }                                                                                   \
+      } else {                                                                              \
+        switch (U_) {                                                                       \
+          case 1: { constexpr int U = 1; constexpr bool NT = false; __VA_ARGS__; } break;          \
+          case 2: { constexpr int U = 2; constexpr bool NT = false; __VA_ARGS__; } break;          \
+          case 8: { constexpr int U = 8; constexpr bool NT = false; __VA_ARGS__; } break;          \
+          default: { constexpr int U = 4; constexpr bool NT = false; __VA_ARGS__; } break;         \
+        }                                                                                   \
+      }                                                                                     \
+    } else {                                                                                \
+      constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__;                                  \
+    }                                                                                       \
+  } while (0)
+
+#define MCTQ_DISPATCH_HEAVY(U_, NT_, ...)                                                   \
+  do {                                                                                      \
+    if constexpr (std::is_same<TI, float>::value) {                                         \
+      if (NT_) {                                                                            \
+        switch (U_) {                                                                       \
+          case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;           \
+          case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;           \
+          default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;          \
+        }                                                                                   \
+      } else {                                                                              \
+        switch (U_) {                                                                       \
+          case 1: { constexpr int U = 1; constexpr bool NT = false; __VA_ARGS__; } break;          \
+          case 2: { constexpr int U = 2; constexpr bool NT = false; __VA_ARGS__; } break;          \
+          default: { constexpr int U = 4; constexpr bool NT = false; __VA_ARGS__; } break;         \
+        }                                                                                   \
+      }                                                                                     \
+    } else {                                                                                \
+      switch (U_) {                                                                         \
+        case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;             \
+        case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;             \
+        default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;            \
+      }                                                                                     \
+    }                                                                                       \
+  } while (0)
+
+template <class Op, class TI, class TO, int U, bool NT>
+static int persist_blocks_per_cu(size_t book_bytes) {
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rows_persist_kernel<Op, TI, TO, U, NT>, kThreads,
+                                                     book_bytes) != hipSuccess || nb < 1) nb = 4;
+    per_cu = nb > 8 ? 8 : nb;
+  }
+  return per_cu;
+}
+
+template <class TI, class TO, class Op>
+static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv, void* yv, int64_t n,
+                       size_t book_bytes, hipStream_t st) {
+  typedef IO<TI, TO> io;
+  if (n == 0) return 0;
+  const TI* x = static_cast<const TI*>(xv);
+  TO* y = static_cast<TO*>(yv);
+  if (!vec_aligned<TI, TO>(x, y)) {
+    int64_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > (int64_t)cu_count() * 32) blocks = (int64_t)cu_count() * 32;
+    hipLaunchKernelGGL((flat_scalar_kernel<Op, TI, TO>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                       op, p, x, y, n);
+    return check_launch("flat scalar launch");
+  }
+  const int64_t nv = n / io::N;
+  if constexpr (Op::kHeavy) {
+    MCTQ_DISPATCH_HEAVY(2, g_nt, {
+      int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
+      const int64_t cap = (int64_t)cu_count() * 16;
+      if (blocks > cap) blocks = cap;
+      if (blocks == 0) blocks = 1;
+      hipLaunchKernelGGL((flat_loop_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                         op, p, x, y, n);
+    });
+    return check_launch("flat loop launch");
+  } else {
+    MCTQ_DISPATCH_U_NT(g_unroll, g_nt, {
+      int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
+      if (blocks == 0) blocks = 1;
+      if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
+      hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                         op, p, x, y, n);
+    });
+    return check_launch("flat launch");
+  }
+}
+
+template <class TI, class TO, class Op>
+static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer, int64_t channels, int64_t inner,
+                           size_t book_bytes, hipStream_t st) {
+  typedef IO<TI, TO> io;
+  const int64_t n = outer * channels * inner;
+  if (n == 0) return 0;
+  const TI* x = static_cast<const TI*>(xv);
+  TO* y = static_cast<TO*>(yv);
+  const int64_t rows = outer * channels;
+  const bool vec_ok = vec_aligned<TI, TO>(x, y);
+
+  // rows shape: long, vector-divisible rows.
+  if (vec_ok && (inner % io::N) == 0 && inner >= 1024 && channels <= 0xffffffffLL && rows <= 0xffffffffLL) {
+    const int64_t innerv = inner / io::N;
+    if constexpr (Op::kHeavy) {
+      // Lane-vectors per lane per tile: the widest of {4, 2, 1} whose idle lanes in the last tile
+      // of a row stay under 1/8 (more bytes in flight per lane), unless a tuning override is set.
+      int u_sel = 1;
+      for (int u = 4; u >= 1; u >>= 1) {
+        const int64_t per_u = (int64_t)kThreads * u;
+        const int64_t cap = ((innerv + per_u - 1) / per_u) * per_u;
+        if ((cap - innerv) * 8 <= cap) { u_sel = u; break; }
+      }
+      if (g_heavy_unroll) u_sel = g_heavy_unroll;
+      const int64_t per = (int64_t)kThreads * u_sel;
+      const int64_t tiles = (innerv + per - 1) / per;
+      const int64_t total = rows * tiles;
+      if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+        MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
+          int64_t grid = (int64_t)cu_count() * persist_blocks_per_cu<Op, TI, TO, U, NT>(book_bytes);
+          if (grid > total) grid = total;
+          hipLaunchKernelGGL((rows_persist_kernel<Op, TI, TO, U, NT>), dim3((unsigned)grid), dim3(kThreads), book_bytes,
+                             st, op, x, y, (uint32_t)tiles, (uint32_t)total, (uint32_t)innerv, (uint32_t)channels);
+        });
+        return check_launch("rows persistent launch");
+      }
+    } else {
+      // Largest U <= tuned unroll that wastes the fewest lanes in the last tile of a row.
+      int best_u = 1;
+      int64_t best_waste = -1;
+      for (int u = 1; u <= g_unroll; u <<= 1) {
+        const int64_t per = (int64_t)kThreads * u;
+        const int64_t tiles = (innerv + per - 1) / per;
+        const int64_t waste = tiles * per - innerv;
+        if (best_waste < 0 || waste <= best_waste) { best_waste = waste; best_u = u; }
+      }
+      if (!(std::is_same<TI, float>::value && std::is_same<TO, float>::value)) best_u = 4;
+      const int64_t per = (int64_t)kThreads * best_u;
+      const int64_t tiles = (innerv + per - 1) / per;
+      if (rows * tiles <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+        MCTQ_DISPATCH_U_NT(best_u, g_nt, {
+          hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)(rows * tiles)), dim3(kThreads), book_bytes,
+                             st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
+        });
+        return check_launch("rows launch");
+      }
+    }
+  }
+
+  // window shape.
+  if (inner > 0x7fffffffLL || channels > 0x7fffffffLL) return fail_arg("inner/channels exceed 2^31-1");
+  const uint32_t V = vec_ok ? io::N : 1;
+  // lane-vectors per lane: 4, or fewer when the parameter window of a 4-wide tile would not fit LDS
+  // (tiny inner with many channels)
+  int wu = 4;
+  uint32_t tile = 0, stride = 0;
+  size_t lds = 0;
+  for (;; wu >>= 1) {
+    tile = kThreads * wu * V;
+    const uint64_t max_rows = (uint64_t)(tile - 1 + (inner - 1)) / (uint64_t)inner + 1;   // rows a tile can touch
+    const uint64_t entries = (uint64_t)channels <= max_rows ? (uint64_t)channels : max_rows;
+    stride = (uint32_t)entries | 1u;       // odd: keeps the parameter planes on different LDS banks
+    lds = book_bytes + (size_t)stride * Op::kWords * sizeof(float);
+    if (lds <= 64 * 1024 || wu == 1) break;
+  }
+  if (lds > 64 * 1024) return fail_arg("parameter window exceeds 64 KiB of LDS");
+  const int64_t blocks = (n + tile - 1) / tile;
+  if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
+  const bool idx32 = n <= (int64_t)0xffffffffLL - (int64_t)tile;
+#define MCTQ_WINDOW(WU_, VEC_, IDX_)                                                                               \
+  hipLaunchKernelGGL((window_kernel<Op, TI, TO, WU_, VEC_, true, IDX_>), dim3((unsigned)blocks), dim3(kThreads), lds, st, \
+                     op, x, y, (IDX_)n, (uint32_t)inner, (uint32_t)channels, stride)
+#define MCTQ_WINDOW_WU(VEC_, IDX_)                                    \
+  do {                                                                \
+    if (wu == 4) MCTQ_WINDOW(4, VEC_, IDX_);                          \
+    else if (wu == 2) MCTQ_WINDOW(2, VEC_, IDX_);                     \
+    else MCTQ_WINDOW(1, VEC_, IDX_);                                  \
+  } while (0)
+  if (!idx32) {                                        // > 4 Gi elements: only the common shape is built
+    if (!vec_ok || wu != 4) return fail_arg("tensors above 2^32 elements need vector alignment and a small window");
+    MCTQ_WINDOW(4, true, uint64_t);
+  } else if (vec_ok) {
+    MCTQ_WINDOW_WU(true, uint32_t);
+  } else {
+    MCTQ_WINDOW_WU(false, uint32_t);
+  }
+#undef MCTQ_WINDOW_WU
+#undef MCTQ_WINDOW
+  return check_launch("window launch");
+}
+
+// ---- LUT helpers (host) ---------------------------------------------------------------------------
+inline int lut_class(int n_lut) { return n_lut <= 4 ? 4 : n_lut <= 16 ? 16 : n_lut <= 64 ? 64 : 0; }
+
+inline void fill_lut_common(LutCommon& op, const float* thr, float eps, float mult, float cmin, float cmax,
+                            int step_round) {
+  op.thr = thr; op.eps = eps; op.mult = mult; op.inv_mult = 1.0f / mult; op.cmin = cmin; op.cmax = cmax;
+  op.step_round = step_round;
+}
+
+template <int LP>
+static LutOp<LP> make_lut_op(const float* thr, float eps, const float* lut, int n_lut, float mult, float cmin, float cmax,
+                             int step_round) {
+  LutOp<LP> op;
+  fill_lut_common(op, thr, eps, mult, cmin, cmax, step_round);
+  op.lut = lut; op.n_lut = n_lut;
+  return op;
+}
+
+inline float lut_literal_host(float t, const float* lut, int n) {
+  float best_c = lut[0];
+  float best_d = fabsf(t - lut[0]);
+  for (int j = 1; j < n; ++j) {
+    const float d = fabsf(t - lut[j]);
+    if (d < best_d) { best_d = d; best_c = lut[j]; }
+  }
+  return best_c;
+}
+inline uint32_t f2ord(float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+inline float ord2f(uint32_t o) { uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; memcpy(&f, &u, 4); return f; }
+
+inline int table_entries(float cmin, float cmax) {
+  if (!(cmin < cmax) || cmin != floorf(cmin) || cmax != floorf(cmax)) return -1;
+  const double k = 2.0 * ((double)cmax - (double)cmin) + 1.0;
+  if (k > 2048.0) return -1;                 // the table must stay well inside LDS
+  return (int)k;
+}
+
+inline int check_pow2(float mult) {
+  int e = 0;
+  if (!(mult > 0.0f) || frexpf(mult, &e) != 0.5f) return fail_arg("mult must be a positive power of two");
+  return 0;
+}
+inline int check_lut_args(const float* lut, int32_t n_lut, float mult) {
+  if (!lut) return fail_arg("lut is NULL");
+  if (n_lut < 1 || n_lut > 4096) return fail_arg("n_lut must be in [1, 4096]");
+  return check_pow2(mult);
+}
+
+inline int make_table_op(LutTableOp& op, const float* thr, float eps, const float* table, int32_t entries, float mult,
+                         float cmin, float cmax, int step_round) {
+  if (!table) return fail_arg("table is NULL");
+  if (int rc = check_pow2(mult)) return rc;
+  if (entries != table_entries(cmin, cmax)) return fail_arg("entries does not match the clip range");
+  fill_lut_common(op, thr, eps, mult, cmin, cmax, step_round);
+  op.table = table; op.entries = entries; op.koff = 0.5f - 2.0f * cmin;
+  return 0;
+}
+inline size_t table_bytes(int32_t entries) { return (size_t)(((entries + 1) * 2 + 3) & ~3) * 4; }
+
+// storage-type dispatch: f(TI{}, TO{})
+template <class F>
+static int with_affine_types(int dtype, F f) {
+  switch (dtype) {
+    case MCTQ_DT_F32: return f(float(), float());
+    case MCTQ_DT_F16: return f(_Float16(), _Float16());
+    case MCTQ_DT_BF16: return f(__bf16(), __bf16());
+    default: return fail_arg("unknown dtype");
+  }
+}
+template <class F>
+static int with_lut_types(int dtype, F f) {
+  switch (dtype) {
+    case MCTQ_DT_F32: return f(float(), float());
+    case MCTQ_DT_F16: return f(_Float16(), float());
+    case MCTQ_DT_BF16: return f(__bf16(), float());
+    default: return fail_arg("unknown dtype");
+  }
+}
+
+}  // namespace mctq

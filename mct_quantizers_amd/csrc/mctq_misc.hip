@@ -1,0 +1,94 @@
+// mctq_misc.hip -- part of libmctq_hip.so: shared state, tuning hook, diagnostics.
+#include "mctq_kernels.hpp"
+
+namespace mctq {
+
+thread_local char g_err[256] = "";
+int g_nt = 1;
+int g_unroll = 4;
+int g_heavy_unroll = 0;
+
+int fail_arg(const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return MCTQ_E_ARG;
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -(int)e;
+  }
+  return 0;
+}
+int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
+// Self-test: the fast division of the LUT ops against the compiler's IEEE '/' for EVERY float32 numerator.
+__global__ __launch_bounds__(kThreads) void selftest_division_kernel(const float* __restrict__ divisors, int n_div,
+                                                                     unsigned long long* __restrict__ mismatches) {
+  const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+  for (int j = 0; j < n_div; ++j) {
+    const LutCommon::Param p = LutCommon::make(divisors[j], divisors[j]);
+    unsigned int bad = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x; b < (1ull << 32); b += stride) {
+      const float x = __uint_as_float((uint32_t)b);
+      const float slow = x / p.d;
+      const float fast = LutCommon::can_fast(p) ? LutCommon::divide<true>(x, p) : LutCommon::divide<false>(x, p);
+      const float a = fabsf(slow);
+      bool ok;
+      if (a >= 0x1p-40f && a < 0x1p59f) ok = __float_as_uint(slow) == __float_as_uint(fast);    // exact domain
+      else if (slow != slow) ok = fast != fast;                                                   // NaN stays NaN
+      else if (a >= 0x1p59f) ok = fabsf(fast) >= 0x1p58f && (slow < 0) == (fast < 0);             // clamps alike
+      else ok = fabsf(fast) < 0x1p-39f;                                                           // stays tiny
+      bad += ok ? 0u : 1u;
+    }
+    if (bad) atomicAdd(&mismatches[j], (unsigned long long)bad);
+  }
+}
+
+}  // namespace mctq
+
+using namespace mctq;
+
+extern "C" {
+
+int mctq_abi_version(void) { return MCTQ_ABI_VERSION; }
+
+const char* mctq_last_error(void) { return g_err; }
+
+int mctq_set_tuning(const char* key, int32_t value) {
+  if (!key) return fail_arg("key is NULL");
+  if (!strcmp(key, "nt")) {
+    if (value != 0 && value != 1) return fail_arg("nt must be 0 or 1");
+    g_nt = value;
+    return 0;
+  }
+  if (!strcmp(key, "unroll")) {
+    if (value != 1 && value != 2 && value != 4 && value != 8) return fail_arg("unroll must be 1, 2, 4 or 8");
+    g_unroll = value;
+    return 0;
+  }
+  if (!strcmp(key, "heavy_unroll")) {
+    if (value != 0 && value != 1 && value != 2 && value != 4) return fail_arg("heavy_unroll must be 0, 1, 2 or 4");
+    g_heavy_unroll = value;
+    return 0;
+  }
+  return fail_arg("unknown tuning key");
+}
+
+int mctq_selftest_division(const float* divisors, int32_t n_div, uint64_t* mismatches, void* stream) {
+  if (!divisors || !mismatches || n_div < 1) return fail_arg("bad selftest arguments");
+  hipLaunchKernelGGL(selftest_division_kernel, dim3(cu_count() * 8), dim3(kThreads), 0, (hipStream_t)stream,
+                     divisors, (int)n_div, reinterpret_cast<unsigned long long*>(mismatches));
+  return check_launch("selftest launch");
+}
+
+}  // extern "C"

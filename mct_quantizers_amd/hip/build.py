@@ -14,12 +14,13 @@ import sys
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPO = os.path.dirname(PKG)
-SOURCES = [os.path.join(PKG, "csrc", "mctq_kernels.hip")]
-HEADERS = [os.path.join(REPO, "include", "mctq_hip.h")]
+CSRC = os.path.join(PKG, "csrc")
+SOURCES = [os.path.join(CSRC, f) for f in ("mctq_misc.hip", "mctq_affine.hip", "mctq_lut_scan.hip", "mctq_lut_table.hip")]
+HEADERS = [os.path.join(REPO, "include", "mctq_hip.h"), os.path.join(CSRC, "mctq_kernels.hpp")]
 OUT = os.path.join(PKG, "lib", "libmctq_hip.so")
 
 # -ffp-contract=off / no fast-math: the kernels must reproduce IEEE float32 results bit for bit.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -37,11 +38,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libmctq_hip.so")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objdir = os.path.join(os.path.dirname(OUT), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    inc = ["-I", os.path.join(REPO, "include"), "-I", CSRC]
+    # one hipcc per translation unit, in parallel (the units are independent)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc, *FLAGS, *inc, "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((obj, cmd, subprocess.Popen(cmd)))
+    objs = []
+    for obj, cmd, proc in procs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        objs.append(obj)
     tmp = OUT + ".tmp"
-    cmd = [hipcc, *FLAGS, "-I", os.path.join(REPO, "include"), "-o", tmp, *SOURCES]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True)
     os.replace(tmp, OUT)
     return OUT
 

@@ -85,9 +85,15 @@ class _on_device:
         return False
 
 
-def _require_f32(x: torch.Tensor, what: str):
-    if x.dtype != torch.float32:
-        raise NotImplementedError(f"{what}: the gfx950 kernels take float32 tensors, got {x.dtype}")
+_DTYPES = {torch.float32: native.DT_F32, torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}
+
+
+def _dtype_code(x: torch.Tensor, what: str) -> int:
+    code = _DTYPES.get(x.dtype)
+    if code is None:
+        raise NotImplementedError(f"{what}: the gfx950 kernels take float32, float16 or bfloat16 tensors, "
+                                  f"got {x.dtype}")
+    return code
 
 
 # ------------------------------------------------------------------------------------------
@@ -95,15 +101,15 @@ def _require_f32(x: torch.Tensor, what: str):
 # ------------------------------------------------------------------------------------------
 
 def _hip_fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
-    _require_f32(x, "fq_per_tensor")
+    dt = _dtype_code(x, "fq_per_tensor")
     lib = native.load()
     x = _dense_input(x)
     y = torch.empty_like(x)
     with _on_device(x):
-        rc = lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), scale, zero_point, qmin, qmax,
-                                        _stream(x))
+        rc = lib.mctq_fq_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
+                                    _stream(x))
     if rc:
-        native.check(rc, "mctq_fq_per_tensor_f32")
+        native.check(rc, "mctq_fq_per_tensor")
     return y
 
 
@@ -115,7 +121,7 @@ def _check_axis(x, n_params: int, axis: int):
 
 
 def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
-    _require_f32(x, "fq_per_channel")
+    dt = _dtype_code(x, "fq_per_channel")
     _check_axis(x, scales.numel(), axis)
     if scales.dtype != torch.float32 or zero_points.dtype != torch.int32:
         raise RuntimeError("scales must be float32 and zero_points int32")
@@ -126,51 +132,59 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int)
     scales = scales.contiguous()
     zero_points = zero_points.contiguous()
     with _on_device(x):
-        rc = lib.mctq_fq_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, scales.data_ptr(),
-                                         zero_points.data_ptr(), qmin, qmax, _stream(x))
+        rc = lib.mctq_fq_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
+                                     zero_points.data_ptr(), qmin, qmax, _stream(x))
     if rc:
-        native.check(rc, "mctq_fq_per_channel_f32")
+        native.check(rc, "mctq_fq_per_channel")
     return y
 
 
-def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None):
-    _require_f32(x, "lut_per_tensor")
+def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
+                        step_round: int = 0):
+    """LUT quantizer, one threshold.  Output is float32 whatever x's type (the reference's chain promotes)."""
+    dt = _dtype_code(x, "lut_per_tensor")
     lib = native.load()
     x = _dense_input(x)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x, dtype=torch.float32)
     with _on_device(x):
         if table is not None:
-            rc = lib.mctq_lutt_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, thr_mul,
-                                              table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
+            rc = lib.mctq_lutt_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
+                                          table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
         else:
             lut = lut.contiguous()
-            rc = lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), thr_div, thr_mul, lut.data_ptr(),
-                                             lut.numel(), mult, cmin, cmax, _stream(x))
+            if dt != native.DT_F32:                       # literal-scan fallback is float32-only: widen (exact)
+                if step_round:
+                    raise NotImplementedError("half-precision activation LUT needs a decision table "
+                                              "(integer codebook, lut_values_bitwidth <= 10)")
+                x, dt = x.float(), native.DT_F32
+            rc = lib.mctq_lut_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
+                                         lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
-        native.check(rc, "mctq_lut_per_tensor_f32")
+        native.check(rc, "mctq_lut_per_tensor")
     return y
 
 
 def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float,
                          table=None):
-    _require_f32(x, "lut_per_channel")
+    dt = _dtype_code(x, "lut_per_channel")
     _check_axis(x, thresholds.numel(), axis)
     lib = native.load()
     x = _dense_input(x)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x, dtype=torch.float32)
     outer, c, inner = _channel_view(x, axis)
     thresholds = thresholds.contiguous()
     with _on_device(x):
         if table is not None:
-            rc = lib.mctq_lutt_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(),
-                                               eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax,
-                                               _stream(x))
+            rc = lib.mctq_lutt_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
+                                           eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
         else:
             lut = lut.contiguous()
-            rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(),
-                                              eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
+            if dt != native.DT_F32:
+                x, dt = x.float(), native.DT_F32
+            rc = lib.mctq_lut_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
+                                          eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
-        native.check(rc, "mctq_lut_per_channel_f32")
+        native.check(rc, "mctq_lut_per_channel")
     return y
 
 
@@ -206,7 +220,12 @@ def _cpu_lut(x, lut, thr_div, thr_mul, mult, cmin, cmax):
     return (lut.flatten()[idx] / mult) * thr_mul
 
 
-def _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax):
+def _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round: int = 0):
+    # step_round == 0: the threshold is a float32 TENSOR in the reference (weights), so a half-precision
+    # input is promoted to float32 by the first division; otherwise (activation, Python-float threshold)
+    # the chain stays in the input's type until the float32 codebook enters.
+    if step_round == 0 and x.dtype != torch.float32:
+        x = x.float()
     return _cpu_lut(x, lut, thr_div, thr_mul, mult, cmin, cmax)
 
 
@@ -261,12 +280,13 @@ def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
     return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
 
 
-def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None):
+def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
+                   step_round: int = 0):
     if _is_real(x):
         if x.is_cuda:
-            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table)
+            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round)
         if x.device.type == "cpu":
-            return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+            return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round)
     return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
 
 

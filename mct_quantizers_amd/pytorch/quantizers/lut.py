@@ -17,7 +17,7 @@ import torch
 
 from mct_quantizers_amd.common.constants import EPS, LUT_VALUES_BITWIDTH
 from mct_quantizers_amd.common.registry import QuantizationMethod, QuantizationTarget, QuantizerID, mark_quantizer
-from mct_quantizers_amd.hip import ops
+from mct_quantizers_amd.hip import native, ops
 from mct_quantizers_amd.pytorch.quantizer_utils import get_working_device, lut_domain, to_torch_tensor
 from mct_quantizers_amd.pytorch.quantizers.affine import BasePyTorchInferableQuantizer, _is_pot
 
@@ -148,13 +148,23 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
     def _rebuild_launch_state(self):
         dev = get_working_device()
         self.lut_values = to_torch_tensor(self._lut_values_np).to(dev)
-        # Python-float threshold: threshold + eps is a DOUBLE add, narrowed to float32 at the division
+        # Python-float threshold: threshold + eps is a DOUBLE add; the division then narrows it to the
+        # tensor's type (float32, or float16/bfloat16 for half-precision activations).
         self._thr_mul0 = float(np.float32(self.threshold))
-        self._thr_div0 = float(np.float32(float(self.threshold) + self.eps))
+        div64 = torch.tensor([float(self.threshold) + self.eps], dtype=torch.float64)
+        self._thr_div_by_dtype = {dt: float(div64.to(dt).item())
+                                  for dt in (torch.float32, torch.float16, torch.bfloat16)}
         self._lut_table_torch = ops.make_lut_table(self._lut_values_np,
                                                    *lut_domain(self.lut_values_bitwidth, self.signed), dev)
 
     def __call__(self, inputs: torch.Tensor):
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
-        return ops.lut_per_tensor(inputs, self.lut_values, self._thr_div0, self._thr_mul0, mult, cmin, cmax,
-                                  self._lut_table_torch)
+        dt = getattr(inputs, "dtype", torch.float32)
+        step = {torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}.get(dt, 0)
+        if type(inputs) in (torch.Tensor, torch.nn.Parameter) and not inputs.is_cuda:
+            # CPU tensor: hand ATen the same double the reference hands it
+            return ops.lut_per_tensor(inputs, self.lut_values, float(self.threshold) + self.eps, self._thr_mul0,
+                                      mult, cmin, cmax, None, step or -1)
+        thr_div = self._thr_div_by_dtype.get(dt, self._thr_div_by_dtype[torch.float32])
+        return ops.lut_per_tensor(inputs, self.lut_values, thr_div, self._thr_mul0, mult, cmin, cmax,
+                                  self._lut_table_torch, step)

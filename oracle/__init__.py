@@ -10,7 +10,19 @@ import numpy as np
 from . import mctq_oracle as O
 
 
-def oracle_call(cls_name: str, kwargs: dict, x: np.ndarray, return_index: bool = False):
+def oracle_call(cls_name: str, kwargs: dict, x: np.ndarray, return_index: bool = False, in_dtype: str = "float32"):
+    """``x`` holds the tensor's values widened to float32; ``in_dtype`` is the tensor's storage type.
+    Affine quantizers return values of that type (widened), LUT quantizers return float32."""
+    if in_dtype != "float32":
+        assert not return_index
+        if "LUT" in cls_name or "Lut" in cls_name:
+            if cls_name == "ActivationLutPOTInferableQuantizer":
+                kw = dict(kwargs)
+                return O.lut_quantize(x, kw["lut_values"], float(kw["threshold"][0]), kw["signed"],
+                                      kw.get("lut_values_bitwidth", O.LUT_VALUES_BITWIDTH), kw.get("eps", O.EPS),
+                                      step_dtype=in_dtype)
+            return oracle_call(cls_name, kwargs, x)
+        return O.narrow(oracle_call(cls_name, kwargs, x), in_dtype)
     kw = dict(kwargs)
     nb = kw["num_bits"]
     if cls_name in ("WeightsSymmetricInferableQuantizer", "WeightsPOTInferableQuantizer"):

@@ -144,6 +144,26 @@ def validate_lut(num_bits, lut_values, threshold, signed, lut_values_bitwidth):
 
 
 # --------------------------------------------------------------------------
+# half-precision storage (float16 / bfloat16 tensors; arithmetic stays float32)
+# --------------------------------------------------------------------------
+
+def narrow(a, dtype: str) -> np.ndarray:
+    """Round float32 values to ``dtype`` (round-to-nearest-even) and widen back to float32."""
+    a = np.asarray(a, dtype=F32)
+    if dtype == "float32":
+        return a
+    if dtype == "float16":
+        with np.errstate(all="ignore"):
+            return a.astype(np.float16).astype(F32)
+    if dtype == "bfloat16":
+        u = a.view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        out = (r & 0xFFFFFFFF).astype(np.uint32).view(F32)
+        return np.where(np.isnan(a), a, out).astype(F32)
+    raise KeyError(dtype)
+
+
+# --------------------------------------------------------------------------
 # element arithmetic (__call__)
 # --------------------------------------------------------------------------
 
@@ -192,7 +212,7 @@ def fake_quant_affine(x: np.ndarray, scale, zero_point, qmin: int, qmax: int,
 def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
                  lut_values_bitwidth: int = LUT_VALUES_BITWIDTH, eps: float = EPS,
                  per_channel: bool = False, channel_axis=None,
-                 return_index: bool = False, chunk_elems: int = 1 << 20):
+                 return_index: bool = False, chunk_elems: int = 1 << 20, step_dtype: str = "float32"):
     """pytorch/quantizer_utils.py:95-139 (lut_quantizer) + :142-170, float32.
 
     ``threshold`` is a float32 vector (weights, per-channel or 1 element) or a
@@ -201,6 +221,10 @@ def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
     float32 scalar.  The codebook scan is the literal first-minimum argmin over
     float32 |t - lut[j]| in list order (quantizer_utils.py:131-134).
     Processes the tensor in chunks so the N x L temporaries stay small.
+
+    ``step_dtype`` ("float16"/"bfloat16", Python-float threshold only): the tensor is a half-precision
+    activation, so ATen narrows the scalar divisor, the quotient and the scaled value to that type
+    before the float32 codebook promotes the rest of the chain to float32.
     """
     x = np.asarray(x, dtype=F32)
     lut = np.asarray(lut_values, dtype=F32).reshape(-1)
@@ -213,7 +237,10 @@ def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
 
     if isinstance(threshold, (float, int)):
         thr_mul = np.broadcast_to(F32(threshold), x.shape)
-        thr_div = np.broadcast_to(F32(float(threshold) + eps), x.shape)   # double add, then fp32
+        div = F32(float(threshold) + eps)                                  # double add, then fp32
+        if step_dtype != "float32":
+            div = narrow(div, step_dtype).reshape(())[()]                  # ... then the tensor's type
+        thr_div = np.broadcast_to(div, x.shape)
     else:
         thr = np.asarray(threshold, dtype=F32).reshape(-1)
         if per_channel:
@@ -229,7 +256,10 @@ def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
     with np.errstate(all="ignore"):
         for lo in range(0, xf.size, chunk_elems):
             hi = min(lo + chunk_elems, xf.size)
-            t = (xf[lo:hi] / td[lo:hi]) * m
+            if step_dtype == "float32":
+                t = (xf[lo:hi] / td[lo:hi]) * m
+            else:
+                t = narrow(narrow(xf[lo:hi] / td[lo:hi], step_dtype) * m, step_dtype)
             t = np.where(np.isnan(t), t, np.minimum(np.maximum(t, cmin), cmax))  # torch.clip keeps NaN
             d = np.abs(t[:, None] - lut[None, :])
             # torch.argmin: first minimum, NaN counts as the minimum -> index 0 for an all-NaN row

@@ -26,6 +26,23 @@ def golden_cases():
     return meta["cases"], arrays
 
 
+@pytest.fixture(scope="session")
+def half_cases():
+    with open(os.path.join(GOLDEN, "cases_half.json")) as f:
+        meta = json.load(f)
+    arrays = np.load(os.path.join(GOLDEN, "cases_half.npz"))
+    return meta["cases"], arrays
+
+
+def finite_equal(got, want, x):
+    """Bit equality wherever the input is finite (non-finite inputs are outside the parity domain:
+    the reference's CPU path runs into int64-cast UB there)."""
+    m = np.isfinite(np.asarray(x))
+    got = np.ascontiguousarray(got, dtype=np.float32)
+    want = np.ascontiguousarray(want, dtype=np.float32)
+    return got.shape == want.shape and np.array_equal(got.view(np.uint32)[m], want.view(np.uint32)[m])
+
+
 def load_json(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)

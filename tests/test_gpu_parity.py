@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import bits_equal, first_mismatch, load_json
+from conftest import bits_equal, finite_equal, first_mismatch, load_json
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,63 @@ def test_golden_cases_via_quantizer_classes(lib, golden_cases):
         got = y.cpu().numpy()
         assert bits_equal(got, want), f'{c["id"]} {c["cls"]} {c["shape"]} {c["memory_format"]}: ' \
                                       f'{first_mismatch(got, want, x_np)}'
+
+
+def test_half_precision_golden_cases_via_quantizer_classes(lib, half_cases):
+    """float16 / bfloat16 tensors: affine quantizers keep the type, LUT quantizers return float32."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    cases, arrays = half_cases
+    for c in cases:
+        x32 = arrays[c["id"] + "_x"]
+        x = _dev(x32).to(getattr(torch, c["in_dtype"]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(Q, c["cls"])(**c["kwargs"])
+        y = q(x)
+        assert y.is_cuda and str(y.dtype) == "torch." + c["out_dtype"], c["id"]
+        got = y.float().cpu().numpy()
+        want = arrays[c["id"] + "_y"]
+        assert finite_equal(got, want, x32), f'{c["id"]} {c["cls"]} {c["in_dtype"]} {c["shape"]}: ' \
+                                             f'{first_mismatch(got, want, x32)}'
+
+
+@pytest.mark.parametrize("dt", ["float16", "bfloat16"])
+@pytest.mark.parametrize("outer,C,inner,offset", [(1, 1, 5, 0), (7, 3, 1, 0), (33, 5, 2, 1), (2, 16, 8, 0), (3, 64, 12, 3),
+                                                  (1, 300, 576, 0), (2, 6, 1024, 0), (3, 5, 1032, 0), (1, 64, 4096, 0),
+                                                  (2, 3, 11008, 8), (1, 20000, 1, 0), (1, 2, 70000, 0), (1, 1, 4099, 1)])
+def test_abi_half_per_channel_and_per_tensor_vs_oracle(lib, dt, outer, C, inner, offset):
+    from oracle import mctq_oracle as O
+    code = {"float16": 1, "bfloat16": 2}[dt]
+    tdt = getattr(torch, dt)
+    rng = np.random.default_rng(C * 7 + inner + offset)
+    qmin, qmax = -128, 127
+    scales = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+    zps = rng.integers(-5, 6, size=C).astype(np.int32)
+    shape = (outer, C, inner)
+    x32 = _tie_heavy(rng, shape, scales.reshape(1, C, 1), zps.reshape(1, C, 1).astype(np.float32), qmin, qmax)
+    xh = _dev(x32.reshape(-1)).to(tdt)
+    x_np = xh.float().cpu().numpy().reshape(shape)                 # the values actually stored
+    n = x_np.size
+    xb = torch.empty(n + offset, dtype=tdt, device="cuda")
+    xb[offset:] = xh
+    yb = torch.full_like(xb, 512.0)
+    s_d, z_d = _dev(scales), _dev(zps)
+    rc = lib.mctq_fq_per_channel(xb[offset:].data_ptr(), yb[offset:].data_ptr(), outer, C, inner, code,
+                                 s_d.data_ptr(), z_d.data_ptr(), qmin, qmax, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want = O.narrow(O.fake_quant_affine(x_np, scales, zps, qmin, qmax, axis=1), dt)
+    got = yb.float().cpu().numpy()
+    assert finite_equal(got[offset:].reshape(shape), want, x_np), first_mismatch(got[offset:], want, x_np)
+    if offset:
+        assert np.all(got[:offset] == 512.0)
+    yb.fill_(512.0)
+    rc = lib.mctq_fq_per_tensor(xb[offset:].data_ptr(), yb[offset:].data_ptr(), n, code, float(scales[0]), int(zps[0]),
+                                qmin, qmax, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want = O.narrow(O.fake_quant_affine(x_np, scales[0], zps[0], qmin, qmax), dt)
+    got = yb.float().cpu().numpy()
+    assert finite_equal(got[offset:].reshape(shape), want, x_np), first_mismatch(got[offset:], want, x_np)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -431,7 +488,7 @@ def test_loud_failures(lib, monkeypatch):
     from mct_quantizers_amd.hip import native
     q = mq.pytorch_quantizers.ActivationSymmetricInferableQuantizer(8, [4.0], True)
     with pytest.raises(NotImplementedError):
-        q(torch.zeros(8, device="cuda", dtype=torch.float64))
+        q(torch.zeros(8, device="cuda", dtype=torch.float64))              # float64 is not a kernel type
     qc = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0], True, 0)
     with pytest.raises(RuntimeError):
         qc(torch.zeros(3, 4, device="cuda"))                   # 2 scales for 3 channels

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import mct_quantizers_amd as mq
-from conftest import bits_equal, first_mismatch, load_json
+from conftest import bits_equal, finite_equal, first_mismatch, load_json
 from mct_quantizers_amd import (PytorchActivationQuantizationHolder, PytorchFLNActivationQuantizationHolder,
                                 PytorchPreservingActivationQuantizationHolder, PytorchQuantizationWrapper,
                                 QuantizationMethod, QuantizationTarget, get_inferable_quantizer_class)
@@ -31,6 +31,19 @@ def test_cpu_tensors_take_the_aten_route_and_match_goldens(golden_cases):
         got = q(x).numpy()
         want = arrays[c["id"] + "_y"]
         assert bits_equal(got, want), f'{c["id"]} {c["cls"]}: {first_mismatch(got, want)}'
+
+
+def test_half_precision_cpu_tensors_match_goldens(half_cases):
+    cases, arrays = half_cases
+    for c in cases:
+        x32 = arrays[c["id"] + "_x"]
+        x = torch.from_numpy(x32).to(getattr(torch, c["in_dtype"]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(Q, c["cls"])(**c["kwargs"])
+        y = q(x)
+        assert str(y.dtype) == "torch." + c["out_dtype"], c["id"]
+        assert finite_equal(y.float().numpy(), arrays[c["id"] + "_y"], x32), f'{c["id"]} {c["cls"]} {c["in_dtype"]}'
 
 
 def test_constructor_attributes_match_reference():

@@ -9,7 +9,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import bits_equal, first_mismatch, load_json
+from conftest import bits_equal, finite_equal, first_mismatch, load_json
 from oracle import mctq_oracle as O
 from oracle import oracle_call
 
@@ -23,6 +23,18 @@ def test_every_golden_case_bit_exact(golden_cases):
         got = oracle_call(c["cls"], c["kwargs"], x)
         assert bits_equal(got, want), f'{c["id"]} {c["cls"]} {c["kwargs"].get("num_bits")}b: ' \
                                       f'{first_mismatch(got, want, x)}'
+
+
+def test_half_precision_cases_bit_exact(half_cases):
+    cases, arrays = half_cases
+    assert len(cases) >= 70
+    for c in cases:
+        x = arrays[c["id"] + "_x"]
+        want = arrays[c["id"] + "_y"]
+        got = oracle_call(c["cls"], c["kwargs"], x, in_dtype=c["in_dtype"])
+        assert finite_equal(got, want, x), f'{c["id"]} {c["cls"]} {c["in_dtype"]}: {first_mismatch(got, want, x)}'
+        is_lut = "LUT" in c["cls"] or "Lut" in c["cls"]
+        assert c["out_dtype"] == ("float32" if is_lut else c["in_dtype"])
 
 
 def test_constructor_goldens():

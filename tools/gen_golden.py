@@ -386,6 +386,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--pickles-only", action="store_true")
+    ap.add_argument("--half-only", action="store_true")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     gen_affine_cases()
@@ -405,6 +406,87 @@ def main():
     print(f"{len(cases)} cases, {sum(a.nbytes for a in arrays.values())} array bytes")
 
 
+
+
+def gen_half_cases():
+    """float16 / bfloat16 inputs: ATen keeps the input type for the affine quantizers, the LUT chain promotes
+    to float32.  Inputs/outputs are stored widened to float32 (exact) with their dtype names."""
+    hc, ha = [], {}
+
+    def add(cls_name, kwargs, x32, dt_name):
+        dt = getattr(torch, dt_name)
+        xt = torch.from_numpy(np.ascontiguousarray(x32)).to(dt)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(refq, cls_name)(**kwargs)
+        y = q(xt.clone())
+        cid = f"h{len(hc):03d}"
+        ha[cid + "_x"] = xt.float().numpy()
+        ha[cid + "_y"] = y.detach().float().numpy()
+        hc.append(dict(id=cid, cls=cls_name, kwargs=kwargs, shape=list(x32.shape), in_dtype=dt_name,
+                       out_dtype=str(y.dtype).replace("torch.", "")))
+
+    for dt_name in ("float16", "bfloat16"):
+        for bits in (4, 8):
+            qmin, qmax = -2 ** (bits - 1), 2 ** (bits - 1) - 1
+            thr = [float(rng.uniform(0.3, 5.0))]
+            add("WeightsSymmetricInferableQuantizer", dict(num_bits=bits, threshold=thr, per_channel=False),
+                adversarial((7, 33, 5), np.asarray(thr) / 2 ** (bits - 1), None, qmin, qmax), dt_name)
+            for shape, axis in (((6, 40), 0), ((5, 7, 11), 1), ((1, 10, 10, 3), 3), ((3, 2048), 0), ((2, 3, 1032), 1)):
+                C = shape[axis]
+                thr = [float(v) for v in rng.uniform(0.05, 7.0, size=C)]
+                add("WeightsSymmetricInferableQuantizer",
+                    dict(num_bits=bits, threshold=thr, per_channel=True, channel_axis=axis),
+                    adversarial(shape, np.asarray(thr) / 2 ** (bits - 1), axis, qmin, qmax), dt_name)
+            thr = [float(2.0 ** e) for e in rng.integers(-3, 3, size=6)]
+            add("WeightsPOTInferableQuantizer", dict(num_bits=bits, threshold=thr, per_channel=True, channel_axis=0),
+                adversarial((6, 48), np.asarray(thr) / 2 ** (bits - 1), 0, qmin, qmax), dt_name)
+            lo = [float(v) for v in rng.uniform(-4.0, 0.5, size=5)]
+            hi = [float(a + d) for a, d in zip(lo, rng.uniform(0.2, 6.0, size=5))]
+            kw = dict(num_bits=bits, min_range=lo, max_range=hi, per_channel=True, channel_axis=1)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                q = refq.WeightsUniformInferableQuantizer(**kw)
+            add("WeightsUniformInferableQuantizer", kw,
+                adversarial((3, 5, 24), q.scales.numpy().reshape(-1), 1, 0, 2 ** bits - 1, q.zero_points.numpy().reshape(-1)),
+                dt_name)
+            for signed in (True, False):
+                thr = [float(rng.uniform(0.5, 6.0))]
+                sc = np.asarray(thr) / (2 ** (bits - 1) if signed else 2 ** bits)
+                dom = (qmin, qmax) if signed else (0, 2 ** bits - 1)
+                add("ActivationSymmetricInferableQuantizer", dict(num_bits=bits, threshold=thr, signed=signed),
+                    adversarial((2, 3, 17, 9), sc, None, *dom), dt_name)
+            add("ActivationPOTInferableQuantizer", dict(num_bits=bits, threshold=[4.0], signed=True),
+                adversarial((3, 50), np.asarray([4.0]) / 2 ** (bits - 1), None, qmin, qmax), dt_name)
+            kw = dict(num_bits=bits, min_range=[-2.5], max_range=[3.1])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                q = refq.ActivationUniformInferableQuantizer(**kw)
+            add("ActivationUniformInferableQuantizer", kw,
+                adversarial((2, 3, 12, 12), [q.scale], None, 0, 2 ** bits - 1, [q.zero_point]), dt_name)
+        lut16 = list(workloads.CFG4_LUT)
+        lut8 = [22.0, -53.0, 62.0, 0.0, -66.0, -21.0, 44.0, -40.0]
+        for lut, bits in ((lut16, 4), (lut8, 3)):
+            thr = [float(rng.uniform(0.5, 3.0))]
+            add("WeightsLUTSymmetricInferableQuantizer",
+                dict(num_bits=bits, lut_values=lut, threshold=thr, per_channel=False), lut_input((9, 31), thr, None), dt_name)
+            for shape, axis in (((6, 37), 0), ((5, 7, 12), 1), ((3, 2048), 0)):
+                C = shape[axis]
+                thr = [float(v) for v in rng.uniform(0.05, 4.0, size=C)]
+                add("WeightsLUTSymmetricInferableQuantizer",
+                    dict(num_bits=bits, lut_values=lut, threshold=thr, per_channel=True, channel_axis=axis,
+                         input_rank=len(shape)), lut_input(shape, thr, axis), dt_name)
+            add("ActivationLutPOTInferableQuantizer", dict(num_bits=bits, lut_values=lut, threshold=[2.0], signed=True),
+                lut_input((2, 3, 8, 8), [2.0], None), dt_name)
+            add("ActivationLutPOTInferableQuantizer", dict(num_bits=bits, lut_values=lut, threshold=[0.5], signed=True),
+                lut_input((3, 700), [0.5], None), dt_name)
+        add("ActivationLutPOTInferableQuantizer",
+            dict(num_bits=3, lut_values=[0.0, 13.0, 50.0, 90.0, 128.0, 200.0, 255.0, 256.0], threshold=[4.0], signed=False),
+            np.abs(lut_input((3, 64), [4.0], None)) * np.float32(1.3), dt_name)
+    np.savez_compressed(os.path.join(OUT, "cases_half.npz"), **ha)
+    with open(os.path.join(OUT, "cases_half.json"), "w") as f:
+        json.dump(dict(meta=dict(generator="tools/gen_golden.py", torch=torch.__version__), cases=hc), f, indent=1)
+    print(len(hc), "half-precision cases")
 
 
 def gen_pickled_reference_models():
@@ -446,6 +528,9 @@ if __name__ == "__main__":
     if "--pickles-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         gen_pickled_reference_models()
+    elif "--half-only" in sys.argv:
+        gen_half_cases()
     else:
         main()
+        gen_half_cases()
         gen_pickled_reference_models()
