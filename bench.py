@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--gather", action="store_true", help="also time the all-gather of dim-0 shards (N > 1)")
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="issue independent steps round-robin on this many HIP streams (default 1: the judged protocol)")
     return ap.parse_args()
 
 
@@ -64,7 +66,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (args.gather and "RANK" in os.environ):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -90,8 +92,14 @@ def main():
     xs = [x0] + [x0.clone() for _ in range(ring - 1)]
     ys = [None] * ring
 
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+
     def step(i):
-        ys[i % ring] = quantizer(xs[i % ring])
+        if streams is None:
+            ys[i % ring] = quantizer(xs[i % ring])
+        else:
+            with torch.cuda.stream(streams[i % len(streams)]):
+                ys[i % ring] = quantizer(xs[i % ring])
 
     for i in range(args.warmup):
         step(i)
@@ -117,6 +125,9 @@ def main():
     else:
         for i in range(args.steps):
             step(i)
+    if streams is not None:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
     ev1.record()
     torch.cuda.synchronize()
     if dist:
@@ -149,29 +160,13 @@ def main():
         "data": "synthetic (portable splitmix64 generator, mct_quantizers_amd/workloads.py)",
         "config": {"workload": wl.name, "shape": list(wl.shape), "quantizer": wl.quantizer,
                    "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
-                   "launch": "hipGraph" if graph is not None else "eager",
+                   "launch": "hipGraph" if graph is not None else "eager", "streams": args.streams,
                    "parallelism": f"replicated x{world} (weak, no collective)"},
         "achieved_gbs": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                      "traffic": None, "kernel_us": launch_us, "algorithmic_bytes_per_launch": alg_bytes},
     }
-
-    if args.gather and dist:
-        shard = ys[(args.steps - 1) % ring]
-        full = torch.empty((shard.shape[0] * world,) + tuple(shard.shape[1:]), device="cuda", dtype=shard.dtype)
-        for _ in range(3):
-            dist.all_gather_into_tensor(full, shard)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            dist.all_gather_into_tensor(full, shard)
-        torch.cuda.synchronize()
-        g = (time.perf_counter() - g0) / reps
-        result["allgather"] = {"ms": g * 1e3, "bytes_received_per_rank": shard.numel() * 4 * (world - 1),
-                               "gbs_per_rank": shard.numel() * 4 * (world - 1) / g / 1e9}
 
     # measured HBM traffic per launch (rocprofv3 PMC passes, committed under profiles/; null if not profiled)
     try:
@@ -182,6 +177,66 @@ def main():
             result["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     except OSError:
         pass
+
+    if dist and (args.gather or world > 1):
+        # Extras for N > 1 (outside the timed region, never allowed to break the main line):
+        # BASELINE config 5, WeightsPOT 4-bit per-channel on 8192x8192, sharded by dim 0 across the ranks
+        # (strong scaling: rank r quantizes rows [8192 r / N, 8192 (r+1) / N)), then ONE all-gather over xGMI.
+        import threading
+        main_line = json.dumps(result)
+
+        def _bail():                                   # a stuck collective must not cost the main result
+            if rank == 0:
+                print(main_line, flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(120.0, _bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            from mct_quantizers_amd.sharded import ShardedWeightsQuantizer, row_block
+            rows5 = 8192
+            start, stop = row_block(rows5, world, rank)
+            # every rank derives the same thresholds from the same portable input (no object collective)
+            x5_full = workloads.make_input("cfg5", shape=(rows5, 8192))
+            kw5 = workloads.make_workload("cfg5", x5_full).kwargs
+            x5_local = torch.from_numpy(x5_full[start:stop].copy()).cuda()
+            del x5_full
+            sq = ShardedWeightsQuantizer("WeightsPOTInferableQuantizer", kw5, full_rows=rows5)
+            xs5 = [x5_local, x5_local.clone(), x5_local.clone()]
+            for i in range(6):
+                y5 = sq(xs5[i % 3])
+            torch.cuda.synchronize()
+            dist.barrier()
+            c0 = time.perf_counter()
+            reps = 60
+            for i in range(reps):
+                y5 = sq(xs5[i % 3])
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_comp = (time.perf_counter() - c0) / reps
+            for _ in range(3):
+                full5 = sq.all_gather(y5)
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            greps = 20
+            for _ in range(greps):
+                full5 = sq.all_gather(y5)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_gather = (time.perf_counter() - g0) / greps
+            recv = (rows5 - (stop - start)) * 8192 * 4
+            result["sharded_cfg5"] = {
+                "workload": "cfg5 WeightsPOT per-channel(axis0) 4b 8192x8192, dim-0 shards",
+                "scaling": "strong", "rows_per_rank": stop - start,
+                "compute_ms": t_comp * 1e3, "compute_elems_per_s": rows5 * 8192 / t_comp,
+                "allgather_ms": t_gather * 1e3, "allgather_recv_bytes_per_rank": recv,
+                "allgather_recv_gbs_per_rank": recv / t_gather / 1e9,
+                "compute_plus_allgather_elems_per_s": rows5 * 8192 / (t_comp + t_gather)}
+        except Exception as e:  # noqa: BLE001  (extras only)
+            result["sharded_cfg5"] = {"error": repr(e)[:300]}
+        finally:
+            watchdog.cancel()
 
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import torch_cpu
