@@ -61,28 +61,47 @@ def _channel_view(x: torch.Tensor, axis: int) -> Tuple[int, int, int]:
     return outer, c, inner
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream      # (device index) -> hipStream_t as int
+_current_device = torch._C._cuda_getDevice
+
+
 def _stream(x: torch.Tensor) -> int:
-    return torch._C._cuda_getCurrentRawStream(x.device.index)
+    return _raw_stream(x.get_device())
 
 
 class _on_device:
-    """Make x's device current for the launch (no-op in the single-device case)."""
+    """Make x's device current for the launch (only entered when it is not already current)."""
     __slots__ = ("idx", "prev")
 
-    def __init__(self, x):
-        self.idx = x.device.index
+    def __init__(self, idx):
+        self.idx = idx
         self.prev = -1
 
     def __enter__(self):
-        cur = torch.cuda.current_device()
-        if cur != self.idx:
-            self.prev = cur
-            torch.cuda.set_device(self.idx)
+        self.prev = _current_device()
+        torch.cuda.set_device(self.idx)
 
     def __exit__(self, *exc):
-        if self.prev >= 0:
-            torch.cuda.set_device(self.prev)
+        torch.cuda.set_device(self.prev)
         return False
+
+
+class _noop:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOOP = _noop()
+
+
+def _maybe_on_device(x):
+    idx = x.get_device()
+    return _NOOP if idx == _current_device() else _on_device(idx)
 
 
 _DTYPES = {torch.float32: native.DT_F32, torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}
@@ -101,13 +120,22 @@ def _dtype_code(x: torch.Tensor, what: str) -> int:
 # ------------------------------------------------------------------------------------------
 
 def _hip_fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
-    dt = _dtype_code(x, "fq_per_tensor")
+    # hot for small activations (launch-bound): keep the Python between the caller and the launch short
+    dt = _DTYPES.get(x.dtype)
+    if dt is None:
+        _dtype_code(x, "fq_per_tensor")
     lib = native.load()
-    x = _dense_input(x)
+    if not x.is_contiguous():
+        x = _dense_input(x)
     y = torch.empty_like(x)
-    with _on_device(x):
+    idx = x.get_device()
+    if idx == _current_device():
         rc = lib.mctq_fq_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
-                                    _stream(x))
+                                    _raw_stream(idx))
+    else:
+        with _on_device(idx):
+            rc = lib.mctq_fq_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
+                                        _raw_stream(idx))
     if rc:
         native.check(rc, "mctq_fq_per_tensor")
     return y
@@ -131,7 +159,7 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int)
     outer, c, inner = _channel_view(x, axis)
     scales = scales.contiguous()
     zero_points = zero_points.contiguous()
-    with _on_device(x):
+    with _maybe_on_device(x):
         rc = lib.mctq_fq_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
                                      zero_points.data_ptr(), qmin, qmax, _stream(x))
     if rc:
@@ -146,7 +174,7 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
     lib = native.load()
     x = _dense_input(x)
     y = torch.empty_like(x, dtype=torch.float32)
-    with _on_device(x):
+    with _maybe_on_device(x):
         if table is not None:
             rc = lib.mctq_lutt_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
                                           table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
@@ -173,7 +201,7 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
     y = torch.empty_like(x, dtype=torch.float32)
     outer, c, inner = _channel_view(x, axis)
     thresholds = thresholds.contiguous()
-    with _on_device(x):
+    with _maybe_on_device(x):
         if table is not None:
             rc = lib.mctq_lutt_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                            eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))

@@ -249,6 +249,10 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
         self.zero_points = 0
 
     def __call__(self, inputs: torch.Tensor):
+        if type(inputs) is torch.Tensor and inputs.is_cuda:
+            # the HIP launch records nothing for autograd: no need for the no_grad context on this path
+            return ops._hip_fq_per_tensor(inputs, self.scales, self.zero_points,
+                                          self.min_quantized_domain, self.max_quantized_domain)
         with torch.no_grad():
             return ops.fq_per_tensor(inputs, self.scales, self.zero_points,
                                      self.min_quantized_domain, self.max_quantized_domain)
@@ -283,6 +287,9 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
         self.zero_point = int(-np.round(self.min_range / self.scale))   # round half even, in double
 
     def __call__(self, inputs: torch.Tensor):
+        if type(inputs) is torch.Tensor and inputs.is_cuda:
+            return ops._hip_fq_per_tensor(inputs, self.scale, self.zero_point,
+                                          self.min_quantized_domain, self.max_quantized_domain)
         with torch.no_grad():
             return ops.fq_per_tensor(inputs, self.scale, self.zero_point,
                                      self.min_quantized_domain, self.max_quantized_domain)

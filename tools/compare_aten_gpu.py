@@ -1,0 +1,67 @@
+"""This package's kernels vs what the REFERENCE would execute on the same MI355X: ATen's own HIP
+fake_quantize kernels (per-tensor / per-channel) and the reference's torch op chain for LUT, on identical
+device-resident tensors, cold-cache ring protocol.  Prints a table; used for profiles/ and DESIGN.md."""
+import os, sys, time, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mct_quantizers_amd as mq
+from mct_quantizers_amd import workloads
+
+def timeit(f, xs, steps):
+    n = len(xs); outs = [None] * n
+    for i in range(min(steps, 10)): outs[i % n] = f(xs[i % n])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps): outs[i % n] = f(xs[i % n])
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / steps, outs[(steps - 1) % n]
+
+def lut_chain_gpu(x, lut, thr, eps, axis, B=8):
+    shape = [1] * x.dim(); shape[axis] = -1
+    t = thr.reshape(shape)
+    v = torch.clip((x / (t + eps)) * (2 ** (B - 1)), min=-2 ** (B - 1), max=2 ** (B - 1) - 1).unsqueeze(-1)
+    idx = torch.argmin(torch.abs(v - lut.reshape([1] * (v.dim() - 1) + [-1])), dim=-1)
+    return (lut.flatten()[idx] / (2 ** (B - 1))) * t
+
+rows = []
+def case(name, q, x, aten, steps=100, bytes_per_elem=8):
+    ring = max(2, -(-(512 << 20) // (x.numel() * bytes_per_elem)) + 1)
+    xs = [x] + [x.clone() for _ in range(ring - 1)]
+    t_ours, y = timeit(q, xs, steps)
+    t_aten, ya = timeit(aten, xs, max(3, steps // 4))
+    same = bool(torch.equal(y, ya))
+    gbs = x.numel() * bytes_per_elem / t_ours / 1e3
+    rows.append((name, tuple(x.shape), t_ours, t_aten, t_aten / t_ours, gbs, same))
+    print(f"{name:44s} {str(tuple(x.shape)):22s} ours {t_ours:9.2f} us  ATen/ref-chain {t_aten:10.2f} us  x{t_aten/t_ours:6.2f}  {gbs:6.0f} GB/s  equal={same}", flush=True)
+
+Q = mq.pytorch_quantizers
+for cfg, shape in (("cfg2", None), ("cfg5", None)):
+    x_np = workloads.make_input(cfg); wl = workloads.make_workload(cfg, x_np)
+    q = getattr(Q, wl.quantizer)(**wl.kwargs); x = torch.from_numpy(x_np).cuda()
+    case(wl.name, q, x, lambda t, q=q: torch.fake_quantize_per_channel_affine(t, q.scales, q.zero_points, 0, q.min_quantized_domain, q.max_quantized_domain))
+for n in (1, 8, 64, 256):
+    x_np = workloads.make_input("cfg3", batch=n); wl = workloads.make_workload("cfg3", x_np)
+    q = getattr(Q, wl.quantizer)(**wl.kwargs); x = torch.from_numpy(x_np).cuda()
+    case(f"cfg3 ActivationUniform N={n}", q, x, lambda t, q=q: torch.fake_quantize_per_tensor_affine(t, q.scale, q.zero_point, 0, 255), steps=300)
+# LUT config 4: the reference chain materialises N x 16 temporaries (2 x 2.9 GB here)
+x_np = workloads.make_input("cfg4"); wl = workloads.make_workload("cfg4", x_np)
+q = getattr(Q, wl.quantizer)(**wl.kwargs); x = torch.from_numpy(x_np).cuda()
+case(wl.name, q, x, lambda t, q=q: lut_chain_gpu(t, q._lut_values_torch, q._threshold_torch, q.eps, 0), steps=40)
+# channel-last activations / conv weights: the window kernel's shapes
+x = torch.randn(64, 256, 56, 56, device="cuda").contiguous(memory_format=torch.channels_last)
+thr = [float(v) for v in np.linspace(0.5, 4.0, 256)]
+q = Q.WeightsSymmetricInferableQuantizer(8, thr, True, 1)
+case("per-channel axis1, channels_last NHWC", q, x, lambda t, q=q: torch.fake_quantize_per_channel_affine(t, q.scales, q.zero_points, 1, -128, 127), steps=60)
+x = torch.randn(64, 256, 56, 56, device="cuda")
+case("per-channel axis1, NCHW (inner=3136)", q, x, lambda t, q=q: torch.fake_quantize_per_channel_affine(t, q.scales, q.zero_points, 1, -128, 127), steps=60)
+x = torch.randn(2048, 1024, 3, 3, device="cuda")
+q = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * i for i in range(2048)], True, 0)
+case("conv weight (2048,1024,3,3) axis0 (inner=9216)", q, x, lambda t, q=q: torch.fake_quantize_per_channel_affine(t, q.scales, q.zero_points, 0, -128, 127), steps=100)
+x = torch.randn(4096, 576, device="cuda")
+q = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * i for i in range(4096)], True, 0)
+case("weight (4096,576) axis0 (inner=576, window)", q, x, lambda t, q=q: torch.fake_quantize_per_channel_affine(t, q.scales, q.zero_points, 0, -128, 127), steps=300)
+xb = torch.randn(4096, 4096, device="cuda").bfloat16()
+q = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * i for i in range(4096)], True, 0)
+case("bf16 weight (4096,4096) axis0", q, xb, lambda t, q=q: torch.fake_quantize_per_channel_affine(t, q.scales, q.zero_points, 0, -128, 127), steps=300, bytes_per_elem=4)
+json.dump([dict(name=r[0], shape=r[1], ours_us=r[2], aten_us=r[3], speedup=r[4], gbs=r[5], equal=r[6]) for r in rows], open("gpurun_out/compare_aten_gpu.json", "w"), indent=1)
