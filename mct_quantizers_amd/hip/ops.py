@@ -149,19 +149,26 @@ def _check_axis(x, n_params: int, axis: int):
 
 
 def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
-    dt = _dtype_code(x, "fq_per_channel")
-    _check_axis(x, scales.numel(), axis)
+    dt = _DTYPES.get(x.dtype)
+    if dt is None:
+        _dtype_code(x, "fq_per_channel")
+    if not 0 <= axis < x.dim() or scales.numel() != x.shape[axis]:
+        _check_axis(x, scales.numel(), axis)
     if scales.dtype != torch.float32 or zero_points.dtype != torch.int32:
         raise RuntimeError("scales must be float32 and zero_points int32")
     lib = native.load()
-    x = _dense_input(x)
+    if not x.is_contiguous():
+        x = _dense_input(x)
     y = torch.empty_like(x)
     outer, c, inner = _channel_view(x, axis)
-    scales = scales.contiguous()
-    zero_points = zero_points.contiguous()
-    with _maybe_on_device(x):
+    if not scales.is_contiguous():
+        scales = scales.contiguous()
+    if not zero_points.is_contiguous():
+        zero_points = zero_points.contiguous()
+    idx = x.get_device()
+    with (_NOOP if idx == _current_device() else _on_device(idx)):
         rc = lib.mctq_fq_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
-                                     zero_points.data_ptr(), qmin, qmax, _stream(x))
+                                     zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
     if rc:
         native.check(rc, "mctq_fq_per_channel")
     return y

@@ -136,11 +136,22 @@ class _WeightsAffineMixin:
         if "_scale0" not in self.__dict__ or "_zp0" not in self.__dict__:
             self._scale0 = float(self.scales.reshape(-1)[0].item())
             self._zp0 = int(self.zero_points.reshape(-1)[0].item())
+        self._flat_params()
+
+    def _flat_params(self):
+        # flattened, contiguous views made once (the reference flattens on every call); refreshed if the
+        # public attributes are replaced
+        self._flat_src = (self.scales, self.zero_points)
+        self._scales_flat = self.scales.flatten().contiguous()
+        self._zps_flat = self.zero_points.flatten().contiguous()
 
     def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
         inputs.requires_grad = False            # the reference flips this on the caller's tensor
         if self.per_channel:
-            return ops.fq_per_channel(inputs, self.scales.flatten(), self.zero_points.flatten(), self.channel_axis,
+            src = self.__dict__.get("_flat_src")
+            if src is None or src[0] is not self.scales or src[1] is not self.zero_points:
+                self._flat_params()
+            return ops.fq_per_channel(inputs, self._scales_flat, self._zps_flat, self.channel_axis,
                                       self.min_quantized_domain, self.max_quantized_domain)
         return ops.fq_per_tensor(inputs, self._scale0, self._zp0,
                                  self.min_quantized_domain, self.max_quantized_domain)
