@@ -50,6 +50,10 @@ extern "C" {
 #define MCTQ_DT_F16 1
 #define MCTQ_DT_BF16 2
 
+/* storage types of the integer-code outputs */
+#define MCTQ_CODE_I8 0
+#define MCTQ_CODE_U8 1
+
 /* ABI version of the loaded library (== MCTQ_ABI_VERSION it was built with). */
 int mctq_abi_version(void);
 
@@ -81,6 +85,23 @@ int mctq_fq_per_channel(const void* x, void* y,
                         const float* scales, const int32_t* zero_points,
                         int32_t quant_min, int32_t quant_max,
                         void* stream);
+
+/*
+ * Integer-code output of the affine quantizers: codes[i] = clamp(rint(x[i] * (1/scale)) + zero_point, quant_min,
+ * quant_max), stored as int8 (MCTQ_CODE_I8, domain within [-128, 127]) or uint8 (MCTQ_CODE_U8, within [0, 255]).
+ * (codes - zero_point) * scale equals the fake-quantized value of mctq_fq_* bit for bit.  This is the
+ * "integer domain" the reference never materialises; consumers that dequantize inside their GEMM
+ * read 1 B per element instead of 4.
+ */
+int mctq_fq_codes_per_tensor(const void* x, void* codes, int64_t n, int32_t dtype, int32_t code_dtype,
+                             float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,
+                             void* stream);
+
+int mctq_fq_codes_per_channel(const void* x, void* codes,
+                              int64_t outer, int64_t channels, int64_t inner, int32_t dtype, int32_t code_dtype,
+                              const float* scales, const int32_t* zero_points,
+                              int32_t quant_min, int32_t quant_max,
+                              void* stream);
 
 /*
  * LUT (codebook) quantizer with one threshold for the whole tensor.

@@ -1,0 +1,45 @@
+// mctq_codes.hip -- part of libmctq_hip.so (C ABI: include/mctq_hip.h); kernels: mctq_kernels.hpp
+// Integer-code outputs of the affine quantizers.
+#include "mctq_kernels.hpp"
+
+using namespace mctq;
+
+static int check_code_range(int32_t code_dtype, int32_t qmin, int32_t qmax) {
+  if (qmin > qmax) return fail_arg("quant_min > quant_max");
+  if (code_dtype == MCTQ_CODE_I8 && (qmin < -128 || qmax > 127)) return fail_arg("clamp domain does not fit int8");
+  if (code_dtype == MCTQ_CODE_U8 && (qmin < 0 || qmax > 255)) return fail_arg("clamp domain does not fit uint8");
+  return 0;
+}
+
+extern "C" {
+
+int mctq_fq_codes_per_tensor(const void* x, void* codes, int64_t n, int32_t dtype, int32_t code_dtype, float scale,
+                             int32_t zero_point, int32_t quant_min, int32_t quant_max, void* stream) {
+  if (n < 0) return fail_arg("n < 0");
+  if (n > 0 && (!x || !codes)) return fail_arg("x or codes is NULL");
+  if (int rc = check_code_range(code_dtype, quant_min, quant_max)) return rc;
+  AffineCodesOp op;
+  op.scales = nullptr; op.zps = nullptr;
+  op.lo = (float)quant_min; op.hi = (float)quant_max;
+  const AffineOp::Param p = AffineOp::make(scale, zero_point);
+  return with_codes_types(dtype, code_dtype, [&](auto ti, auto to) {
+    return launch_flat<decltype(ti), decltype(to)>(op, p, x, codes, n, 0, (hipStream_t)stream);
+  });
+}
+
+int mctq_fq_codes_per_channel(const void* x, void* codes, int64_t outer, int64_t channels, int64_t inner,
+                              int32_t dtype, int32_t code_dtype, const float* scales, const int32_t* zero_points,
+                              int32_t quant_min, int32_t quant_max, void* stream) {
+  if (outer < 0 || channels < 0 || inner < 0) return fail_arg("negative extent");
+  const int64_t n = outer * channels * inner;
+  if (n > 0 && (!x || !codes || !scales || !zero_points)) return fail_arg("NULL pointer");
+  if (int rc = check_code_range(code_dtype, quant_min, quant_max)) return rc;
+  AffineCodesOp op;
+  op.scales = scales; op.zps = zero_points;
+  op.lo = (float)quant_min; op.hi = (float)quant_max;
+  return with_codes_types(dtype, code_dtype, [&](auto ti, auto to) {
+    return launch_channels<decltype(ti), decltype(to)>(op, x, codes, outer, channels, inner, 0, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

@@ -51,7 +51,16 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
 
+typedef int8_t i8x4 __attribute__((ext_vector_type(4)));
+typedef int8_t i8x8 __attribute__((ext_vector_type(8)));
+typedef uint8_t u8x4 __attribute__((ext_vector_type(4)));
+typedef uint8_t u8x8 __attribute__((ext_vector_type(8)));
+
 template <class T, int N> struct VecT;
+template <> struct VecT<int8_t, 4> { typedef i8x4 type; };
+template <> struct VecT<int8_t, 8> { typedef i8x8 type; };
+template <> struct VecT<uint8_t, 4> { typedef u8x4 type; };
+template <> struct VecT<uint8_t, 8> { typedef u8x8 type; };
 template <> struct VecT<float, 4> { typedef f32x4 type; };
 template <> struct VecT<_Float16, 8> { typedef f16x8 type; };
 template <> struct VecT<_Float16, 4> { typedef f16x4 type; };
@@ -129,6 +138,16 @@ struct AffineOp {
     float q = __builtin_rintf(x * p.inv) + p.zf;      // v_rndne_f32: ties to even
     q = fminf(fmaxf(q, lo), hi);                      // NaN -> lo, +inf -> hi, -inf -> lo
     return (q - p.zf) * p.s;
+  }
+};
+
+// Same clamp index, left as an integer code (stored as int8 / uint8): the integer domain of the affine
+// quantizers for consumers that dequantize themselves (1 B written per element instead of 4).
+struct AffineCodesOp : AffineOp {
+  template <bool FAST = true>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book&) const {
+    const float q = __builtin_rintf(x * p.inv) + p.zf;
+    return fminf(fmaxf(q, lo), hi);                   // integer-valued, inside the 8-bit code range
   }
 };
 
@@ -939,6 +958,26 @@ static int with_affine_types(int dtype, F f) {
     case MCTQ_DT_BF16: return f(__bf16(), __bf16());
     default: return fail_arg("unknown dtype");
   }
+}
+template <class F>
+static int with_codes_types(int dtype, int code_dtype, F f) {
+  if (code_dtype == MCTQ_CODE_I8) {
+    switch (dtype) {
+      case MCTQ_DT_F32: return f(float(), int8_t());
+      case MCTQ_DT_F16: return f(_Float16(), int8_t());
+      case MCTQ_DT_BF16: return f(__bf16(), int8_t());
+      default: return fail_arg("unknown dtype");
+    }
+  }
+  if (code_dtype == MCTQ_CODE_U8) {
+    switch (dtype) {
+      case MCTQ_DT_F32: return f(float(), uint8_t());
+      case MCTQ_DT_F16: return f(_Float16(), uint8_t());
+      case MCTQ_DT_BF16: return f(__bf16(), uint8_t());
+      default: return fail_arg("unknown dtype");
+    }
+  }
+  return fail_arg("unknown code dtype");
 }
 template <class F>
 static int with_lut_types(int dtype, F f) {

@@ -16,6 +16,7 @@ import threading
 
 ABI_VERSION = 2
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+CODE_I8, CODE_U8 = 0, 1
 LIB_NAME = "libmctq_hip.so"
 LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
 MCTQ_E_ARG = -10001
@@ -47,6 +48,12 @@ SIGNATURES = {
     "mctq_fq_per_channel": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_int32, _c_f32p, _c_i32p, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_void_p]),
+    "mctq_fq_codes_per_tensor": (ctypes.c_int, [_c_f32p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_void_p]),
+    "mctq_fq_codes_per_channel": (ctypes.c_int, [_c_f32p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _c_f32p, _c_i32p,
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mctq_lut_per_tensor": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_float, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),

@@ -223,6 +223,51 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
     return y
 
 
+def _code_dtype(qmin: int, qmax: int):
+    if qmin >= 0 and qmax <= 255:
+        return torch.uint8, native.CODE_U8
+    if qmin >= -128 and qmax <= 127:
+        return torch.int8, native.CODE_I8
+    raise ValueError(f"clamp domain [{qmin}, {qmax}] does not fit an 8-bit code")
+
+
+def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float = None, zp0: int = None):
+    """Integer clamp indices of the affine quantizers as int8 / uint8 (extension, not in the reference).
+
+    ``axis`` None = per-tensor (scale0 / zp0 are the host copies of the single scale and zero point).
+    ``(codes - zero_point) * scale`` is bit-identical to the fake-quantized tensor.
+    """
+    tdt, code = _code_dtype(qmin, qmax)
+    if not x.is_cuda:
+        # CPU tensors: the same arithmetic with torch ops (float32 math, as ATen's CPU kernel)
+        xf = x.float()
+        if axis is None:
+            q = torch.round(xf * (torch.tensor(1.0, dtype=torch.float32) / torch.tensor(scale0, dtype=torch.float32))) + zp0
+        else:
+            shape = [1] * x.dim()
+            shape[axis] = -1
+            q = torch.round(xf * (1.0 / scales.float()).reshape(shape)) + zero_points.reshape(shape).float()
+        return torch.clamp(torch.nan_to_num(q, nan=float(qmin)), qmin, qmax).to(tdt)
+    dt = _dtype_code(x, "fq_codes")
+    lib = native.load()
+    if not x.is_contiguous():
+        x = _dense_input(x)
+    y = torch.empty_like(x, dtype=tdt)
+    idx = x.get_device()
+    with (_NOOP if idx == _current_device() else _on_device(idx)):
+        if axis is None:
+            rc = lib.mctq_fq_codes_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, code, scale0, zp0, qmin, qmax,
+                                              _raw_stream(idx))
+        else:
+            _check_axis(x, scales.numel(), axis)
+            outer, c, inner = _channel_view(x, axis)
+            rc = lib.mctq_fq_codes_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, code,
+                                               scales.data_ptr(), zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
+    if rc:
+        native.check(rc, "mctq_fq_codes")
+    return y
+
+
 def make_lut_table(lut_values, mult: float, cmin: float, cmax: float, device):
     """Device copy of the codebook's decision table (see include/mctq_hip.h), or None.
 

@@ -145,6 +145,18 @@ class _WeightsAffineMixin:
         self._scales_flat = self.scales.flatten().contiguous()
         self._zps_flat = self.zero_points.flatten().contiguous()
 
+    def quantize_to_codes(self, inputs: torch.Tensor):
+        """Extension (not in the reference): the integer clamp indices as int8/uint8 plus the parameters that
+        dequantize them, ``(codes - zero_points) * scales`` == ``self(inputs)`` bit for bit.
+        Returns (codes, scales float32 [C or 1], zero_points int32 [C or 1])."""
+        src = self.__dict__.get("_flat_src")
+        if src is None or src[0] is not self.scales or src[1] is not self.zero_points:
+            self._flat_params()
+        axis = self.channel_axis if self.per_channel else None
+        codes = ops.fq_codes(inputs, self._scales_flat, self._zps_flat, axis, self.min_quantized_domain,
+                             self.max_quantized_domain, self._scale0, self._zp0)
+        return codes, self._scales_flat, self._zps_flat
+
     def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
         inputs.requires_grad = False            # the reference flips this on the caller's tensor
         if self.per_channel:
@@ -259,6 +271,13 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
         self.scales = float(self.scales[0])      # stays a Python double; narrowed to float32 at launch
         self.zero_points = 0
 
+    def quantize_to_codes(self, inputs: torch.Tensor):
+        """Extension: (codes int8/uint8, scale float, zero_point int) with (codes - zero_point) * float32(scale)
+        == self(inputs)."""
+        codes = ops.fq_codes(inputs, None, None, None, self.min_quantized_domain, self.max_quantized_domain,
+                             self.scales, self.zero_points)
+        return codes, self.scales, self.zero_points
+
     def __call__(self, inputs: torch.Tensor):
         if type(inputs) is torch.Tensor and inputs.is_cuda:
             # the HIP launch records nothing for autograd: no need for the no_grad context on this path
@@ -296,6 +315,13 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
         self.max_range = self._max_range_host[0].item()
         self.scale = float((self.max_range - self.min_range) / ((2 ** num_bits) - 1))
         self.zero_point = int(-np.round(self.min_range / self.scale))   # round half even, in double
+
+    def quantize_to_codes(self, inputs: torch.Tensor):
+        """Extension: (codes uint8, scale float, zero_point int) with (codes - zero_point) * float32(scale)
+        == self(inputs)."""
+        codes = ops.fq_codes(inputs, None, None, None, self.min_quantized_domain, self.max_quantized_domain,
+                             self.scale, self.zero_point)
+        return codes, self.scale, self.zero_point
 
     def __call__(self, inputs: torch.Tensor):
         if type(inputs) is torch.Tensor and inputs.is_cuda:

@@ -342,6 +342,50 @@ def test_fast_division_is_exact(lib):
     assert not bad.any(), {float(div[i]): int(bad[i]) for i in np.flatnonzero(bad)}
 
 
+@pytest.mark.parametrize("dt", ["float32", "float16", "bfloat16"])
+@pytest.mark.parametrize("outer,C,inner", [(7, 3, 1), (33, 5, 2), (2, 8, 100), (2, 6, 1024), (1, 64, 4096), (1, 5000, 7)])
+def test_integer_codes_equal_the_oracle_index(lib, dt, outer, C, inner):
+    """int8 / uint8 code outputs == the oracle's clamp index, for per-channel and per-tensor, all storage types."""
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(C + inner)
+    tdt = getattr(torch, dt)
+    code_in = {"float32": 0, "float16": 1, "bfloat16": 2}[dt]
+    for qmin, qmax, tcode, code_dt in ((-128, 127, torch.int8, 0), (0, 255, torch.uint8, 1), (-8, 7, torch.int8, 0)):
+        scales = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+        zps = rng.integers(qmin, qmax + 1, size=C).astype(np.int32)
+        shape = (outer, C, inner)
+        x32 = _tie_heavy(rng, shape, scales.reshape(1, C, 1), zps.reshape(1, C, 1).astype(np.float32), qmin, qmax)
+        x = _dev(x32).to(tdt)
+        x_np = x.float().cpu().numpy()
+        codes = torch.empty(shape, dtype=tcode, device="cuda")
+        s_d, z_d = _dev(scales), _dev(zps)
+        rc = lib.mctq_fq_codes_per_channel(x.data_ptr(), codes.data_ptr(), outer, C, inner, code_in, code_dt,
+                                           s_d.data_ptr(), z_d.data_ptr(), qmin, qmax, _stream())
+        assert rc == 0, lib.mctq_last_error()
+        _, q_want = O.fake_quant_affine(x_np, scales, zps, qmin, qmax, axis=1, return_index=True)
+        finite = np.isfinite(x_np)
+        assert np.array_equal(codes.cpu().numpy().astype(np.int64)[finite], q_want[finite])
+        rc = lib.mctq_fq_codes_per_tensor(x.data_ptr(), codes.data_ptr(), x.numel(), code_in, code_dt, float(scales[0]),
+                                          int(zps[0]), qmin, qmax, _stream())
+        assert rc == 0, lib.mctq_last_error()
+        _, q_want = O.fake_quant_affine(x_np, scales[0], zps[0], qmin, qmax, return_index=True)
+        assert np.array_equal(codes.cpu().numpy().astype(np.int64)[finite], q_want[finite])
+    assert lib.mctq_fq_codes_per_tensor(x.data_ptr(), codes.data_ptr(), 4, 0, 0, 1.0, 0, -200, 127, None) == -10001
+
+
+def test_quantize_to_codes_dequantizes_bit_exactly(lib):
+    import mct_quantizers_amd as mq
+    x = torch.randn(4096, 512, device="cuda") * 2
+    q = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [0.5 + 0.001 * i for i in range(4096)], True, 0)
+    codes, s, z = q.quantize_to_codes(x)
+    assert codes.dtype == torch.int8 and codes.shape == x.shape
+    assert torch.equal((codes.float() - z.float().reshape(-1, 1)) * s.reshape(-1, 1), q(x))
+    qa = mq.pytorch_quantizers.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    codes, s, z = qa.quantize_to_codes(x)
+    assert codes.dtype == torch.uint8
+    assert torch.equal((codes.float() - z) * torch.tensor(s, dtype=torch.float32, device="cuda"), qa(x))
+
+
 def test_abi_argument_errors(lib):
     x = torch.zeros(16, device="cuda")
     y = torch.zeros(16, device="cuda")

@@ -243,3 +243,20 @@ def test_utils_surface():
     lut = torch.tensor([-25.0, 25.0])
     y = U.lut_quantizer(torch.tensor([[-1.0, 0.3]]), lut, True, torch.tensor([2.0]), 8, 1e-8)
     assert torch.allclose(y, torch.tensor([[-25.0 / 128 * 2, 25.0 / 128 * 2]]))
+
+
+def test_integer_codes_dequantize_to_the_fake_quant_output_cpu():
+    """Extension API: (codes - zero_point) * scale reproduces the fake-quantized tensor exactly."""
+    x = torch.randn(6, 40) * 2
+    for q in (Q.WeightsSymmetricInferableQuantizer(8, [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], True, 0),
+              Q.WeightsUniformInferableQuantizer(8, [-1.0] * 6, [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], True, 0),
+              Q.WeightsPOTInferableQuantizer(4, [2.0], False)):
+        codes, s, z = q.quantize_to_codes(x)
+        assert codes.dtype in (torch.int8, torch.uint8)
+        shape = [-1, 1] if q.per_channel else [1, 1]
+        deq = (codes.float() - z.float().reshape(shape)) * s.reshape(shape)
+        assert torch.equal(deq, q(x.clone()))
+    qa = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    codes, s, z = qa.quantize_to_codes(x)
+    assert codes.dtype == torch.uint8
+    assert torch.equal((codes.float() - z) * torch.tensor(s, dtype=torch.float32), qa(x))
