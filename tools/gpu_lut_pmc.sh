@@ -7,7 +7,7 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'rows_loop' in r['Kernel_Name']:
+    if 'rows_persist' in r['Kernel_Name']:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items(): print(k, sum(v)/len(v), len(v))
 PY
