@@ -1,0 +1,137 @@
+"""Behavioural checks in the style of the reference's own unit tests
+(tests/pytorch_tests/quantizers_tests/*.py): unseeded random (1, 50, 50, 3) inputs in [-50, 50), value range,
+number of distinct levels, sign, and equality with the hand-written formula; once on CPU tensors and once on
+the GPU (through the HIP kernels)."""
+import numpy as np
+import pytest
+import torch
+
+import mct_quantizers_amd as mq
+
+Q = mq.pytorch_quantizers
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+def _input(device):
+    return (torch.rand(1, 50, 50, 3) * 100 - 50).to(device)
+
+
+def _chan(values, device):
+    return torch.tensor(values, dtype=torch.float32, device=device).reshape(1, 1, 1, -1)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("cls,thr,bits", [(Q.WeightsSymmetricInferableQuantizer, [4.0], 3),
+                                          (Q.WeightsPOTInferableQuantizer, [2.0], 3)])
+def test_weights_symmetric_per_tensor(device, cls, thr, bits):
+    q = cls(num_bits=bits, per_channel=False, threshold=thr)
+    x = _input(device)
+    y = q(x)
+    assert y.max() < thr[0] and y.min() >= -thr[0]
+    assert y.unique().numel() <= 2 ** bits and torch.any(y < 0)
+    scale = thr[0] / 2 ** (bits - 1)
+    assert torch.equal(y, torch.round(torch.clip(x, -thr[0], thr[0] - scale) / scale) * scale)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("cls,thr,bits", [(Q.WeightsSymmetricInferableQuantizer, [3.0, 6.0, 2.0], 2),
+                                          (Q.WeightsPOTInferableQuantizer, [2.0, 4.0, 1.0], 3)])
+def test_weights_symmetric_per_channel_last_axis(device, cls, thr, bits):
+    q = cls(num_bits=bits, per_channel=True, threshold=thr, channel_axis=3)
+    if cls is Q.WeightsPOTInferableQuantizer:
+        assert torch.all(q.scales.log2().int() == q.scales.log2())
+    x = _input(device)
+    y = q(x)
+    for i, t in enumerate(thr):
+        c = y[..., i]
+        assert c.max() < t and c.min() >= -t and c.unique().numel() <= 2 ** bits and torch.any(c < 0)
+    t = _chan(thr, device)
+    s = t / 2 ** (bits - 1)
+    assert torch.equal(y, torch.round(torch.clip(x, -t, t - s) / s) * s)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_weights_uniform(device, per_channel):
+    bits = 3
+    lo, hi = ([-10.0, -5.0, -8.0], [4.0, 9.0, 6.0]) if per_channel else ([-10.0], [4.0])
+    q = Q.WeightsUniformInferableQuantizer(num_bits=bits, per_channel=per_channel, min_range=lo, max_range=hi,
+                                           channel_axis=3 if per_channel else None)
+    x = _input(device)
+    y = q(x)
+    a = torch.from_numpy(q.adjusted_min_range_np).to(device)
+    b = torch.from_numpy(q.adjusted_max_range_np).to(device)
+    if per_channel:
+        a, b = a.reshape(1, 1, 1, -1), b.reshape(1, 1, 1, -1)
+    assert torch.all(y <= b + 1e-6) and torch.all(y >= a - 1e-6)
+    for i in range(3 if per_channel else 1):
+        c = y[..., i] if per_channel else y
+        assert c.unique().numel() <= 2 ** bits and torch.any(c < 0) and torch.any(c > 0)
+    # zero is on the grid: quantizing zeros gives exact zeros
+    assert torch.count_nonzero(q(torch.zeros_like(x))) == 0
+    delta = (b - a) / (2 ** bits - 1)
+    manual = torch.round((torch.clip(x, a, b) - a) / delta) * delta + a
+    assert torch.allclose(y, manual, atol=1e-5)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("signed", [True, False])
+def test_activation_symmetric_and_pot(device, signed):
+    bits, thr = 3, [4.0]
+    for cls in (Q.ActivationSymmetricInferableQuantizer, Q.ActivationPOTInferableQuantizer):
+        q = cls(num_bits=bits, threshold=thr, signed=signed)
+        x = _input(device)
+        y = q(x)
+        assert y.max() < thr[0] and y.min() >= (-thr[0] if signed else 0)
+        assert y.unique().numel() <= 2 ** bits and bool(torch.any(y < 0)) == signed
+        scale = thr[0] / (2 ** (bits - int(signed)))
+        lo = -thr[0] if signed else 0.0
+        assert torch.equal(y, torch.round(torch.clip(x, lo, thr[0] - scale) / scale) * scale)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_activation_uniform_and_range_fix(device):
+    q = Q.ActivationUniformInferableQuantizer(num_bits=3, min_range=[-10.0], max_range=[4.0])
+    x = _input(device)
+    y = q(x)
+    assert y.max() <= q.max_range and y.min() >= q.min_range and y.unique().numel() <= 8
+    assert torch.count_nonzero(q(torch.zeros_like(x))) == 0
+    q2 = Q.ActivationUniformInferableQuantizer(num_bits=3, min_range=[3.0], max_range=[10.0])   # moved to [0, 10]
+    assert q2.min_range == 0.0 and q2.max_range == 10.0
+    y2 = q2(x)
+    assert y2.min() >= 0 and y2.max() <= 10 and y2.unique().numel() <= 8
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("axis", [3, 1])
+def test_weights_lut_matches_the_literal_op_chain(device, axis):
+    lut = [-25.0, 25.0, 3.0, -8.0]
+    thr = [3.0, 8.0, 7.0] if axis == 3 else [float(v) for v in np.linspace(1.0, 9.0, 50)]
+    for cls, t in ((Q.WeightsLUTSymmetricInferableQuantizer, thr),
+                   (Q.WeightsLUTPOTInferableQuantizer, [float(2.0 ** (i % 4)) for i in range(len(thr))])):
+        q = cls(num_bits=2, lut_values=lut, threshold=t, per_channel=True, channel_axis=axis, input_rank=4)
+        x = _input(device)
+        y = q(x)
+        shape = [1, 1, 1, 1]
+        shape[axis] = -1
+        tt = torch.tensor(t, dtype=torch.float32, device=device).reshape(shape)
+        lt = torch.tensor(lut, dtype=torch.float32, device=device)
+        v = torch.clip((x / (tt + 1e-8)) * 128, min=-128, max=127).unsqueeze(-1)
+        idx = torch.argmin(torch.abs(v - lt.reshape(1, 1, 1, 1, -1)), dim=-1)
+        assert torch.equal(y, (lt[idx] / 128) * tt)
+        assert y.unique().numel() <= len(lut) * len(t)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("signed", [True, False])
+def test_activation_lut_pot(device, signed):
+    lut = [-25.0, 25.0, 3.0, -8.0] if signed else [0.0, 25.0, 90.0, 200.0]
+    q = Q.ActivationLutPOTInferableQuantizer(num_bits=2, lut_values=lut, threshold=[4.0], signed=signed)
+    x = _input(device)
+    y = q(x)
+    m = 128.0 if signed else 256.0
+    allowed = torch.tensor(lut, device=device) / m * 4.0
+    assert torch.all(torch.isin(y, allowed)) and bool(torch.any(y < 0)) == signed
+    v = torch.clip((x / (4.0 + 1e-8)) * m, min=-128 if signed else 0, max=127 if signed else 255).unsqueeze(-1)
+    idx = torch.argmin(torch.abs(v - torch.tensor(lut, device=device).reshape(1, 1, 1, 1, -1)), dim=-1)
+    assert torch.equal(y, (torch.tensor(lut, device=device)[idx] / m) * 4.0)
