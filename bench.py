@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--nt", type=int, default=None)
     ap.add_argument("--unroll", type=int, default=None)
     ap.add_argument("--heavy-unroll", type=int, default=None)
+    ap.add_argument("--heavy-persistent", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--gather", action="store_true", help="also time the all-gather of dim-0 shards (N > 1)")
@@ -80,6 +81,8 @@ def main():
         native.set_tuning("unroll", args.unroll)
     if args.heavy_unroll is not None:
         native.set_tuning("heavy_unroll", args.heavy_unroll)
+    if args.heavy_persistent is not None:
+        native.set_tuning("heavy_persistent", args.heavy_persistent)
 
     # ---- workload -------------------------------------------------------------------------
     x_np = workloads.make_input(args.config, batch=args.batch)

@@ -113,7 +113,11 @@ struct AffineOp {
   struct Param { float s, inv, zf; };
   typedef NoBook Book;
   static constexpr int kWords = 3;
+#ifdef MCTQ_AFFINE_HEAVY
+  static constexpr bool kHeavy = true;        // timing experiment: affine through the persistent path
+#else
   static constexpr bool kHeavy = false;       // a few VALU ops per element: pure streaming
+#endif
 
   __host__ __device__ __forceinline__ static Param make(float s, int32_t zp) {
     Param p;
@@ -197,6 +201,9 @@ struct LutCommon {
       return x / p.d;
     } else {
       const float q0 = x * p.r;
+#ifdef MCTQ_ABLATE_DIV
+      return q0;
+#endif
       const float e0 = __builtin_fmaf(-q0, p.d, x);
       const float q1 = __builtin_fmaf(e0, p.r, q0);
       const float e1 = __builtin_fmaf(-q1, p.d, x);
@@ -345,7 +352,11 @@ struct LutTableOp : LutCommon {
 #pragma unroll
     for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], t[i], k[i]);
 #pragma unroll
+#ifdef MCTQ_ABLATE_LDS
+    for (int i = 0; i < NE; ++i) { e[i].x = (float)k[i]; e[i].y = __uint_as_float(0x3c003800u); }
+#else
     for (int i = 0; i < NE; ++i) e[i] = b.tab[k[i]];
+#endif
 #pragma unroll
     for (int i = 0; i < NE; ++i) out[i] = decide(v[i], t[i], e[i], p, b);
   }
@@ -356,12 +367,15 @@ struct HasTile : std::false_type {};
 template <class Op>
 struct HasTile<Op, std::void_t<decltype(&Op::template tile<true, 4>)>> : std::true_type {};
 
-// NE elements with one Param (all in the same channel).
+// NE elements with one Param (all in the same channel).  Batched ops work on at most 16 elements at a
+// time (their index / table-entry arrays live in registers).
 template <bool FAST, int NE, class Op>
 __device__ __forceinline__ void run(const Op& op, const float* in, float* out, const typename Op::Param& p,
                                     const typename Op::Book& b) {
   if constexpr (HasTile<Op>::value) {
-    op.template tile<FAST, NE>(in, out, p, b);
+    constexpr int CH = NE > 16 ? 16 : NE;
+#pragma unroll
+    for (int c = 0; c < NE; c += CH) op.template tile<FAST, CH>(in + c, out + c, p, b);
   } else {
 #pragma unroll
     for (int i = 0; i < NE; ++i) out[i] = op.template apply<FAST>(in[i], p, b);
@@ -382,6 +396,43 @@ __device__ __forceinline__ void run_vectors(const Op& op, const typename IO<TI, 
   for (int u = 0; u < U; ++u) r[u] = io::pack(out + u * io::N);
 }
 
+// Tile helpers shared by every launch shape: full tiles (wave-uniform test) run straight-line code.
+template <class TI, class TO, int U, bool NT>
+__device__ __forceinline__ void load_tile(typename IO<TI, TO>::VI (&v)[U], const TI* __restrict__ x, int64_t first,
+                                          int64_t limit, bool full /* wave-uniform */) {
+  typedef IO<TI, TO> io;
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(x + (first + u * kThreads) * io::N);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (first + u * kThreads < limit) v[u] = io::template load<NT>(x + (first + u * kThreads) * io::N);
+  }
+}
+
+template <bool FAST, class Op, class TI, class TO, int U, bool NT>
+__device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Param& p, const typename Op::Book& book,
+                                            const typename IO<TI, TO>::VI (&w)[U], TO* __restrict__ y, int64_t first,
+                                            int64_t limit, bool full) {
+  typedef IO<TI, TO> io;
+  if (full) {
+    typename io::VO r[U];
+    run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
+#pragma unroll
+    for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (first + u * kThreads < limit) {
+        typename io::VI one[1] = {w[u]};
+        typename io::VO res[1];
+        run_vectors<FAST, Op, TI, TO, 1>(op, one, res, p, book);
+        io::template store<NT>(y + (first + u * kThreads) * io::N, res[0]);
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // flat: per-tensor parameters.  Block b owns lane-vectors [b*256*U, (b+1)*256*U); lane accesses
 // are 16 B (8 B for a 16-bit input widened to float32), consecutive lanes consecutive addresses,
@@ -392,29 +443,14 @@ __global__ __launch_bounds__(kThreads) void flat_kernel(Op op, typename Op::Para
                                                         const TI* __restrict__ xs, TO* __restrict__ ys, int64_t n) {
   typedef IO<TI, TO> io;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const typename Op::Book book = op.setup(smem);
   const int64_t nv = n / io::N;
   const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
   typename io::VI v[U];
-  if (((int64_t)blockIdx.x + 1) * (kThreads * U) <= nv) {   // full tile (wave-uniform test): no per-lane guards
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(xs + (base + u * kThreads) * io::N);
-    typename io::VO r[U];
-    run_vectors<false, Op, TI, TO, U>(op, v, r, p, book);
-#pragma unroll
-    for (int u = 0; u < U; ++u) io::template store<NT>(ys + (base + u * kThreads) * io::N, r[u]);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = base + u * kThreads;
-      if (i < nv) {
-        typename io::VI one[1] = {io::template load<NT>(xs + i * io::N)};
-        typename io::VO res[1];
-        run_vectors<false, Op, TI, TO, 1>(op, one, res, p, book);
-        io::template store<NT>(ys + i * io::N, res[0]);
-      }
-    }
-  }
+  const bool full = ((int64_t)blockIdx.x + 1) * (kThreads * U) <= nv;   // wave-uniform: no per-lane guards
+  load_tile<TI, TO, U, NT>(v, xs, base, nv, full);
+  const typename Op::Book book = op.setup(smem);            // after the loads are in flight
+  if (Op::can_fast(p)) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, v, ys, base, nv, full);
+  else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, v, ys, base, nv, full);
   if (blockIdx.x == 0) {                                   // n % N trailing elements
     const int64_t i = nv * io::N + threadIdx.x;
     if (i < n) ys[i] = (TO)op.template apply<false>((float)xs[i], p, book);
@@ -466,21 +502,10 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restr
   uint32_t c = row;
   if (c >= channels) c = row % channels;                   // uniform; outer == 1 needs no modulo
   const typename Op::Param p = op.fetch(c);
-  if (full) {
-    typename io::VO r[U];
-    run_vectors<false, Op, TI, TO, U>(op, v, r, p, book);
-#pragma unroll
-    for (int u = 0; u < U; ++u) io::template store<NT>(ys + (rbase + col + u * kThreads) * io::N, r[u]);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (col + u * kThreads < innerv) {
-        typename io::VI one[1] = {v[u]};
-        typename io::VO res[1];
-        run_vectors<false, Op, TI, TO, 1>(op, one, res, p, book);
-        io::template store<NT>(ys + (rbase + col + u * kThreads) * io::N, res[0]);
-      }
-  }
+  const bool fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;   // wave-uniform
+  const int64_t first = rbase + col;
+  if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, v, ys, first, rbase + innerv, full);
+  else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, v, ys, first, rbase + innerv, full);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -490,42 +515,6 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restr
 // tile's loads before it computes the current one, and pays the table / codebook staging once.
 // Full tiles run straight-line code so the LDS table reads of a tile are issued back to back.
 // ------------------------------------------------------------------------------------------
-template <class TI, class TO, int U, bool NT>
-__device__ __forceinline__ void load_tile(typename IO<TI, TO>::VI (&v)[U], const TI* __restrict__ x, int64_t first,
-                                          int64_t limit, bool full /* wave-uniform */) {
-  typedef IO<TI, TO> io;
-  if (full) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(x + (first + u * kThreads) * io::N);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (first + u * kThreads < limit) v[u] = io::template load<NT>(x + (first + u * kThreads) * io::N);
-  }
-}
-
-template <bool FAST, class Op, class TI, class TO, int U, bool NT>
-__device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Param& p, const typename Op::Book& book,
-                                            const typename IO<TI, TO>::VI (&w)[U], TO* __restrict__ y, int64_t first,
-                                            int64_t limit, bool full) {
-  typedef IO<TI, TO> io;
-  if (full) {
-    typename io::VO r[U];
-    run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
-#pragma unroll
-    for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (first + u * kThreads < limit) {
-        typename io::VI one[1] = {w[u]};
-        typename io::VO res[1];
-        run_vectors<FAST, Op, TI, TO, 1>(op, one, res, p, book);
-        io::template store<NT>(y + (first + u * kThreads) * io::N, res[0]);
-      }
-  }
-}
-
 template <class Op, class TI, class TO, int U, bool NT>
 __global__ __launch_bounds__(kThreads) void rows_persist_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
                                                                 uint32_t tiles_per_row, uint32_t total_tiles,
@@ -533,36 +522,35 @@ __global__ __launch_bounds__(kThreads) void rows_persist_kernel(Op op, const TI*
   typedef IO<TI, TO> io;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr uint32_t TILE = kThreads * U;
+  const uint32_t G = gridDim.x;
   uint32_t item = blockIdx.x;                                // grid <= total_tiles
-  typename io::VI v[U];
-  {
-    const uint32_t row = item / tiles_per_row, tile = item - row * tiles_per_row;
+  // two tiles of loads in flight per lane: vA = the tile after the current one, vB = the one after that
+  typename io::VI vA[U], vB[U];
+  auto issue = [&](typename io::VI (&v)[U], uint32_t it) {
+    const uint32_t row = it / tiles_per_row, tile = it - row * tiles_per_row;
     const int64_t rbase = (int64_t)row * innerv;
     load_tile<TI, TO, U, NT>(v, xs, rbase + tile * TILE + threadIdx.x, rbase + innerv, (tile + 1) * TILE <= innerv);
-  }
+  };
+  issue(vA, item);
+  if (item + G < total_tiles) issue(vB, item + G);
   const typename Op::Book book = op.setup(smem);
-  uint32_t cur_row = 0xffffffffu;
-  typename Op::Param p;
-  bool fast = false;
-  for (; item < total_tiles; item += gridDim.x) {
+  // The parameters of a tile are fetched one iteration ahead (scalar loads + one IEEE reciprocal), so
+  // their latency sits under the previous tile's compute instead of in front of the next loads.
+  auto params_of = [&](uint32_t it) {
+    const uint32_t row = it / tiles_per_row;
+    return op.fetch(row >= channels ? row % channels : row);
+  };
+  typename Op::Param p_next = params_of(item);
+  for (; item < total_tiles; item += G) {
     const uint32_t row = item / tiles_per_row;
     const uint32_t tile = item - row * tiles_per_row;
-    if (row != cur_row) {                                    // wave-uniform
-      uint32_t c = row;
-      if (c >= channels) c = row % channels;
-      p = op.fetch(c);
-      fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;
-      cur_row = row;
-    }
+    const typename Op::Param p = p_next;
+    const bool fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;
     typename io::VI w[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = v[u];
-    const uint32_t next = item + gridDim.x;
-    if (next < total_tiles) {
-      const uint32_t nrow = next / tiles_per_row, ntile = next - nrow * tiles_per_row;
-      const int64_t nbase = (int64_t)nrow * innerv;
-      load_tile<TI, TO, U, NT>(v, xs, nbase + ntile * TILE + threadIdx.x, nbase + innerv, (ntile + 1) * TILE <= innerv);
-    }
+    for (int u = 0; u < U; ++u) { w[u] = vA[u]; vA[u] = vB[u]; }
+    if (item + 2 * G < total_tiles) issue(vB, item + 2 * G);
+    if (item + G < total_tiles) p_next = params_of(item + G);
     const int64_t rbase = (int64_t)row * innerv;
     const int64_t first = rbase + tile * TILE + threadIdx.x;
     const bool full = (tile + 1) * TILE <= innerv;
@@ -681,6 +669,7 @@ extern thread_local char g_err[256];
 extern int g_nt;             // non-temporal loads/stores: +7% on the cold 4096x4096 stream (profiles/)
 extern int g_unroll;
 extern int g_heavy_unroll;   // 0 = automatic
+extern int g_heavy_persistent;
 int fail_arg(const char* msg);
 int check_launch(const char* what);
 int cu_count();
@@ -722,6 +711,7 @@ static bool vec_aligned(const void* x, const void* y) {
         switch (U_) {                                                                       \
           case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;           \
           case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;           \
+          case 8: { constexpr int U = 8; constexpr bool NT = true; __VA_ARGS__; } break;           \
           default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;          \
         }                                                                                   \
       } else {                                                                              \
@@ -768,6 +758,16 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
   }
   const int64_t nv = n / io::N;
   if constexpr (Op::kHeavy) {
+    if (!g_heavy_persistent) {
+      MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, g_nt, {
+        int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
+        if (blocks == 0) blocks = 1;
+        if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
+        hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                           op, p, x, y, n);
+      });
+      return check_launch("flat launch");
+    }
     MCTQ_DISPATCH_HEAVY(2, g_nt, {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       const int64_t cap = (int64_t)cu_count() * 16;
@@ -816,6 +816,13 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       const int64_t per = (int64_t)kThreads * u_sel;
       const int64_t tiles = (innerv + per - 1) / per;
       const int64_t total = rows * tiles;
+      if (!g_heavy_persistent && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+        MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
+          hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
+                             st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
+        });
+        return check_launch("rows launch");
+      }
       if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
           int64_t grid = (int64_t)cu_count() * persist_blocks_per_cu<Op, TI, TO, U, NT>(book_bytes);

@@ -465,6 +465,52 @@ def test_tuning_variants_do_not_change_results(lib):
         native.set_tuning("unroll", 4)
 
 
+def test_lut_tuning_variants_do_not_change_results(lib):
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(12)
+    C, inner = 9, 11008
+    lut = LUTS["l16"]
+    thr = rng.uniform(0.05, 4.0, size=C).astype(np.float32)
+    x_np = _lut_inputs(rng, (1, C, inner), thr.reshape(1, C, 1))
+    want = O.lut_quantize(x_np, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=1)
+    x, t_d, tab, lut_d = _dev(x_np), _dev(thr), _table(lut), _dev(np.asarray(lut, dtype=np.float32))
+    try:
+        for nt, hu, pers in [(n_, h_, p_) for n_ in (0, 1) for h_ in (1, 2, 4, 0) for p_ in (0, 1)]:
+            if True:
+                native.set_tuning("nt", nt)
+                native.set_tuning("heavy_unroll", hu)
+                native.set_tuning("heavy_persistent", pers)
+                for use_table in (True, False):
+                    y = torch.empty_like(x)
+                    if use_table:
+                        rc = lib.mctq_lutt_per_channel_f32(x.data_ptr(), y.data_ptr(), 1, C, inner, t_d.data_ptr(), 1e-8,
+                                                           tab.data_ptr(), tab.shape[0] - 1, 128.0, -128.0, 127.0,
+                                                           _stream())
+                    else:
+                        rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y.data_ptr(), 1, C, inner, t_d.data_ptr(), 1e-8,
+                                                          lut_d.data_ptr(), len(lut), 128.0, -128.0, 127.0, _stream())
+                    assert rc == 0, lib.mctq_last_error()
+                    assert bits_equal(y.cpu().numpy(), want), (nt, hu, pers, use_table)
+                    # per-tensor launch shapes of the same ops
+                    y = torch.empty_like(x)
+                    if use_table:
+                        rc = lib.mctq_lutt_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(thr[0] + np.float32(1e-8)),
+                                                          float(thr[0]), tab.data_ptr(), tab.shape[0] - 1, 128.0, -128.0,
+                                                          127.0, _stream())
+                    else:
+                        rc = lib.mctq_lut_per_tensor_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(thr[0] + np.float32(1e-8)),
+                                                         float(thr[0]), lut_d.data_ptr(), len(lut), 128.0, -128.0, 127.0,
+                                                         _stream())
+                    assert rc == 0, lib.mctq_last_error()
+                    assert bits_equal(y.cpu().numpy(), O.lut_quantize(x_np, lut, thr[:1], True, 8, 1e-8)), \
+                        (nt, hu, pers, use_table, "per-tensor")
+    finally:
+        native.set_tuning("nt", 1)
+        native.set_tuning("heavy_unroll", 0)
+        native.set_tuning("heavy_persistent", 0)
+
+
 def test_side_stream_and_graph_capture(lib):
     import mct_quantizers_amd as mq
     q = mq.pytorch_quantizers.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
