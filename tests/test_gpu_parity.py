@@ -252,6 +252,36 @@ def test_abi_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
     assert bits_equal(got, centres.astype(np.float32))
 
 
+@pytest.mark.parametrize("scale,zp,qmin,qmax", [(0.0371, 17, 0, 255), (1.0 / 127.0, 0, -128, 127), (0.25, -3, -8, 7)])
+def test_affine_kernel_equals_aten_cpu_for_every_float_in_the_parity_domain(lib, scale, zp, qmin, qmax):
+    """All float32 bit patterns with |x / scale| < 2^31 (everything else is excluded by the parity gate):
+    the HIP kernel equals the ATen CPU operator the reference calls, bit for bit."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    chunk = 1 << 27
+    s32 = float(np.float32(scale))
+    limit = float(np.float32(2.0 ** 31) * np.float32(scale))
+    y = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    for c in range(32):
+        bits = torch.arange(c * chunk - (1 << 31), (c + 1) * chunk - (1 << 31), dtype=torch.int64, device="cuda")
+        x = bits.to(torch.int32).view(torch.float32)
+        del bits
+        assert lib.mctq_fq_per_tensor_f32(x.data_ptr(), y.data_ptr(), chunk, s32, zp, qmin, qmax, _stream()) == 0
+        x_cpu = x.cpu()
+        want = torch.fake_quantize_per_tensor_affine(x_cpu, s32, zp, qmin, qmax)
+        got = y.cpu()
+        inside = x_cpu.abs() < limit                                    # NaN/inf compare False -> excluded
+        same = (got.view(torch.int32) == want.view(torch.int32)) | ~inside
+        if not bool(same.all()):
+            i = int(torch.nonzero(~same)[0])
+            raise AssertionError(f"x={x_cpu[i].item()!r} hip={got[i].item()!r} aten_cpu={want[i].item()!r}")
+        # outside the domain the kernel saturates instead of inheriting the CPU path's int64-cast UB
+        big = (x_cpu.abs() >= limit) & torch.isfinite(x_cpu)
+        if bool(big.any()):
+            sat = torch.where(x_cpu > 0, torch.tensor((qmax - zp) * s32), torch.tensor((qmin - zp) * s32))
+            assert bool(((got == sat) | ~big).all())
+        del x
+
+
 def _table(lut, mult=128.0, cmin=-128.0, cmax=127.0):
     from mct_quantizers_amd.hip import native
     tab = native.build_lut_table(lut, mult, cmin, cmax)
