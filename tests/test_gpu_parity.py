@@ -603,6 +603,55 @@ def test_non_dense_and_permuted_inputs(lib):
     assert bits_equal(q(sliced).cpu().numpy(), want_s)
 
 
+def test_fuzz_shapes_axes_layouts_and_dtypes_against_aten_cpu(lib):
+    """Seeded fuzz: random ranks, shapes, channel axes, dimension permutations, storage types and slices;
+    the HIP result must equal ATen's CPU operator on the same (finite, in-domain) tensor, strides included."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(2024)
+    for case in range(160):
+        rank = int(rng.integers(1, 6))
+        shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 64])) for _ in range(rank)]
+        if rng.random() < 0.25:
+            shape[int(rng.integers(0, rank))] = int(rng.choice([257, 1024, 1030, 4096]))
+        axis = int(rng.integers(0, rank))
+        dt = [torch.float32, torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 4))]
+        C = shape[axis]
+        bits = int(rng.choice([2, 4, 8]))
+        x = (torch.from_numpy(rng.standard_normal(shape).astype(np.float32)) * 3).to(dt)
+        perm = list(rng.permutation(rank))
+        x = x.permute(perm).contiguous().permute(list(np.argsort(perm)))      # same logical shape, permuted storage
+        if rng.random() < 0.2 and shape[0] > 1:
+            x = x[::2]                                                            # gaps: not dense
+            C = x.shape[axis]
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            q = Q.WeightsSymmetricInferableQuantizer(bits, [float(v) for v in rng.uniform(0.2, 6.0, size=C)], True, axis)
+            ref = lambda t: torch.fake_quantize_per_channel_affine(t, q.scales.cpu(), q.zero_points.cpu(), axis,
+                                                                   q.min_quantized_domain, q.max_quantized_domain)
+        elif kind == 1:
+            lo = [float(v) for v in rng.uniform(-4.0, -0.1, size=C)]
+            hi = [float(v) for v in rng.uniform(0.1, 5.0, size=C)]
+            q = Q.WeightsUniformInferableQuantizer(bits, lo, hi, True, axis)
+            ref = lambda t: torch.fake_quantize_per_channel_affine(t, q.scales.cpu(), q.zero_points.cpu(), axis,
+                                                                   0, 2 ** bits - 1)
+        else:
+            q = Q.ActivationUniformInferableQuantizer(bits, [-2.5], [3.1])
+            ref = lambda t: torch.fake_quantize_per_tensor_affine(t, q.scale, q.zero_point, 0, 2 ** bits - 1)
+        want = ref(x.clone())
+        got = q(x.cuda())
+        info = (case, tuple(x.shape), x.stride(), axis, dt, kind)
+        assert got.dtype == want.dtype and got.shape == want.shape, info
+        assert torch.equal(got.cpu().float().view(torch.int32), want.float().view(torch.int32)), info
+        if x.is_contiguous() or kind != 2:
+            pass
+        # dense inputs keep their strides (ATen semantics); gapped ones are compacted
+        xc = x.cuda()
+        from mct_quantizers_amd.hip.ops import _is_dense
+        if _is_dense(xc):
+            assert got.stride() == xc.stride(), info
+
+
 def test_loud_failures(lib, monkeypatch):
     import mct_quantizers_amd as mq
     from mct_quantizers_amd.hip import native
