@@ -382,18 +382,29 @@ __device__ __forceinline__ void run(const Op& op, const float* in, float* out, c
   }
 }
 
-// U lane-vectors: unpack, run, pack.
+// U lane-vectors: unpack, run, pack.  Ops without a batched tile() go vector by vector, so the wave can
+// start on the first load while the later ones are still in flight (progressive s_waitcnt vmcnt).
 template <bool FAST, class Op, class TI, class TO, int U>
 __device__ __forceinline__ void run_vectors(const Op& op, const typename IO<TI, TO>::VI (&v)[U],
                                             typename IO<TI, TO>::VO (&r)[U], const typename Op::Param& p,
                                             const typename Op::Book& b) {
   typedef IO<TI, TO> io;
-  float in[U * io::N], out[U * io::N];
+  if constexpr (HasTile<Op>::value) {
+    float in[U * io::N], out[U * io::N];
 #pragma unroll
-  for (int u = 0; u < U; ++u) io::unpack(v[u], in + u * io::N);
-  run<FAST, U * io::N>(op, in, out, p, b);
+    for (int u = 0; u < U; ++u) io::unpack(v[u], in + u * io::N);
+    run<FAST, U * io::N>(op, in, out, p, b);
 #pragma unroll
-  for (int u = 0; u < U; ++u) r[u] = io::pack(out + u * io::N);
+    for (int u = 0; u < U; ++u) r[u] = io::pack(out + u * io::N);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float in[io::N], out[io::N];
+      io::unpack(v[u], in);
+      run<FAST, io::N>(op, in, out, p, b);
+      r[u] = io::pack(out);
+    }
+  }
 }
 
 // Tile helpers shared by every launch shape: full tiles (wave-uniform test) run straight-line code.
@@ -417,10 +428,20 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
                                             int64_t limit, bool full) {
   typedef IO<TI, TO> io;
   if (full) {
-    typename io::VO r[U];
-    run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
+    if constexpr (HasTile<Op>::value) {
+      typename io::VO r[U];
+      run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
 #pragma unroll
-    for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
+      for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                            // compute + store as each load lands
+        typename io::VI one[1] = {w[u]};
+        typename io::VO res[1];
+        run_vectors<FAST, Op, TI, TO, 1>(op, one, res, p, book);
+        io::template store<NT>(y + (first + u * kThreads) * io::N, res[0]);
+      }
+    }
   } else {
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -431,6 +452,25 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
         io::template store<NT>(y + (first + u * kThreads) * io::N, res[0]);
       }
   }
+}
+
+// One tile whose parameters are wave-uniform, FULL known at compile time so the hot (full) path and
+// the guarded (row-end) path never share code: the compiler otherwise merges their tails and ends up
+// serialising the loads of the hot path.
+template <bool FULL, class Op, class TI, class TO, int U, bool NT, class GetParam>
+__device__ __forceinline__ void one_tile(const Op& op, float* smem, const TI* __restrict__ xs, TO* __restrict__ ys,
+                                         int64_t first, int64_t limit, GetParam get_param) {
+  typedef IO<TI, TO> io;
+  typename io::VI v[U];
+  // Issue the data loads FIRST; the table staging / parameter fetch (dependent scalar loads + an IEEE
+  // divide) then run in the shadow of the HBM latency.
+  load_tile<TI, TO, U, NT>(v, xs, first, limit, FULL);
+  __builtin_amdgcn_sched_barrier(0);                       // keep the loads above the fetch in the schedule
+  const typename Op::Book book = op.setup(smem);
+  const typename Op::Param p = get_param();
+  const bool fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;   // wave-uniform
+  if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, v, ys, first, limit, FULL);
+  else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, v, ys, first, limit, FULL);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -445,13 +485,14 @@ __global__ __launch_bounds__(kThreads) void flat_kernel(Op op, typename Op::Para
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int64_t nv = n / io::N;
   const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
-  typename io::VI v[U];
-  const bool full = ((int64_t)blockIdx.x + 1) * (kThreads * U) <= nv;   // wave-uniform: no per-lane guards
-  load_tile<TI, TO, U, NT>(v, xs, base, nv, full);
-  const typename Op::Book book = op.setup(smem);            // after the loads are in flight
-  if (Op::can_fast(p)) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, v, ys, base, nv, full);
-  else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, v, ys, base, nv, full);
-  if (blockIdx.x == 0) {                                   // n % N trailing elements
+  auto get_param = [&]() { return p; };
+  if (((int64_t)blockIdx.x + 1) * (kThreads * U) <= nv)     // full tile (wave-uniform test): no per-lane guards
+    one_tile<true, Op, TI, TO, U, NT>(op, smem, xs, ys, base, nv, get_param);
+  else
+    one_tile<false, Op, TI, TO, U, NT>(op, smem, xs, ys, base, nv, get_param);
+  if (blockIdx.x == 0 && nv * io::N < n) {                  // n % N trailing elements (uniform branch)
+    __syncthreads();                                         // everyone is done with the block's table
+    const typename Op::Book book = op.setup(smem);           // all threads: setup may synchronise
     const int64_t i = nv * io::N + threadIdx.x;
     if (i < n) ys[i] = (TO)op.template apply<false>((float)xs[i], p, book);
   }
@@ -476,7 +517,6 @@ __global__ __launch_bounds__(kThreads) void flat_scalar_kernel(Op op, typename O
 template <class Op, class TI, class TO, int U, bool NT>
 __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
                                                         uint32_t tiles_per_row, uint32_t innerv, uint32_t channels) {
-  typedef IO<TI, TO> io;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t row = blockIdx.x, tile = 0;
   if (tiles_per_row != 1) {                                // uniform branch: skip the division for 1 tile/row
@@ -484,28 +524,16 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restr
     tile = blockIdx.x - row * tiles_per_row;
   }
   const int64_t rbase = (int64_t)row * innerv;
-  const uint32_t col = tile * (kThreads * U) + threadIdx.x;
-  const bool full = (tile + 1) * (kThreads * U) <= innerv;     // wave-uniform
-  typename io::VI v[U];
-  // Issue the data loads FIRST; the parameter fetch (two dependent scalar loads + an IEEE divide)
-  // then runs in the shadow of the HBM latency.
-  if (full) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(xs + (rbase + col + u * kThreads) * io::N);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (col + u * kThreads < innerv) v[u] = io::template load<NT>(xs + (rbase + col + u * kThreads) * io::N);
-  }
-  __builtin_amdgcn_sched_barrier(0);                       // keep the loads above the fetch in the schedule
-  const typename Op::Book book = op.setup(smem);
-  uint32_t c = row;
-  if (c >= channels) c = row % channels;                   // uniform; outer == 1 needs no modulo
-  const typename Op::Param p = op.fetch(c);
-  const bool fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;   // wave-uniform
-  const int64_t first = rbase + col;
-  if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, v, ys, first, rbase + innerv, full);
-  else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, v, ys, first, rbase + innerv, full);
+  const int64_t first = rbase + tile * (kThreads * U) + threadIdx.x;
+  auto get_param = [&]() {
+    uint32_t c = row;
+    if (c >= channels) c = row % channels;                 // uniform; outer == 1 needs no modulo
+    return op.fetch(c);
+  };
+  if ((tile + 1) * (kThreads * U) <= innerv)               // wave-uniform
+    one_tile<true, Op, TI, TO, U, NT>(op, smem, xs, ys, first, rbase + innerv, get_param);
+  else
+    one_tile<false, Op, TI, TO, U, NT>(op, smem, xs, ys, first, rbase + innerv, get_param);
 }
 
 // ------------------------------------------------------------------------------------------
