@@ -4,7 +4,6 @@ Bar: bit-exact float32 outputs (hence bit-exact integer clamp indices and LUT in
 inputs with |x/scale| < 2**31.  Everything here reaches the kernels through the C ABI
 (ctypes -> libmctq_hip.so), either directly or via the quantizer classes.
 """
-import ctypes
 import hashlib
 import warnings
 
