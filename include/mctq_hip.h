@@ -210,7 +210,8 @@ int mctq_set_tuning(const char* key, int32_t value);
  * corrections) against the compiler's IEEE division for ALL 2^32 float32 numerators, for each of
  * divisors[n_div] (device float32).  mismatches[n_div] (device uint64, zeroed by the caller) receives the
  * number of numerators whose quotient differs inside the domain where the last bit can matter
- * (2^-40 <= |x/d| < 2^59); outside it the two results must agree on NaN-ness, sign and saturation.
+ * (2^-40 <= |x/d| < 2^59); outside it the two results must agree on sign and saturation (a NaN numerator comes
+ * out saturated low: the kernels test the input itself for NaN).
  */
 int mctq_selftest_division(const float* divisors, int32_t n_div, uint64_t* mismatches, void* stream);
 

@@ -163,55 +163,51 @@ struct LutCommon {
   int step_round;                      // 0, or MCTQ_DT_F16 / MCTQ_DT_BF16: round the quotient and the scaled
                                        // value to that type (half-precision activations, per-tensor only)
 
-  // divisor fl32(thr + eps), multiplier thr, and r = RN(1/d) when the fast exact division below
-  // is valid for this divisor (r == 0 selects the plain IEEE division).
-  struct Param { float d, t, r; };
-  static constexpr int kWords = 3;
+  // divisor d = fl32(thr + eps), multiplier thr; for the fast exact division below also ds = d / mult
+  // (exact: mult is a power of two) and r = RN(1/ds); r == 0 selects the plain IEEE division.
+  // x / ds == (x / d) * mult with a single rounding, bit-identical to the reference's two steps wherever
+  // the codebook decision can depend on the value (no under/overflow there).
+  struct Param { float d, t, r, ds; };
+  static constexpr int kWords = 4;
   static constexpr bool kHeavy = true;         // blocks loop over tiles (set-up paid once per block)
 
-  __host__ __device__ __forceinline__ static Param make(float d, float t) {
+  __host__ __device__ __forceinline__ static Param make(float d, float t, float mult) {
     Param p; p.d = d; p.t = t;
     const float a = fabsf(d);
-    p.r = (a > 0x1p-60f && a < 0x1p60f) ? 1.0f / d : 0.0f;
+    const bool ok = a > 0x1p-60f && a < 0x1p60f;
+    p.ds = d / mult;
+    p.r = ok ? 1.0f / p.ds : 0.0f;
     return p;
   }
   __device__ __forceinline__ Param fetch(uint32_t c) const {
     const float t = thr[c];
-    return make(t + eps, t);
+    return make(t + eps, t, mult);
   }
   __device__ __forceinline__ static void put(float* lds, uint32_t i, uint32_t stride, const Param& p) {
-    lds[i] = p.d; lds[stride + i] = p.t; lds[2 * stride + i] = p.r;
+    lds[i] = p.d; lds[stride + i] = p.t; lds[2 * stride + i] = p.r; lds[3 * stride + i] = p.ds;
   }
   __device__ __forceinline__ static Param get(const float* lds, uint32_t i, uint32_t stride) {
-    Param p; p.d = lds[i]; p.t = lds[stride + i]; p.r = lds[2 * stride + i]; return p;
-  }
-
-  // x / d, correctly rounded, for a divisor shared by many elements.  FAST: with r = RN(1/d),
-  // q0 = x*r followed by two residual corrections with exact FMA residuals -- the same recurrence
-  // the compiler's IEEE expansion runs after its v_rcp/Newton steps, minus the per-element
-  // reciprocal and scaling (7 VALU ops instead of ~11, and no v_div_* wait states).  Outside
-  // |q| < 2^60 (and for inf/NaN) q0 is returned: there the result is clamped anyway, and below
-  // |q| ~ 2^-31 the codebook decision does not depend on the last bits (every |t - c| with c != 0
-  // rounds to |c|).  Verified exhaustively against '/' on the GPU
-  // (tests/test_gpu_parity.py::test_fast_division_is_exact).  Kernels pick FAST per block (rows,
-  // flat: the divisor is wave-uniform) when p.r != 0; FAST = false is the plain IEEE division.
-  template <bool FAST>
-  __device__ __forceinline__ static float divide(float x, const Param& p) {
-    if constexpr (!FAST) {
-      return x / p.d;
-    } else {
-      const float q0 = x * p.r;
-#ifdef MCTQ_ABLATE_DIV
-      return q0;
-#endif
-      const float e0 = __builtin_fmaf(-q0, p.d, x);
-      const float q1 = __builtin_fmaf(e0, p.r, q0);
-      const float e1 = __builtin_fmaf(-q1, p.d, x);
-      const float q2 = __builtin_fmaf(e1, p.r, q1);
-      return (fabsf(q0) < 0x1p60f) ? q2 : q0;
-    }
+    Param p; p.d = lds[i]; p.t = lds[stride + i]; p.r = lds[2 * stride + i]; p.ds = lds[3 * stride + i]; return p;
   }
   __device__ __forceinline__ static bool can_fast(const Param& p) { return p.r != 0.0f; }
+
+  // x / ds, correctly rounded, for a divisor shared by many elements: with r = RN(1/ds), q0 = x*r
+  // followed by two residual corrections with exact FMA residuals -- the recurrence the compiler's
+  // IEEE expansion runs after its v_rcp/Newton steps, minus the per-element reciprocal and scaling
+  // (5 VALU ops instead of ~11, no v_div_* wait states).  The caller keeps |x / ds| <= 2^60 (x is
+  // clamped first: beyond that the value saturates the clip range anyway); below |q| ~ 2^-31 the
+  // codebook decision does not depend on the last bits (every |t - c| with c != 0 rounds to |c|).
+  // Verified exhaustively against '/' on the GPU (tests/test_gpu_parity.py::test_fast_division_is_exact).
+  __device__ __forceinline__ static float divide_fast(float x, float ds, float r) {
+    const float q0 = x * r;
+#ifdef MCTQ_ABLATE_DIV
+    return q0;
+#endif
+    const float e0 = __builtin_fmaf(-q0, ds, x);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-q1, ds, x);
+    return __builtin_fmaf(e1, r, q1);
+  }
 
   __device__ __forceinline__ float narrow(float v) const {
     if (step_round == MCTQ_DT_F16) return (float)(_Float16)v;
@@ -219,11 +215,18 @@ struct LutCommon {
     return v;
   }
   // (x / d) * mult as the reference's op chain computes it (quantizer_utils.py:169), incl. the
-  // per-op roundings of a half-precision activation tensor.
+  // per-op roundings of a half-precision activation tensor.  FAST (wave-uniform divisor with
+  // p.r != 0): NaN inputs come out as the saturated minimum and must be handled by the caller.
   template <bool FAST>
   __device__ __forceinline__ float scaled(float x, const Param& p) const {
-    if (step_round == 0) return divide<FAST>(x, p) * mult;
-    return narrow(narrow(divide<false>(x, p)) * mult);
+    if (step_round != 0) return narrow(narrow(x / p.d) * mult);
+    if constexpr (FAST) {
+      const float xmax = 0x1p60f * fabsf(p.ds);                          // uniform, once per tile
+      const float xc = __builtin_amdgcn_fmed3f(x, -xmax, xmax);          // NaN -> -xmax
+      return divide_fast(xc, p.ds, p.r);
+    } else {
+      return (x / p.d) * mult;
+    }
   }
 };
 
@@ -266,7 +269,10 @@ struct LutOp : LutCommon {
   __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
     const float v = scaled<FAST>(x, p);
     float t = fminf(fmaxf(v, cmin), cmax);
-    t = (v != v) ? v : t;                              // torch.clip keeps NaN
+    // torch.clip keeps NaN: a NaN input (hidden by the clamped numerator of the fast division) or a NaN
+    // made by the IEEE division itself (0/0, inf/inf)
+    t = (x != x) ? x : t;
+    t = (v != v) ? v : t;
     float best_c = b.c[0];
     float best_d = fabsf(t - best_c);
     if constexpr (LP > 0) {
@@ -319,38 +325,44 @@ struct LutTableOp : LutCommon {
     return b;
   }
 
-  // stage 1: scaled, clamped value and its table index
+  // stage 1: scaled value and its table index.  The value is NOT clamped: the index is (integer
+  // clamp, one v_med3_i32), and comparing the raw value with the edge entries' thresholds gives the
+  // same side as comparing the clipped one (T_0 > clip_min or -inf; T_last <= clip_max).
   template <bool FAST>
-  __device__ __forceinline__ void locate(float x, const Param& p, float& v, float& t, int& k) const {
+  __device__ __forceinline__ void locate(float x, const Param& p, float& v, int& k) const {
     v = scaled<FAST>(x, p);
-    t = fminf(fmaxf(v, cmin), cmax);                  // NaN -> cmin here, overridden in decide()
-    k = (int)__builtin_fmaf(t, 2.0f, koff);           // nearest half-integer point (any tie is fine)
+    const int kk = (int)__builtin_fmaf(v, 2.0f, koff);  // nearest half-integer point (any tie is fine); saturating
+    k = min(max(kk, 0), entries - 1);
   }
   // stage 3: pick the side of the step, dequantize
-  __device__ __forceinline__ float decide(float v, float t, f32x2 e, const Param& p, const Book& b) const {
+  template <bool FAST>
+  __device__ __forceinline__ float decide(float x, float v, f32x2 e, const Param& p, const Book& b) const {
     const uint32_t pair = __float_as_uint(e.y);
-    const uint32_t h = (t >= e.x) ? (pair >> 16) : (pair & 0xffffu);
+    const uint32_t h = (v >= e.x) ? (pair >> 16) : pair;             // cvt reads the low half only
     float q = __half2float(__ushort_as_half((unsigned short)h));
-    q = (v != v) ? b.nan_q : q;                       // all-NaN distances: argmin is index 0
+    // NaN input (all-NaN distances: argmin is index 0).  FAST: the clamped numerator hid it, look at x;
+    // otherwise the IEEE chain propagated it (and 0/0, inf/inf) into v.
+    const bool nan = (FAST && step_round == 0) ? (x != x) : (v != v);
+    q = nan ? b.nan_q : q;
     return q * p.t;
   }
 
   template <bool FAST = false>
   __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
-    float v, t; int k;
-    locate<FAST>(x, p, v, t, k);
-    return decide(v, t, b.tab[k], p, b);
+    float v; int k;
+    locate<FAST>(x, p, v, k);
+    return decide<FAST>(x, v, b.tab[k], p, b);
   }
 
   // A whole tile: all indices first, then all LDS reads back to back, then all selects, so one
   // s_waitcnt covers NE lookups instead of one per element.
   template <bool FAST, int NE>
   __device__ __forceinline__ void tile(const float* in, float* out, const Param& p, const Book& b) const {
-    float v[NE], t[NE];
+    float v[NE];
     int k[NE];
     f32x2 e[NE];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], t[i], k[i]);
+    for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], k[i]);
 #pragma unroll
 #ifdef MCTQ_ABLATE_LDS
     for (int i = 0; i < NE; ++i) { e[i].x = (float)k[i]; e[i].y = __uint_as_float(0x3c003800u); }
@@ -358,7 +370,7 @@ struct LutTableOp : LutCommon {
     for (int i = 0; i < NE; ++i) e[i] = b.tab[k[i]];
 #endif
 #pragma unroll
-    for (int i = 0; i < NE; ++i) out[i] = decide(v[i], t[i], e[i], p, b);
+    for (int i = 0; i < NE; ++i) out[i] = decide<FAST>(in[i], v[i], e[i], p, b);
   }
 };
 

@@ -15,7 +15,7 @@ int mctq_lut_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32
   if (int rc = check_lut_args(lut, n_lut, mult)) return rc;
   if (step_round != 0 && step_round != MCTQ_DT_F16 && step_round != MCTQ_DT_BF16) return fail_arg("bad step_round");
   hipStream_t st = (hipStream_t)stream;
-  const LutCommon::Param p = LutCommon::make(thr_div, thr_mul);
+  const LutCommon::Param p = LutCommon::make(thr_div, thr_mul, mult);
   if (dtype != MCTQ_DT_F32) return fail_arg("the literal-scan LUT kernels take float32 input (widen first)");
   {
     typedef float TI;

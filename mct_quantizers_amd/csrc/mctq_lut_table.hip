@@ -69,7 +69,7 @@ int mctq_lutt_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int3
   if (step_round != 0 && step_round != MCTQ_DT_F16 && step_round != MCTQ_DT_BF16) return fail_arg("bad step_round");
   LutTableOp op;
   if (int rc = make_table_op(op, nullptr, 0.f, table, entries, mult, clip_min, clip_max, step_round)) return rc;
-  const LutCommon::Param p = LutCommon::make(thr_div, thr_mul);
+  const LutCommon::Param p = LutCommon::make(thr_div, thr_mul, mult);
   return with_lut_types(dtype, [&](auto ti, auto to) {
     return launch_flat<decltype(ti), decltype(to)>(op, p, x, y, n, table_bytes(entries), (hipStream_t)stream);
   });

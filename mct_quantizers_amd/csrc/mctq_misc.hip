@@ -37,16 +37,18 @@ __global__ __launch_bounds__(kThreads) void selftest_division_kernel(const float
                                                                      unsigned long long* __restrict__ mismatches) {
   const uint64_t stride = (uint64_t)gridDim.x * kThreads;
   for (int j = 0; j < n_div; ++j) {
-    const LutCommon::Param p = LutCommon::make(divisors[j], divisors[j]);
+    const LutCommon::Param p = LutCommon::make(divisors[j], divisors[j], 1.0f);
     unsigned int bad = 0;
     for (uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x; b < (1ull << 32); b += stride) {
       const float x = __uint_as_float((uint32_t)b);
       const float slow = x / p.d;
-      const float fast = LutCommon::can_fast(p) ? LutCommon::divide<true>(x, p) : LutCommon::divide<false>(x, p);
+      const float xmax = 0x1p60f * fabsf(p.ds);
+      const float fast = LutCommon::can_fast(p) ? LutCommon::divide_fast(__builtin_amdgcn_fmed3f(x, -xmax, xmax), p.ds, p.r) : x / p.d;
       const float a = fabsf(slow);
       bool ok;
       if (a >= 0x1p-40f && a < 0x1p59f) ok = __float_as_uint(slow) == __float_as_uint(fast);    // exact domain
-      else if (slow != slow) ok = fast != fast;                                                   // NaN stays NaN
+      else if (slow != slow) ok = LutCommon::can_fast(p) ? (x != x && fast <= -0x1p58f) || (x == x && fast != fast) || fabsf(fast) >= 0x1p58f
+                                                         : fast != fast;      // NaN numerator: saturated low (caller checks x)
       else if (a >= 0x1p59f) ok = fabsf(fast) >= 0x1p58f && (slow < 0) == (fast < 0);             // clamps alike
       else ok = fabsf(fast) < 0x1p-39f;                                                           // stays tiny
       bad += ok ? 0u : 1u;
