@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Tuple
 
+import os
+
 import torch
 
 from mct_quantizers_amd.hip import native
@@ -342,11 +344,19 @@ def _is_real(x) -> bool:
     return type(x) is torch.Tensor or type(x) is torch.nn.Parameter
 
 
+def _cpu_route_allowed():
+    """CPU tensors run the ATen operators the reference runs on them (BASELINE config 1).  Deployments that
+    must never leave the GPU set MCTQ_REQUIRE_HIP=1: a CPU tensor then raises instead."""
+    if os.environ.get("MCTQ_REQUIRE_HIP", "0") not in ("", "0"):
+        raise RuntimeError("MCTQ_REQUIRE_HIP is set: refusing to quantize a CPU tensor outside the HIP kernels")
+
+
 def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
     if _is_real(x):
         if x.is_cuda:
             return _hip_fq_per_tensor(x, scale, zero_point, qmin, qmax)
         if x.device.type == "cpu":
+            _cpu_route_allowed()
             return _cpu_fq_per_tensor(x, scale, zero_point, qmin, qmax)
     return torch.ops.mctq_amd.fq_per_tensor(x, scale, zero_point, qmin, qmax)
 
@@ -356,6 +366,7 @@ def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
         if x.is_cuda:
             return _hip_fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
         if x.device.type == "cpu":
+            _cpu_route_allowed()
             return _cpu_fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
     return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
 
@@ -366,6 +377,7 @@ def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: fl
         if x.is_cuda:
             return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round)
         if x.device.type == "cpu":
+            _cpu_route_allowed()
             return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round)
     return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
 
@@ -375,5 +387,6 @@ def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin
         if x.is_cuda:
             return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, table)
         if x.device.type == "cpu":
+            _cpu_route_allowed()
             return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
     return torch.ops.mctq_amd.lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)

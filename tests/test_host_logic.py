@@ -260,3 +260,23 @@ def test_integer_codes_dequantize_to_the_fake_quant_output_cpu():
     codes, s, z = qa.quantize_to_codes(x)
     assert codes.dtype == torch.uint8
     assert torch.equal((codes.float() - z) * torch.tensor(s, dtype=torch.float32), qa(x))
+
+
+def test_require_hip_switch_refuses_cpu_tensors(monkeypatch):
+    q = Q.ActivationSymmetricInferableQuantizer(8, [4.0], True)
+    monkeypatch.setenv("MCTQ_REQUIRE_HIP", "1")
+    with pytest.raises(RuntimeError, match="MCTQ_REQUIRE_HIP"):
+        q(torch.zeros(4))
+    monkeypatch.setenv("MCTQ_REQUIRE_HIP", "0")
+    assert q(torch.zeros(4)).abs().sum() == 0
+
+
+def test_torch_compile_traces_through_the_custom_ops():
+    lin = torch.nn.Linear(16, 8)
+    m = torch.nn.Sequential(
+        PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 8, True, 0)}),
+        PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])))
+    x = torch.randn(4, 16)
+    want = m(x)
+    torch._dynamo.reset()
+    assert torch.equal(torch.compile(m, backend="aot_eager")(x), want)
