@@ -118,6 +118,7 @@ struct AffineOp {
 #else
   static constexpr bool kHeavy = false;       // a few VALU ops per element: pure streaming
 #endif
+  static constexpr bool kFallback = false;
 
   __host__ __device__ __forceinline__ static Param make(float s, int32_t zp) {
     Param p;
@@ -169,7 +170,8 @@ struct LutCommon {
   // the codebook decision can depend on the value (no under/overflow there).
   struct Param { float d, t, r, ds; };
   static constexpr int kWords = 4;
-  static constexpr bool kHeavy = true;         // blocks loop over tiles (set-up paid once per block)
+  static constexpr bool kHeavy = true;         // launched through the heavy-op dispatch
+  static constexpr bool kFallback = false;     // overridden by the literal-scan op
 
   __host__ __device__ __forceinline__ static Param make(float d, float t, float mult) {
     Param p; p.d = d; p.t = t;
@@ -239,6 +241,9 @@ template <int LP>   // LP > 0: codebook broadcast into LP scalar registers; LP =
 struct LutOp : LutCommon {
   const float* __restrict__ lut;       // [n_lut] device codebook, caller's order
   int n_lut;
+  // Fallback path (non-integer codebooks, bit widths the decision table does not cover): built in one
+  // launch variant only (2 lane-vectors per lane, non-temporal, one tile per block) to keep the library small.
+  static constexpr bool kFallback = true;
 
   typedef typename std::conditional<(LP > 0), RegBook<(LP > 0 ? LP : 1)>, LdsBook>::type Book;
 
@@ -746,7 +751,9 @@ static bool vec_aligned(const void* x, const void* y) {
 
 #define MCTQ_DISPATCH_HEAVY(U_, NT_, ...)                                                   \
   do {                                                                                      \
-    if constexpr (std::is_same<TI, float>::value) {                                         \
+    if constexpr (Op::kFallback) {                                                          \
+      constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__;                           \
+    } else if constexpr (std::is_same<TI, float>::value) {                                  \
       if (NT_) {                                                                            \
         switch (U_) {                                                                       \
           case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;           \
@@ -798,7 +805,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
   }
   const int64_t nv = n / io::N;
   if constexpr (Op::kHeavy) {
-    if (!g_heavy_persistent) {
+    if (Op::kFallback || !g_heavy_persistent) {
       MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, g_nt, {
         int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
         if (blocks == 0) blocks = 1;
@@ -808,7 +815,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
       });
       return check_launch("flat launch");
     }
-    MCTQ_DISPATCH_HEAVY(2, g_nt, {
+    if constexpr (!Op::kFallback) MCTQ_DISPATCH_HEAVY(2, g_nt, {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       const int64_t cap = (int64_t)cu_count() * 16;
       if (blocks > cap) blocks = cap;
@@ -853,17 +860,18 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         if ((cap - innerv) * 8 <= cap) { u_sel = u; break; }
       }
       if (g_heavy_unroll) u_sel = g_heavy_unroll;
+      if (Op::kFallback) u_sel = 2;                       // the only variant built for the fallback ops
       const int64_t per = (int64_t)kThreads * u_sel;
       const int64_t tiles = (innerv + per - 1) / per;
       const int64_t total = rows * tiles;
-      if (!g_heavy_persistent && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+      if ((Op::kFallback || !g_heavy_persistent) && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
         });
         return check_launch("rows launch");
       }
-      if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+      if constexpr (!Op::kFallback) if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
           int64_t grid = (int64_t)cu_count() * persist_blocks_per_cu<Op, TI, TO, U, NT>(book_bytes);
           if (grid > total) grid = total;
