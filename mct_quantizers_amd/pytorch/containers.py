@@ -22,8 +22,19 @@ from mct_quantizers_amd.common.registry import BaseInferableQuantizer
 from mct_quantizers_amd.logger import Logger
 
 
+_TRAINING_FLAG_BY_CLASS = {}
+
+
 def _takes_training_flag(quantizer) -> bool:
-    return TRAINING in inspect.signature(quantizer.__call__).parameters
+    """Does ``quantizer.__call__`` have a parameter literally named ``training``?  The reference reflects on
+    the signature in every forward (quantize_wrapper.py:232); the answer is a property of the class, so it is
+    looked up once per class here."""
+    cls = type(quantizer)
+    flag = _TRAINING_FLAG_BY_CLASS.get(cls)
+    if flag is None:
+        flag = TRAINING in inspect.signature(quantizer.__call__).parameters
+        _TRAINING_FLAG_BY_CLASS[cls] = flag
+    return flag
 
 
 class PytorchQuantizationWrapper(nn.Module):
