@@ -1,0 +1,44 @@
+"""End-to-end: a stack of wrapped Linear layers + activation holders, weights re-quantized every forward
+(the reference's default behaviour), this package vs the ATen operators the reference would call on the GPU."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mct_quantizers_amd as mq
+Q = mq.pytorch_quantizers
+
+class AtenWeights(mq.BaseInferableQuantizer):          # what the reference's WeightsSymmetric.__call__ does on a GPU tensor
+    def __init__(self, q): super().__init__(); self.q = q
+    def __call__(self, w):
+        return torch.fake_quantize_per_channel_affine(w, self.q.scales, self.q.zero_points, 0, -128, 127)
+class AtenAct(mq.BaseInferableQuantizer):
+    def __init__(self, q): super().__init__(); self.q = q
+    def __call__(self, x):
+        with torch.no_grad():
+            return torch.fake_quantize_per_tensor_affine(x, self.q.scale, self.q.zero_point, 0, 255)
+
+def build(layers, d, aten):
+    mods = []
+    torch.manual_seed(0)
+    for _ in range(layers):
+        lin = torch.nn.Linear(d, d, bias=False).cuda()
+        thr = [float(v) for v in lin.weight.detach().abs().amax(dim=1)]
+        wq = Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)
+        aq = Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0])
+        mods.append(mq.PytorchQuantizationWrapper(lin, {"weight": AtenWeights(wq) if aten else wq}))
+        mods.append(mq.PytorchActivationQuantizationHolder(AtenAct(aq) if aten else aq))
+    return torch.nn.Sequential(*mods)
+
+def timeit(m, x, n=30):
+    with torch.no_grad():
+        for _ in range(5): y = m(x)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(n): y = m(x)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3, y
+
+for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
+    x = torch.randn(batch, d, device="cuda")
+    ours, y1 = timeit(build(layers, d, False), x)
+    aten, y2 = timeit(build(layers, d, True), x)
+    print(f"{layers} x Linear({d},{d}) batch {batch}: this package {ours:7.3f} ms/forward, ATen fake-quant ops {aten:7.3f} ms/forward "
+          f"(x{aten/ours:.2f}), outputs equal={torch.equal(y1, y2)}", flush=True)
