@@ -36,8 +36,8 @@ HBM_COPY_GBS = 6290.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--batch", type=int, default=64, help="N of config 3")
     ap.add_argument("--ring", type=int, default=0, help="buffer pairs to rotate over (0 = enough to exceed 512 MiB)")
