@@ -15,6 +15,8 @@
 //   rows          per-channel, long vector-divisible rows: one block = one tile of one
 //                 (outer, channel) row; data loads are issued first, then the channel's parameters
 //                 arrive through scalar loads (wave-uniform index) -> SGPR broadcast.
+//   lastaxis      per-channel along the fastest axis (inner == 1): parameters by 16-byte loads from the
+//                 L1/L2-resident tables, one set per element.
 //   window        per-channel, any inner (channel-last, conv kernels, ragged, unaligned): one
 //                 block = one contiguous tile; the parameters of the rows that tile touches are
 //                 staged in LDS once per block and looked up per element without any per-element
@@ -128,6 +130,19 @@ struct AffineOp {
     return p;
   }
   __device__ __forceinline__ Param fetch(uint32_t c) const { return make(scales[c], zps[c]); }
+  // N consecutive channels starting at c (c % 4 == 0, tables 16-byte aligned): 16-byte loads of the tables
+  template <int N>
+  __device__ __forceinline__ void fetch_vec(uint32_t c, Param* p) const {
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(scales + c + j);
+      const i32x4 z4 = *reinterpret_cast<const i32x4*>(zps + c + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[j + i] = make(s4[i], z4[i]);
+    }
+  }
+  __host__ bool tables_aligned16() const { return (((uintptr_t)scales | (uintptr_t)zps) & 15u) == 0; }
   __device__ __forceinline__ static void put(float* lds, uint32_t i, uint32_t stride, const Param& p) {
     lds[i] = p.s; lds[stride + i] = p.inv; lds[2 * stride + i] = p.zf;
   }
@@ -185,6 +200,16 @@ struct LutCommon {
     const float t = thr[c];
     return make(t + eps, t, mult);
   }
+  template <int N>
+  __device__ __forceinline__ void fetch_vec(uint32_t c, Param* p) const {
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(thr + c + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[j + i] = make(t4[i] + eps, t4[i], mult);
+    }
+  }
+  __host__ bool tables_aligned16() const { return ((uintptr_t)thr & 15u) == 0; }
   __device__ __forceinline__ static void put(float* lds, uint32_t i, uint32_t stride, const Param& p) {
     lds[i] = p.d; lds[stride + i] = p.t; lds[2 * stride + i] = p.r; lds[3 * stride + i] = p.ds;
   }
@@ -633,6 +658,39 @@ __global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op:
 }
 
 // ------------------------------------------------------------------------------------------
+// lastaxis: the channel axis is the fastest-varying one (inner == 1: NHWC activations, [tokens, hidden],
+// weights quantized along their last axis) and C % N == 0.  Every element has its own parameters, so no
+// staging can amortise them; a lane's N consecutive elements are N consecutive channels and their
+// parameters are fetched with 16-byte loads straight from the (L1/L2-resident) tables.
+// ------------------------------------------------------------------------------------------
+template <class Op, class TI, class TO, int U, bool NT, typename IdxT>
+__global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT nv,
+                                                            uint32_t channels) {
+  typedef IO<TI, TO> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const IdxT base = (IdxT)blockIdx.x * (kThreads * U) + threadIdx.x;
+  typename io::VI v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (base + u * kThreads < nv) v[u] = io::template load<NT>(xs + (base + u * kThreads) * io::N);
+  const typename Op::Book book = op.setup(smem);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const IdxT i = base + u * kThreads;
+    if (i < nv) {
+      const uint32_t c0 = (uint32_t)((i * io::N) % channels);
+      typename Op::Param p[io::N];
+      op.template fetch_vec<io::N>(c0, p);
+      float in[io::N], out[io::N];
+      io::unpack(v[u], in);
+#pragma unroll
+      for (int j = 0; j < io::N; ++j) out[j] = op.template apply<false>(in[j], p[j], book);
+      io::template store<NT>(ys + i * io::N, io::pack(out));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // window: block b owns elements [b*TILE, (b+1)*TILE), TILE = 256*U*V (V = lane-vector width, or
 // 1 for unaligned tensors).  The tile touches rows row0 .. row0+nrows-1 of the [outer*C][inner]
 // view; their parameters are staged in LDS (structure-of-arrays, so lanes that read different rows
@@ -848,7 +906,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   const bool vec_ok = vec_aligned<TI, TO>(x, y);
 
   // rows shape: long, vector-divisible rows.
-  if (vec_ok && (inner % io::N) == 0 && inner >= 1024 && channels <= 0xffffffffLL && rows <= 0xffffffffLL) {
+  if (vec_ok && (inner % io::N) == 0 && inner / io::N >= kThreads && channels <= 0xffffffffLL && rows <= 0xffffffffLL) {
     const int64_t innerv = inner / io::N;
     if constexpr (Op::kHeavy) {
       // Lane-vectors per lane per tile: the widest of {4, 2, 1} whose idle lanes in the last tile
@@ -900,6 +958,22 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         });
         return check_launch("rows launch");
       }
+    }
+  }
+
+  // lastaxis shape.
+  if (vec_ok && inner == 1 && (channels % io::N) == 0 && channels <= 0x7fffffffLL && op.tables_aligned16()) {
+    constexpr int LU = 4;
+    const int64_t nv = n / io::N;
+    const int64_t blocks = (nv + kThreads * LU - 1) / (kThreads * LU);
+    if (blocks <= 0x7fffffffLL) {
+      if (nv <= 0x7fffffffLL / (int64_t)io::N)
+        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, true, uint32_t>), dim3((unsigned)blocks), dim3(kThreads),
+                           book_bytes, st, op, x, y, (uint32_t)nv, (uint32_t)channels);
+      else
+        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, true, uint64_t>), dim3((unsigned)blocks), dim3(kThreads),
+                           book_bytes, st, op, x, y, (uint64_t)nv, (uint32_t)channels);
+      return check_launch("lastaxis launch");
     }
   }
 

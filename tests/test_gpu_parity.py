@@ -81,7 +81,8 @@ def test_half_precision_golden_cases_via_quantizer_classes(lib, half_cases):
 @pytest.mark.parametrize("dt", ["float16", "bfloat16"])
 @pytest.mark.parametrize("outer,C,inner,offset", [(1, 1, 5, 0), (7, 3, 1, 0), (33, 5, 2, 1), (2, 16, 8, 0), (3, 64, 12, 3),
                                                   (1, 300, 576, 0), (2, 6, 1024, 0), (3, 5, 1032, 0), (1, 64, 4096, 0),
-                                                  (2, 3, 11008, 8), (1, 20000, 1, 0), (1, 2, 70000, 0), (1, 1, 4099, 1)])
+                                                  (2, 3, 11008, 8), (1, 20000, 1, 0), (1, 2, 70000, 0), (1, 1, 4099, 1),
+                                                  (37, 64, 1, 0), (5, 4096, 1, 0), (9, 24, 1, 8)])
 def test_abi_half_per_channel_and_per_tensor_vs_oracle(lib, dt, outer, C, inner, offset):
     from oracle import mctq_oracle as O
     code = {"float16": 1, "bfloat16": 2}[dt]
@@ -156,6 +157,7 @@ CHANNEL_SHAPES = [
     (1, 1, 1), (1, 3, 1), (7, 3, 1), (1000, 3, 1), (33, 5, 2), (9, 4, 3), (2, 16, 4), (5, 7, 5),
     (3, 64, 12), (2, 8, 100), (1, 300, 576), (4, 6, 1020), (2, 6, 1024), (3, 5, 1028), (1, 64, 4096),
     (2, 3, 11008), (1, 5000, 7), (1, 20000, 1), (3, 1, 5000), (1, 2, 70000), (1, 1, 4099),
+    (37, 64, 1), (5, 4096, 1), (1, 8, 1), (300, 12, 1),          # channel-last: the lastaxis shape (C % 4 == 0)
 ]
 
 
@@ -229,7 +231,7 @@ def test_abi_lut_per_tensor_vs_oracle(lib, lut_name, n, offset):
 
 @pytest.mark.parametrize("lut_name", ["l3dup", "l16", "l40", "l256"])
 @pytest.mark.parametrize("outer,C,inner", [(1, 3, 1), (50, 3, 1), (4, 6, 5), (2, 8, 100), (2, 6, 1024), (3, 5, 1028),
-                                           (1, 16, 11008), (1, 3000, 3)])
+                                           (1, 16, 11008), (1, 3000, 3), (41, 64, 1), (3, 4096, 1)])
 def test_abi_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
     from oracle import mctq_oracle as O
     rng = np.random.default_rng(C * 31 + inner)
@@ -338,7 +340,7 @@ def test_decision_table_unsigned_and_wide_codebooks(lib):
 
 @pytest.mark.parametrize("lut_name", ["l3dup", "l16", "l256"])
 @pytest.mark.parametrize("outer,C,inner", [(1, 3, 1), (50, 3, 1), (4, 6, 5), (2, 8, 100), (2, 6, 1024), (3, 5, 1028),
-                                           (1, 16, 11008), (1, 3000, 3), (1, 2, 70000)])
+                                           (1, 16, 11008), (1, 3000, 3), (1, 2, 70000), (41, 64, 1), (3, 4096, 1)])
 def test_abi_table_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
     from oracle import mctq_oracle as O
     rng = np.random.default_rng(C * 31 + inner + 1)
@@ -372,7 +374,8 @@ def test_fast_division_is_exact(lib):
 
 
 @pytest.mark.parametrize("dt", ["float32", "float16", "bfloat16"])
-@pytest.mark.parametrize("outer,C,inner", [(7, 3, 1), (33, 5, 2), (2, 8, 100), (2, 6, 1024), (1, 64, 4096), (1, 5000, 7)])
+@pytest.mark.parametrize("outer,C,inner", [(7, 3, 1), (33, 5, 2), (2, 8, 100), (2, 6, 1024), (1, 64, 4096), (1, 5000, 7),
+                                           (19, 256, 1)])
 def test_integer_codes_equal_the_oracle_index(lib, dt, outer, C, inner):
     """int8 / uint8 code outputs == the oracle's clamp index, for per-channel and per-tensor, all storage types."""
     from oracle import mctq_oracle as O

@@ -1,0 +1,31 @@
+"""Throughput sweep of the per-channel / per-tensor affine kernels over shapes, axes and storage types
+(cold ring), to spot launch shapes that fall off the HBM roof."""
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mct_quantizers_amd as mq
+Q = mq.pytorch_quantizers
+def timeit(f, xs, steps):
+    n = len(xs); outs = [None] * n
+    for i in range(5): outs[i % n] = f(xs[i % n])
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps): outs[i % n] = f(xs[i % n])
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) * 1e3 / steps
+cases = []
+_w = torch.randn(4096, 4096, device='cuda'); _q = Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 4096, True, 0)
+for _ in range(3000): _q(_w)          # bring the clocks up before the first measurement
+torch.cuda.synchronize()
+for dt in (torch.float32, torch.bfloat16):
+    for shape, axis in (((4096, 4096), 0), ((4096, 4096), 1), ((4096, 4100), 0), ((4096, 4099), 0), ((4097, 4096), 0),
+                        ((16384, 1024), 0), ((16384, 1020), 0), ((65536, 256), 0), ((262144, 64), 0), ((1048576, 16), 0),
+                        ((2048, 8192), 1), ((256, 65536), 0), ((8, 2097152), 0), ((1, 16777216), 0),
+                        ((64, 256, 56, 56), 1), ((64, 56, 56, 256), 3), ((512, 512, 3, 3), 0), ((2048, 2048, 3, 3), 0),
+                        ((32, 3, 224, 224), 1), ((50257, 768), 0), ((50257, 768), 1)):
+        C = shape[axis]
+        q = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + (i % 97) * 0.01 for i in range(C)], True, axis)
+        x = torch.randn(*shape, device="cuda").to(dt)
+        b = x.numel() * x.element_size() * 2
+        ring = max(2, -(-(512 << 20) // b) + 1); ring = min(ring, 64)
+        xs = [x] + [x.clone() for _ in range(ring - 1)]
+        t = timeit(q, xs, 100)
+        print(f"{str(dt)[6:]:9s} {str(shape):22s} axis {axis}  {t:9.2f} us  {b / t / 1e3:7.0f} GB/s", flush=True)
