@@ -711,12 +711,24 @@ __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __res
   float* tab = smem + op.book_words();
 
   const IdxT e0 = (IdxT)blockIdx.x * TILE;
-  const IdxT row0 = e0 / inner;                            // uniform, once per block
-  const uint32_t rem0 = (uint32_t)(e0 - row0 * inner);
   const IdxT left = n - e0;
   const uint32_t count = left < (IdxT)TILE ? (uint32_t)left : TILE;
+
+  // data loads first: the window staging below (division, table reads, barrier) runs under their latency
+  typename io::VI v[U];
+  if (VEC) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t off = (u * kThreads + threadIdx.x) * V;
+      if (off + V <= count) v[u] = io::template load<NT>(xs + e0 + off);
+    }
+  }
+
+  const IdxT row0 = e0 / inner;                            // uniform, once per block
+  const uint32_t rem0 = (uint32_t)(e0 - row0 * inner);
   const uint32_t nrows = (rem0 + count - 1) / inner + 1;
   const bool whole = channels <= nrows;
+  const bool same_row = VEC && (inner % V) == 0;            // a lane-vector never straddles two rows
   const uint32_t c0 = (uint32_t)(row0 % channels);
   if (whole) {
     for (uint32_t i = threadIdx.x; i < channels; i += kThreads) Op::put(tab, i, stride, op.fetch(i));
@@ -740,7 +752,10 @@ __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __res
     if (whole) li = (c0 + lrow) % channels;
     if (VEC && off + V <= count) {
       float in[V], out[V];
-      io::unpack(io::template load<NT>(xs + e0 + off), in);
+      io::unpack(v[u], in);
+      if (same_row) {                                        // uniform: one parameter set per lane-vector
+        run<false, (int)V>(op, in, out, Op::get(tab, li, stride), book);
+      } else
 #pragma unroll
       for (uint32_t j = 0; j < V; ++j) {
         out[j] = op.template apply<false>(in[j], Op::get(tab, li, stride), book);
