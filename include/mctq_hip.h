@@ -65,7 +65,8 @@ int mctq_fq_per_tensor_f32(const float* x, float* y, int64_t n,
                            float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,
                            void* stream);
 
-/* Same, with scale/zero point taken per channel: scales[channels] float32, zero_points[channels] int32. */
+/* Same, with scale/zero point taken per channel: scales[channels] float32, zero_points[channels] int32
+ * (zero_points may be NULL, meaning all zero: the symmetric quantizers). */
 int mctq_fq_per_channel_f32(const float* x, float* y,
                             int64_t outer, int64_t channels, int64_t inner,
                             const float* scales, const int32_t* zero_points,

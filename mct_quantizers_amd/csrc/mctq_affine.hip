@@ -27,7 +27,7 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
   if (outer < 0 || channels < 0 || inner < 0) return fail_arg("negative extent");
   if (quant_min > quant_max) return fail_arg("quant_min > quant_max");
   const int64_t n = outer * channels * inner;
-  if (n > 0 && (!x || !y || !scales || !zero_points)) return fail_arg("NULL pointer");
+  if (n > 0 && (!x || !y || !scales)) return fail_arg("NULL pointer");
   AffineOp op;
   op.scales = scales; op.zps = zero_points;
   op.lo = (float)quant_min; op.hi = (float)quant_max;

@@ -32,7 +32,7 @@ int mctq_fq_codes_per_channel(const void* x, void* codes, int64_t outer, int64_t
                               int32_t quant_min, int32_t quant_max, void* stream) {
   if (outer < 0 || channels < 0 || inner < 0) return fail_arg("negative extent");
   const int64_t n = outer * channels * inner;
-  if (n > 0 && (!x || !codes || !scales || !zero_points)) return fail_arg("NULL pointer");
+  if (n > 0 && (!x || !codes || !scales)) return fail_arg("NULL pointer");
   if (int rc = check_code_range(code_dtype, quant_min, quant_max)) return rc;
   AffineCodesOp op;
   op.scales = scales; op.zps = zero_points;

@@ -109,7 +109,7 @@ struct NoBook {};
 
 struct AffineOp {
   const float* __restrict__ scales;    // [C] (per-channel launches only)
-  const int32_t* __restrict__ zps;     // [C]
+  const int32_t* __restrict__ zps;     // [C], or NULL for all-zero zero points (symmetric quantizers)
   float lo, hi;                        // clamp domain as floats (exact: |q| < 2^24)
 
   struct Param { float s, inv, zf; };
@@ -129,7 +129,7 @@ struct AffineOp {
     p.zf = (float)zp;
     return p;
   }
-  __device__ __forceinline__ Param fetch(uint32_t c) const { return make(scales[c], zps[c]); }
+  __device__ __forceinline__ Param fetch(uint32_t c) const { return make(scales[c], zps ? zps[c] : 0); }
   // N consecutive channels starting at c (c % 4 == 0, tables 16-byte aligned): 16-byte loads of the tables
   template <int N>
   __device__ __forceinline__ void fetch_vec(uint32_t c, Param* p) const {
@@ -137,7 +137,8 @@ struct AffineOp {
 #pragma unroll
     for (int j = 0; j < N; j += 4) {
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(scales + c + j);
-      const i32x4 z4 = *reinterpret_cast<const i32x4*>(zps + c + j);
+      i32x4 z4 = {0, 0, 0, 0};
+      if (zps) z4 = *reinterpret_cast<const i32x4*>(zps + c + j);       // NULL = all zero (symmetric)
 #pragma unroll
       for (int i = 0; i < 4; ++i) p[j + i] = make(s4[i], z4[i]);
     }

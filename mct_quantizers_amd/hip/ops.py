@@ -150,7 +150,8 @@ def _check_axis(x, n_params: int, axis: int):
         raise RuntimeError("dimensions of scale and zero-point are not consistent with input tensor")
 
 
-def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
+def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero_zps: bool = False):
+    """``zero_zps``: the caller knows every zero point is 0 (symmetric quantizers); the table is not read."""
     dt = _DTYPES.get(x.dtype)
     if dt is None:
         _dtype_code(x, "fq_per_channel")
@@ -170,7 +171,7 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int)
     idx = x.get_device()
     with (_NOOP if idx == _current_device() else _on_device(idx)):
         rc = lib.mctq_fq_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
-                                     zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
+                                     None if zero_zps else zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
     if rc:
         native.check(rc, "mctq_fq_per_channel")
     return y
@@ -361,10 +362,10 @@ def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
     return torch.ops.mctq_amd.fq_per_tensor(x, scale, zero_point, qmin, qmax)
 
 
-def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int):
+def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero_zps: bool = False):
     if _is_real(x):
         if x.is_cuda:
-            return _hip_fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
+            return _hip_fq_per_channel(x, scales, zero_points, axis, qmin, qmax, zero_zps)
         if x.device.type == "cpu":
             _cpu_route_allowed()
             return _cpu_fq_per_channel(x, scales, zero_points, axis, qmin, qmax)

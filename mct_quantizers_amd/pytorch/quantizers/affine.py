@@ -144,6 +144,7 @@ class _WeightsAffineMixin:
         self._flat_src = (self.scales, self.zero_points)
         self._scales_flat = self.scales.flatten().contiguous()
         self._zps_flat = self.zero_points.flatten().contiguous()
+        self._zps_all_zero = not bool(torch.any(self._zps_flat != 0).item())     # symmetric: skip the table
 
     def quantize_to_codes(self, inputs: torch.Tensor):
         """Extension (not in the reference): the integer clamp indices as int8/uint8 plus the parameters that
@@ -164,7 +165,7 @@ class _WeightsAffineMixin:
             if src is None or src[0] is not self.scales or src[1] is not self.zero_points:
                 self._flat_params()
             return ops.fq_per_channel(inputs, self._scales_flat, self._zps_flat, self.channel_axis,
-                                      self.min_quantized_domain, self.max_quantized_domain)
+                                      self.min_quantized_domain, self.max_quantized_domain, self._zps_all_zero)
         return ops.fq_per_tensor(inputs, self._scale0, self._zp0,
                                  self.min_quantized_domain, self.max_quantized_domain)
 
