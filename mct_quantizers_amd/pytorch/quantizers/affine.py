@@ -47,6 +47,20 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
     def disable_reuse_quantizer(self):
         self.enable_reuse = False
 
+    def enable_versioned_reuse(self):
+        """Extension (not in the reference): keep the quantized tensor until the input changes.
+
+        ``enable_reuse_quantizer`` returns the first result forever; this variant re-quantizes whenever the
+        input is a different tensor or has been modified in place (torch bumps ``Tensor._version`` on every
+        in-place write, e.g. an optimizer step or ``copy_``), so inference loops stop paying for the
+        re-quantization of unchanged weights without any risk of serving stale ones."""
+        self.__dict__["_versioned_reuse"] = True
+        self.__dict__["_versioned_key"] = None
+
+    def disable_versioned_reuse(self):
+        self.__dict__["_versioned_reuse"] = False
+        self.__dict__["_versioned_key"] = None
+
     def __call__(self, inputs: torch.Tensor):
         raise NotImplementedError(f'{self.__class__.__name__} did not implement __call__')  # pragma: no cover
 
@@ -64,13 +78,24 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
         return t.to(get_working_device()) if isinstance(t, torch.Tensor) else t
 
     # -- reuse cache helpers shared by the weights quantizers (weights_symmetric...py:128-129,153-155)
-    def _cached(self):
-        return self.enable_reuse and not self.quantizer_first_run
+    def _cached(self, inputs=None):
+        if self.enable_reuse and not self.quantizer_first_run:
+            return True
+        if inputs is not None and self.__dict__.get("_versioned_reuse") and isinstance(inputs, torch.Tensor):
+            key = (inputs.data_ptr(), inputs._version, tuple(inputs.shape), inputs.stride(), inputs.dtype,
+                   inputs.device)
+            hit = key == self.__dict__.get("_versioned_key") and self.resue_outputs is not None
+            self.__dict__["_versioned_pending"] = key
+            return hit
+        return False
 
     def _remember(self, outputs):
         if self.enable_reuse and self.quantizer_first_run:
             self.resue_outputs = outputs
             self.quantizer_first_run = False
+        elif self.__dict__.get("_versioned_reuse"):
+            self.resue_outputs = outputs
+            self.__dict__["_versioned_key"] = self.__dict__.get("_versioned_pending")
         return outputs
 
 
@@ -196,7 +221,7 @@ class WeightsSymmetricInferableQuantizer(_WeightsAffineMixin, BaseSymmetricInfer
         self.zero_points = torch.zeros(len(threshold), dtype=torch.int32).to(dev)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
-        if self._cached():
+        if self._cached(inputs):
             return self.resue_outputs
         return self._remember(self._quantize_weights(inputs))
 
@@ -250,7 +275,7 @@ class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferable
         self.zero_points = zero_points.to(dev)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
-        if self._cached():
+        if self._cached(inputs):
             return self.resue_outputs
         return self._remember(self._quantize_weights(inputs))
 

@@ -98,7 +98,7 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
                                                    dev)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
-        if self._cached():
+        if self._cached(inputs):
             return self.resue_outputs
         inputs.requires_grad = False
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, True)

@@ -357,6 +357,37 @@ def test_abi_table_lut_per_channel_vs_oracle(lib, lut_name, outer, C, inner):
     assert bits_equal(y.cpu().numpy(), want), first_mismatch(y.cpu().numpy(), want, x_np)
 
 
+@pytest.mark.parametrize("dt", ["float16", "bfloat16"])
+@pytest.mark.parametrize("outer,C,inner", [(50, 3, 1), (4, 6, 5), (2, 8, 104), (2, 6, 2048), (3, 5, 1032), (1, 16, 11008),
+                                           (41, 64, 1), (3, 4096, 1), (1, 3000, 3)])
+def test_abi_table_lut_half_inputs_vs_oracle(lib, dt, outer, C, inner):
+    """16-bit inputs to the LUT kernels: float32 arithmetic on the widened value, float32 output (the
+    reference's weights-LUT chain promotes at the first division)."""
+    from oracle import mctq_oracle as O
+    code = {"float16": 1, "bfloat16": 2}[dt]
+    rng = np.random.default_rng(C * 13 + inner)
+    lut = LUTS["l16"]
+    thr = rng.uniform(0.05, 4.0, size=C).astype(np.float32)
+    shape = (outer, C, inner)
+    xh = _dev(_lut_inputs(rng, shape, thr.reshape(1, C, 1))).to(getattr(torch, dt))
+    x_np = xh.float().cpu().numpy()
+    t_d, tab = _dev(thr), _table(lut)
+    y = torch.empty(shape, dtype=torch.float32, device="cuda")
+    rc = lib.mctq_lutt_per_channel(xh.data_ptr(), y.data_ptr(), outer, C, inner, code, t_d.data_ptr(), 1e-8,
+                                   tab.data_ptr(), tab.shape[0] - 1, 128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want = O.lut_quantize(x_np, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=1)
+    assert finite_equal(y.cpu().numpy(), want, x_np), first_mismatch(y.cpu().numpy(), want, x_np)
+    # per-tensor, with the per-op half roundings of an activation tensor (step_round)
+    y1 = torch.empty(xh.numel(), dtype=torch.float32, device="cuda")
+    thr_div = float(torch.tensor([2.0 + 1e-8], dtype=torch.float64).to(getattr(torch, dt)).item())
+    rc = lib.mctq_lutt_per_tensor(xh.data_ptr(), y1.data_ptr(), xh.numel(), code, code, thr_div, 2.0, tab.data_ptr(),
+                                  tab.shape[0] - 1, 128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    want1 = O.lut_quantize(x_np.reshape(-1), lut, 2.0, True, 8, 1e-8, step_dtype=dt)
+    assert finite_equal(y1.cpu().numpy(), want1, x_np.reshape(-1)), first_mismatch(y1.cpu().numpy(), want1, x_np.reshape(-1))
+
+
 def test_fast_division_is_exact(lib):
     """Every float32 numerator x 48 divisors: the shared-divisor division equals IEEE '/' bit for bit."""
     rng = np.random.default_rng(99)

@@ -280,3 +280,22 @@ def test_torch_compile_traces_through_the_custom_ops():
     want = m(x)
     torch._dynamo.reset()
     assert torch.equal(torch.compile(m, backend="aot_eager")(x), want)
+
+
+def test_versioned_reuse_requantizes_only_when_the_weight_changes():
+    for q in (Q.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0], True, 0),
+              Q.WeightsUniformInferableQuantizer(8, [-1.0], [1.0], False),
+              Q.WeightsLUTSymmetricInferableQuantizer(2, [-25.0, 25.0], [1.0], False)):
+        w = torch.nn.Parameter(torch.randn(2, 16))
+        q.enable_versioned_reuse()
+        a = q(w)
+        assert q(w) is a                                   # unchanged: the very same tensor
+        with torch.no_grad():
+            w.neg_()                                       # in-place write bumps the version
+        b = q(w)
+        assert b is not a and not torch.equal(a, b)
+        assert q(w) is b
+        other = torch.nn.Parameter(w.detach().clone())
+        assert q(other) is not b                           # a different tensor is never served from the cache
+        q.disable_versioned_reuse()
+        assert q(other) is not q(other)
