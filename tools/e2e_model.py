@@ -40,5 +40,12 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
     x = torch.randn(batch, d, device="cuda")
     ours, y1 = timeit(build(layers, d, False), x)
     aten, y2 = timeit(build(layers, d, True), x)
+    m3 = build(layers, d, False)
+    for mod in m3:
+        if isinstance(mod, mq.PytorchQuantizationWrapper):
+            for q in mod.weights_quantizers.values():
+                q.enable_versioned_reuse()
+    reuse, y3 = timeit(m3, x)
     print(f"{layers} x Linear({d},{d}) batch {batch}: this package {ours:7.3f} ms/forward, ATen fake-quant ops {aten:7.3f} ms/forward "
-          f"(x{aten/ours:.2f}), outputs equal={torch.equal(y1, y2)}", flush=True)
+          f"(x{aten/ours:.2f}), with versioned weight reuse {reuse:7.3f} ms; outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3)}",
+          flush=True)
