@@ -150,3 +150,51 @@ def build_lut_table(lut_values, mult: float, clip_min: float, clip_max: float):
     if rc != 0:
         return None
     return table
+
+
+# ------------------------------------------------------------------------------------------
+# optional roctx ranges (MCTQ_ROCTX=1): one named range per launch, visible in rocprofv3 --marker-trace
+# ------------------------------------------------------------------------------------------
+TRACE = os.environ.get("MCTQ_ROCTX", "0") not in ("", "0")
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx, TRACE
+    if _roctx is None:
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                lib_ = ctypes.CDLL(name)
+                lib_.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                lib_.roctxRangePushA.restype = ctypes.c_int
+                lib_.roctxRangePop.restype = ctypes.c_int
+                _roctx = lib_
+                break
+            except (OSError, AttributeError):
+                continue
+        if _roctx is None:
+            TRACE = False
+            _roctx = False
+    return _roctx
+
+
+class trace_range:
+    """``with trace_range("mctq.fq_per_channel")`` -- a roctx range when MCTQ_ROCTX=1, free otherwise."""
+    __slots__ = ("name", "on")
+
+    def __init__(self, name: str):
+        self.name = name
+        self.on = False
+
+    def __enter__(self):
+        if TRACE:
+            lib_ = _roctx_lib()
+            if lib_:
+                lib_.roctxRangePushA(self.name.encode())
+                self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _roctx.roctxRangePop()
+        return False

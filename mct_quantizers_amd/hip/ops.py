@@ -88,6 +88,14 @@ class _on_device:
         return False
 
 
+def _launch(fn, *args):
+    """Call a C-ABI launch function; with MCTQ_ROCTX=1 the launch is wrapped in a roctx range named after it."""
+    if native.TRACE:
+        with native.trace_range(fn.__name__):
+            return fn(*args)
+    return fn(*args)
+
+
 class _noop:
     __slots__ = ()
 
@@ -132,11 +140,11 @@ def _hip_fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
     y = torch.empty_like(x)
     idx = x.get_device()
     if idx == _current_device():
-        rc = lib.mctq_fq_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
+        rc = _launch(lib.mctq_fq_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
                                     _raw_stream(idx))
     else:
         with _on_device(idx):
-            rc = lib.mctq_fq_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
+            rc = _launch(lib.mctq_fq_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, scale, zero_point, qmin, qmax,
                                         _raw_stream(idx))
     if rc:
         native.check(rc, "mctq_fq_per_tensor")
@@ -170,7 +178,7 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int,
         zero_points = zero_points.contiguous()
     idx = x.get_device()
     with (_NOOP if idx == _current_device() else _on_device(idx)):
-        rc = lib.mctq_fq_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
+        rc = _launch(lib.mctq_fq_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
                                      None if zero_zps else zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
     if rc:
         native.check(rc, "mctq_fq_per_channel")
@@ -186,7 +194,7 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
     y = torch.empty_like(x, dtype=torch.float32)
     with _maybe_on_device(x):
         if table is not None:
-            rc = lib.mctq_lutt_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
+            rc = _launch(lib.mctq_lutt_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
                                           table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
         else:
             lut = lut.contiguous()
@@ -195,7 +203,7 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
                     raise NotImplementedError("half-precision activation LUT needs a decision table "
                                               "(integer codebook, lut_values_bitwidth <= 10)")
                 x, dt = x.float(), native.DT_F32
-            rc = lib.mctq_lut_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
+            rc = _launch(lib.mctq_lut_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
                                          lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
         native.check(rc, "mctq_lut_per_tensor")
@@ -213,13 +221,13 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
     thresholds = thresholds.contiguous()
     with _maybe_on_device(x):
         if table is not None:
-            rc = lib.mctq_lutt_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
+            rc = _launch(lib.mctq_lutt_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                            eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
         else:
             lut = lut.contiguous()
             if dt != native.DT_F32:
                 x, dt = x.float(), native.DT_F32
-            rc = lib.mctq_lut_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
+            rc = _launch(lib.mctq_lut_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                           eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
         native.check(rc, "mctq_lut_per_channel")
@@ -259,12 +267,12 @@ def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float =
     idx = x.get_device()
     with (_NOOP if idx == _current_device() else _on_device(idx)):
         if axis is None:
-            rc = lib.mctq_fq_codes_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), dt, code, scale0, zp0, qmin, qmax,
+            rc = _launch(lib.mctq_fq_codes_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, code, scale0, zp0, qmin, qmax,
                                               _raw_stream(idx))
         else:
             _check_axis(x, scales.numel(), axis)
             outer, c, inner = _channel_view(x, axis)
-            rc = lib.mctq_fq_codes_per_channel(x.data_ptr(), y.data_ptr(), outer, c, inner, dt, code,
+            rc = _launch(lib.mctq_fq_codes_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, code,
                                                scales.data_ptr(), zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
     if rc:
         native.check(rc, "mctq_fq_codes")
