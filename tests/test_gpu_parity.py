@@ -173,15 +173,18 @@ def test_abi_per_channel_vs_oracle(lib, outer, C, inner, offset):
     shape = (outer, C, inner)
     x_np = _tie_heavy(rng, shape, scales.reshape(1, C, 1), zps.reshape(1, C, 1).astype(np.float32), qmin, qmax)
     n = x_np.size
-    xb = torch.empty(n + offset, dtype=torch.float32, device="cuda")
-    xb[offset:] = _dev(x_np.reshape(-1))
+    pad = 64                                                     # sentinels after the end, too
+    xb = torch.zeros(n + offset + pad, dtype=torch.float32, device="cuda")
+    xb[offset:offset + n] = _dev(x_np.reshape(-1))
     yb = torch.full_like(xb, 777.0)
     s_d, z_d = _dev(scales), _dev(zps)
     rc = lib.mctq_fq_per_channel_f32(xb[offset:].data_ptr(), yb[offset:].data_ptr(), outer, C, inner,
                                      s_d.data_ptr(), z_d.data_ptr(), qmin, qmax, _stream())
     assert rc == 0, lib.mctq_last_error()
     want, q_want = O.fake_quant_affine(x_np, scales, zps, qmin, qmax, axis=1, return_index=True)
-    got = yb.cpu().numpy()
+    got_all = yb.cpu().numpy()
+    assert np.all(got_all[:offset] == 777.0) and np.all(got_all[offset + n:] == 777.0)   # nothing outside [0, n)
+    got = got_all[:offset + n]
     assert bits_equal(got[offset:].reshape(shape), want), first_mismatch(got[offset:], want, x_np)
     if offset:
         assert np.all(got[:offset] == 777.0)
