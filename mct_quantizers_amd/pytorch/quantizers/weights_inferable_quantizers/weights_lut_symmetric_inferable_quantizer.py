@@ -1,0 +1,2 @@
+"""Import-path shim: the reference keeps WeightsLUTSymmetricInferableQuantizer here; the implementation is in mct_quantizers_amd.pytorch.quantizers.lut."""
+from mct_quantizers_amd.pytorch.quantizers.lut import WeightsLUTSymmetricInferableQuantizer  # noqa: F401

@@ -1,0 +1,2 @@
+"""Import-path shim: the reference keeps WeightsPOTInferableQuantizer here; the implementation is in mct_quantizers_amd.pytorch.quantizers.affine."""
+from mct_quantizers_amd.pytorch.quantizers.affine import WeightsPOTInferableQuantizer  # noqa: F401

@@ -299,3 +299,29 @@ def test_versioned_reuse_requantizes_only_when_the_weight_changes():
         assert q(other) is not b                           # a different tensor is never served from the cache
         q.disable_versioned_reuse()
         assert q(other) is not q(other)
+
+
+def test_reference_import_paths_exist():
+    """s/mct_quantizers/mct_quantizers_amd/ in an import statement keeps working for the hot-path modules."""
+    import importlib
+    paths = {
+        "common.base_inferable_quantizer": ["BaseInferableQuantizer", "QuantizationTarget", "mark_quantizer", "QuantizerID"],
+        "common.quant_info": ["QuantizationMethod"],
+        "common.get_quantizers": ["get_inferable_quantizer_class"],
+        "common.get_all_subclasses": ["get_all_subclasses"],
+        "common.constants": ["EPS", "LUT_VALUES_BITWIDTH", "TRAINING", "LAYER"],
+        "logger": ["Logger"],
+        "pytorch.quantizer_utils": ["get_working_device", "to_torch_tensor", "fix_range_to_include_zero", "lut_quantizer"],
+        "pytorch.quantize_wrapper": ["PytorchQuantizationWrapper"],
+        "pytorch.activation_quantization_holder": ["PytorchActivationQuantizationHolder"],
+        "pytorch.fln_activation_quantization_holder": ["PytorchFLNActivationQuantizationHolder"],
+        "pytorch.preserving_activation_quantization_holder": ["PytorchPreservingActivationQuantizationHolder"],
+        "pytorch.load_model": ["pytorch_load_quantized_model"],
+        "pytorch.quantizers.base_pytorch_inferable_quantizer": ["BasePyTorchInferableQuantizer"],
+        "pytorch.quantizers.weights_inferable_quantizers.weights_lut_pot_inferable_quantizer": ["WeightsLUTPOTInferableQuantizer"],
+        "pytorch.quantizers.activation_inferable_quantizers.activation_uniform_inferable_quantizer": ["ActivationUniformInferableQuantizer"],
+    }
+    for rel, names in paths.items():
+        mod = importlib.import_module("mct_quantizers_amd." + rel)
+        for n in names:
+            assert hasattr(mod, n), (rel, n)
