@@ -899,7 +899,10 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
     });
     return check_launch("flat loop launch");
   } else {
-    MCTQ_DISPATCH_U_NT(g_unroll, g_nt, {
+    // small tensors: fewer lane-vectors per lane so that the grid still covers the chip (>= 2 blocks per CU)
+    int u_sel = g_unroll;
+    while (u_sel > 1 && nv < (int64_t)kThreads * u_sel * 2 * cu_count()) u_sel >>= 1;
+    MCTQ_DISPATCH_U_NT(u_sel, g_nt, {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       if (blocks == 0) blocks = 1;
       if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
