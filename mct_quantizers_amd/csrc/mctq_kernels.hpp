@@ -1,6 +1,6 @@
 // mctq_kernels.hpp -- gfx950 (MI355X / CDNA4) kernels and launch helpers of libmctq_hip.so.
-// Included by the translation units that hold the C ABI (mctq_affine.hip, mctq_lut_scan.hip,
-// mctq_lut_table.hip, mctq_misc.hip); they are compiled in parallel and linked into one library.
+// Included by the translation units that hold the C ABI (mctq_affine.hip, mctq_codes.hip,
+// mctq_lut_scan.hip, mctq_lut_table.hip, mctq_misc.hip); they are compiled in parallel and linked into one library.
 //
 // Hot path of sony/mct_quantizers' PyTorch inferable quantizers, written for CDNA4:
 // one fused load -> scale -> round-half-even -> clamp -> dequant -> store pass (8 algorithmic
@@ -21,8 +21,13 @@
 //                 block = one contiguous tile; the parameters of the rows that tile touches are
 //                 staged in LDS once per block and looked up per element without any per-element
 //                 division.
-//   flat_loop /   "heavy" ops (LUT): persistent blocks stride over tiles, prefetch the next tile
-//   rows_persist  while computing the current one, stage the codebook table in LDS once per block.
+//   flat_loop /   optional variants for the LUT ops (tuning key heavy_persistent): persistent blocks
+//   rows_persist  stride over tiles with two tiles of prefetch; measured 2-5 % slower than one tile
+//                 per block, which is the default for every op.
+// The LUT ops stage their codebook table in LDS after the block's data loads are in flight.
+//
+// MCTQ_ABLATE_* / MCTQ_AFFINE_HEAVY are timing-experiment switches (tools/build_ablate.sh); they are
+// never defined in the shipped build.
 //
 // Storage types: float32, float16, bfloat16 in; the affine ops write the input type (as ATen
 // does), the LUT ops always write float32 (the reference's op chain promotes).  All arithmetic is
