@@ -600,6 +600,44 @@ def test_side_stream_and_graph_capture(lib):
     assert torch.equal(static_y, q(x2))
 
 
+def test_graph_capture_of_a_wrapped_layer_stack(lib):
+    """A small quantized model (per-channel affine + LUT weights, activation holders) captured into one
+    hipGraph replays to the same outputs as eager execution."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(3)
+    lin1, lin2 = torch.nn.Linear(256, 512).cuda(), torch.nn.Linear(512, 64).cuda()
+    thr1 = [float(v) for v in lin1.weight.detach().abs().amax(dim=1)]
+    thr2 = [float(v) for v in lin2.weight.detach().abs().amax(dim=1)]
+    lut = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+    model = torch.nn.Sequential(
+        mq.PytorchQuantizationWrapper(lin1, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr1, True, 0)}),
+        mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0])),
+        mq.PytorchQuantizationWrapper(lin2, {"weight": Q.WeightsLUTSymmetricInferableQuantizer(4, lut, thr2, True, 0, 2)}),
+        mq.PytorchActivationQuantizationHolder(Q.ActivationLutPOTInferableQuantizer(4, lut, [4.0], True)))
+    x = torch.randn(32, 256, device="cuda")
+    with torch.no_grad():
+        want = model(x)
+        static_x = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(static_x)                                   # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_y = model(static_x)
+        x2 = torch.randn_like(x)
+        static_x.copy_(x2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_y, model(x2))
+        static_x.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_y, want)
+
+
 def test_weights_quantizer_side_effects_and_reuse(lib):
     import mct_quantizers_amd as mq
     q = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0, 0.5], True, 0)
