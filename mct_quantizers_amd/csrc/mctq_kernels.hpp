@@ -80,16 +80,18 @@ struct IO {
   typedef typename VecT<TI, N>::type VI;
   typedef typename VecT<TO, N>::type VO;
 
-  template <bool NT>
+  // NT: 0 = cached loads and stores, 1 = non-temporal loads and stores (streaming: the default),
+  //     2 = non-temporal loads, cached stores (the output is consumed right away and fits the Infinity Cache)
+  template <int NT>
   __device__ __forceinline__ static VI load(const TI* p) {
     const VI* q = reinterpret_cast<const VI*>(p);
-    if (NT) return __builtin_nontemporal_load(q);
+    if (NT != 0) return __builtin_nontemporal_load(q);
     return *q;
   }
-  template <bool NT>
+  template <int NT>
   __device__ __forceinline__ static void store(TO* p, VO v) {
     VO* q = reinterpret_cast<VO*>(p);
-    if (NT) __builtin_nontemporal_store(v, q);
+    if (NT == 1) __builtin_nontemporal_store(v, q);
     else *q = v;
   }
   __device__ __forceinline__ static void unpack(VI v, float* f) {
@@ -456,7 +458,7 @@ __device__ __forceinline__ void run_vectors(const Op& op, const typename IO<TI, 
 }
 
 // Tile helpers shared by every launch shape: full tiles (wave-uniform test) run straight-line code.
-template <class TI, class TO, int U, bool NT>
+template <class TI, class TO, int U, int NT>
 __device__ __forceinline__ void load_tile(typename IO<TI, TO>::VI (&v)[U], const TI* __restrict__ x, int64_t first,
                                           int64_t limit, bool full /* wave-uniform */) {
   typedef IO<TI, TO> io;
@@ -470,7 +472,7 @@ __device__ __forceinline__ void load_tile(typename IO<TI, TO>::VI (&v)[U], const
   }
 }
 
-template <bool FAST, class Op, class TI, class TO, int U, bool NT>
+template <bool FAST, class Op, class TI, class TO, int U, int NT>
 __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Param& p, const typename Op::Book& book,
                                             const typename IO<TI, TO>::VI (&w)[U], TO* __restrict__ y, int64_t first,
                                             int64_t limit, bool full) {
@@ -505,7 +507,7 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
 // One tile whose parameters are wave-uniform, FULL known at compile time so the hot (full) path and
 // the guarded (row-end) path never share code: the compiler otherwise merges their tails and ends up
 // serialising the loads of the hot path.
-template <bool FULL, class Op, class TI, class TO, int U, bool NT, class GetParam>
+template <bool FULL, class Op, class TI, class TO, int U, int NT, class GetParam>
 __device__ __forceinline__ void one_tile(const Op& op, float* smem, const TI* __restrict__ xs, TO* __restrict__ ys,
                                          int64_t first, int64_t limit, GetParam get_param) {
   typedef IO<TI, TO> io;
@@ -526,7 +528,7 @@ __device__ __forceinline__ void one_tile(const Op& op, float* smem, const TI* __
 // are 16 B (8 B for a 16-bit input widened to float32), consecutive lanes consecutive addresses,
 // U independent loads in flight per lane.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, bool NT>
+template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void flat_kernel(Op op, typename Op::Param p,
                                                         const TI* __restrict__ xs, TO* __restrict__ ys, int64_t n) {
   typedef IO<TI, TO> io;
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(kThreads) void flat_scalar_kernel(Op op, typename O
 // row's channel index is wave-uniform, so fetch() compiles to scalar loads and the parameters sit
 // in SGPRs for the whole block.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, bool NT>
+template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
                                                         uint32_t tiles_per_row, uint32_t innerv, uint32_t channels) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restr
 // tile's loads before it computes the current one, and pays the table / codebook staging once.
 // Full tiles run straight-line code so the LDS table reads of a tile are issued back to back.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, bool NT>
+template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void rows_persist_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
                                                                 uint32_t tiles_per_row, uint32_t total_tiles,
                                                                 uint32_t innerv, uint32_t channels) {
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(kThreads) void rows_persist_kernel(Op op, const TI*
   }
 }
 
-template <class Op, class TI, class TO, int U, bool NT>
+template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op::Param p, const TI* __restrict__ xs,
                                                              TO* __restrict__ ys, int64_t n) {
   typedef IO<TI, TO> io;
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op:
 // staging can amortise them; a lane's N consecutive elements are N consecutive channels and their
 // parameters are fetched with 16-byte loads straight from the (L1/L2-resident) tables.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, bool NT, typename IdxT>
+template <class Op, class TI, class TO, int U, int NT, typename IdxT>
 __global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT nv,
                                                             uint32_t channels) {
   typedef IO<TI, TO> io;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __r
 // (channel-last layouts: inner == 1, C small) the whole table is staged instead and indexed
 // modulo C.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, bool VEC, bool NT, typename IdxT>
+template <class Op, class TI, class TO, int U, bool VEC, int NT, typename IdxT>
 __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT n,
                                                           uint32_t inner, uint32_t channels,
                                                           uint32_t stride /* LDS entries per param word */) {
@@ -790,7 +792,12 @@ __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __res
 // ------------------------------------------------------------------------------------------
 // shared state and helpers, defined in mctq_misc.hip
 extern thread_local char g_err[256];
-extern int g_nt;             // non-temporal loads/stores: +7% on the cold 4096x4096 stream (profiles/)
+extern int g_nt;             // 0 cached, 1 non-temporal (+7% on the cold 4096x4096 stream), 2 nt loads + cached stores
+extern int64_t g_cached_store_max_bytes;   // with g_nt == 1: outputs up to this size use mode 2 (0 = never)
+inline int nt_mode(int64_t out_bytes) {
+  if (g_nt != 1) return g_nt;
+  return (g_cached_store_max_bytes > 0 && out_bytes <= g_cached_store_max_bytes) ? 2 : 1;
+}
 extern int g_unroll;
 extern int g_heavy_unroll;   // 0 = automatic
 extern int g_heavy_persistent;
@@ -803,60 +810,52 @@ static bool vec_aligned(const void* x, const void* y) {
   return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % (io::N * sizeof(TO))) == 0;
 }
 
-// (U, NT) variants are instantiated for float32 -> float32 only (that is where tuning is done);
-// the 16-bit storage types use U = 4 with the library's non-temporal default.
+// Launch-variant dispatch.  NT_ is the runtime cache-policy mode (0, 1, 2: see IO::load/store).  Unroll
+// variants and mode 0 are instantiated for float32 -> float32 only (that is where tuning is done); the
+// other storage types use U = 4.  Fallback ops are built in one variant.
+#define MCTQ_WITH_MODE(MODE_, ALLOW0_, ...)                                                 \
+  do {                                                                                      \
+    const int mode__ = (MODE_);                                                             \
+    if (mode__ == 2) { constexpr int NT = 2; __VA_ARGS__; }                                 \
+    else if ((ALLOW0_) && mode__ == 0) { constexpr int NT = (ALLOW0_) ? 0 : 1; __VA_ARGS__; } \
+    else { constexpr int NT = 1; __VA_ARGS__; }                                             \
+  } while (0)
+
 #define MCTQ_DISPATCH_U_NT(U_, NT_, ...)                                                    \
   do {                                                                                      \
     if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {      \
-      if (NT_) {                                                                            \
-        switch (U_) {                                                                       \
-          case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;           \
-          case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;           \
-          case 8: { constexpr int U = 8; constexpr bool NT = true; __VA_ARGS__; } break;           \
-          default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;          \
-        }                                                                                   \
-      } else {                                                                              \
-        switch (U_) {                                                                       \
-          case 1: { constexpr int U = 1; constexpr bool NT = false; __VA_ARGS__; } break;          \
-          case 2: { constexpr int U = 2; constexpr bool NT = false; __VA_ARGS__; } break;          \
-          case 8: { constexpr int U = 8; constexpr bool NT = false; __VA_ARGS__; } break;          \
-          default: { constexpr int U = 4; constexpr bool NT = false; __VA_ARGS__; } break;         \
-        }                                                                                   \
+      switch (U_) {                                                                         \
+        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
+        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
+        case 8: { constexpr int U = 8; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;    \
       }                                                                                     \
     } else {                                                                                \
-      constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__;                                  \
+      constexpr int U = 4; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__);                         \
     }                                                                                       \
   } while (0)
 
 #define MCTQ_DISPATCH_HEAVY(U_, NT_, ...)                                                   \
   do {                                                                                      \
     if constexpr (Op::kFallback) {                                                          \
-      constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__;                           \
+      constexpr int U = 2; constexpr int NT = 1; __VA_ARGS__;                               \
     } else if constexpr (std::is_same<TI, float>::value) {                                  \
-      if (NT_) {                                                                            \
-        switch (U_) {                                                                       \
-          case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;           \
-          case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;           \
-          case 8: { constexpr int U = 8; constexpr bool NT = true; __VA_ARGS__; } break;           \
-          default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;          \
-        }                                                                                   \
-      } else {                                                                              \
-        switch (U_) {                                                                       \
-          case 1: { constexpr int U = 1; constexpr bool NT = false; __VA_ARGS__; } break;          \
-          case 2: { constexpr int U = 2; constexpr bool NT = false; __VA_ARGS__; } break;          \
-          default: { constexpr int U = 4; constexpr bool NT = false; __VA_ARGS__; } break;         \
-        }                                                                                   \
+      switch (U_) {                                                                         \
+        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
+        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
+        case 8: { constexpr int U = 8; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;    \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;    \
       }                                                                                     \
     } else {                                                                                \
       switch (U_) {                                                                         \
-        case 1: { constexpr int U = 1; constexpr bool NT = true; __VA_ARGS__; } break;             \
-        case 2: { constexpr int U = 2; constexpr bool NT = true; __VA_ARGS__; } break;             \
-        default: { constexpr int U = 4; constexpr bool NT = true; __VA_ARGS__; } break;            \
+        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;    \
+        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;    \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;   \
       }                                                                                     \
     }                                                                                       \
   } while (0)
 
-template <class Op, class TI, class TO, int U, bool NT>
+template <class Op, class TI, class TO, int U, int NT>
 static int persist_blocks_per_cu(size_t book_bytes) {
   static int per_cu = 0;
   if (per_cu == 0) {
@@ -885,7 +884,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
   const int64_t nv = n / io::N;
   if constexpr (Op::kHeavy) {
     if (Op::kFallback || !g_heavy_persistent) {
-      MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, g_nt, {
+      MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, nt_mode(n * (int64_t)sizeof(TO)), {
         int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
         if (blocks == 0) blocks = 1;
         if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
@@ -894,7 +893,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
       });
       return check_launch("flat launch");
     }
-    if constexpr (!Op::kFallback) MCTQ_DISPATCH_HEAVY(2, g_nt, {
+    if constexpr (!Op::kFallback) MCTQ_DISPATCH_HEAVY(2, nt_mode(n * (int64_t)sizeof(TO)), {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       const int64_t cap = (int64_t)cu_count() * 16;
       if (blocks > cap) blocks = cap;
@@ -907,7 +906,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
     // small tensors: fewer lane-vectors per lane so that the grid still covers the chip (>= 2 blocks per CU)
     int u_sel = g_unroll;
     while (u_sel > 1 && nv < (int64_t)kThreads * u_sel * 2 * cu_count()) u_sel >>= 1;
-    MCTQ_DISPATCH_U_NT(u_sel, g_nt, {
+    MCTQ_DISPATCH_U_NT(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       if (blocks == 0) blocks = 1;
       if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
@@ -947,14 +946,14 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       const int64_t tiles = (innerv + per - 1) / per;
       const int64_t total = rows * tiles;
       if ((Op::kFallback || !g_heavy_persistent) && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
-        MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
+        MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
         });
         return check_launch("rows launch");
       }
       if constexpr (!Op::kFallback) if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
-        MCTQ_DISPATCH_HEAVY(u_sel, g_nt, {
+        MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           int64_t grid = (int64_t)cu_count() * persist_blocks_per_cu<Op, TI, TO, U, NT>(book_bytes);
           if (grid > total) grid = total;
           hipLaunchKernelGGL((rows_persist_kernel<Op, TI, TO, U, NT>), dim3((unsigned)grid), dim3(kThreads), book_bytes,
@@ -976,7 +975,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       const int64_t per = (int64_t)kThreads * best_u;
       const int64_t tiles = (innerv + per - 1) / per;
       if (rows * tiles <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
-        MCTQ_DISPATCH_U_NT(best_u, g_nt, {
+        MCTQ_DISPATCH_U_NT(best_u, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)(rows * tiles)), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
         });
@@ -991,12 +990,14 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
     const int64_t nv = n / io::N;
     const int64_t blocks = (nv + kThreads * LU - 1) / (kThreads * LU);
     if (blocks <= 0x7fffffffLL) {
-      if (nv <= 0x7fffffffLL / (int64_t)io::N)
-        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, true, uint32_t>), dim3((unsigned)blocks), dim3(kThreads),
-                           book_bytes, st, op, x, y, (uint32_t)nv, (uint32_t)channels);
-      else
-        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, true, uint64_t>), dim3((unsigned)blocks), dim3(kThreads),
-                           book_bytes, st, op, x, y, (uint64_t)nv, (uint32_t)channels);
+      MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
+        if (nv <= 0x7fffffffLL / (int64_t)io::N)
+          hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT, uint32_t>), dim3((unsigned)blocks), dim3(kThreads),
+                             book_bytes, st, op, x, y, (uint32_t)nv, (uint32_t)channels);
+        else
+          hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT, uint64_t>), dim3((unsigned)blocks), dim3(kThreads),
+                             book_bytes, st, op, x, y, (uint64_t)nv, (uint32_t)channels);
+      });
       return check_launch("lastaxis launch");
     }
   }
@@ -1022,7 +1023,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
   const bool idx32 = n <= (int64_t)0xffffffffLL - (int64_t)tile;
 #define MCTQ_WINDOW(WU_, VEC_, IDX_)                                                                               \
-  hipLaunchKernelGGL((window_kernel<Op, TI, TO, WU_, VEC_, true, IDX_>), dim3((unsigned)blocks), dim3(kThreads), lds, st, \
+  hipLaunchKernelGGL((window_kernel<Op, TI, TO, WU_, VEC_, NT, IDX_>), dim3((unsigned)blocks), dim3(kThreads), lds, st, \
                      op, x, y, (IDX_)n, (uint32_t)inner, (uint32_t)channels, stride)
 #define MCTQ_WINDOW_WU(VEC_, IDX_)                                    \
   do {                                                                \
@@ -1030,14 +1031,16 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
     else if (wu == 2) MCTQ_WINDOW(2, VEC_, IDX_);                     \
     else MCTQ_WINDOW(1, VEC_, IDX_);                                  \
   } while (0)
-  if (!idx32) {                                        // > 4 Gi elements: only the common shape is built
-    if (!vec_ok || wu != 4) return fail_arg("tensors above 2^32 elements need vector alignment and a small window");
-    MCTQ_WINDOW(4, true, uint64_t);
-  } else if (vec_ok) {
-    MCTQ_WINDOW_WU(true, uint32_t);
-  } else {
-    MCTQ_WINDOW_WU(false, uint32_t);
-  }
+  MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
+    if (!idx32) {                                      // > 4 Gi elements: only the common shape is built
+      if (!vec_ok || wu != 4) return fail_arg("tensors above 2^32 elements need vector alignment and a small window");
+      MCTQ_WINDOW(4, true, uint64_t);
+    } else if (vec_ok) {
+      MCTQ_WINDOW_WU(true, uint32_t);
+    } else {
+      MCTQ_WINDOW_WU(false, uint32_t);
+    }
+  });
 #undef MCTQ_WINDOW_WU
 #undef MCTQ_WINDOW
   return check_launch("window launch");

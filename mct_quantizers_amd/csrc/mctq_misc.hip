@@ -5,6 +5,7 @@ namespace mctq {
 
 thread_local char g_err[256] = "";
 int g_nt = 1;
+int64_t g_cached_store_max_bytes = 0;
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)
@@ -70,8 +71,13 @@ const char* mctq_last_error(void) { return g_err; }
 int mctq_set_tuning(const char* key, int32_t value) {
   if (!key) return fail_arg("key is NULL");
   if (!strcmp(key, "nt")) {
-    if (value != 0 && value != 1) return fail_arg("nt must be 0 or 1");
+    if (value != 0 && value != 1 && value != 2) return fail_arg("nt must be 0, 1 or 2");
     g_nt = value;
+    return 0;
+  }
+  if (!strcmp(key, "cached_store_max_mb")) {
+    if (value < 0) return fail_arg("cached_store_max_mb must be >= 0");
+    g_cached_store_max_bytes = (int64_t)value << 20;
     return 0;
   }
   if (!strcmp(key, "unroll")) {

@@ -113,6 +113,10 @@ def load():
         got = handle.mctq_abi_version()
         if got != ABI_VERSION:
             raise NativeLibraryError(f"{path} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+        # deployment knob: outputs up to this many MiB are stored through the caches (see include/mctq_hip.h)
+        mb = os.environ.get("MCTQ_CACHED_STORE_MAX_MB")
+        if mb:
+            handle.mctq_set_tuning(b"cached_store_max_mb", int(mb))
         _lib = handle
     return _lib
 

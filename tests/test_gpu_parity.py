@@ -512,7 +512,7 @@ def test_tuning_variants_do_not_change_results(lib):
     want = O.fake_quant_affine(x_np, scales, zps, -128, 127, axis=0)
     x, s_d, z_d = _dev(x_np), _dev(scales), _dev(zps)
     try:
-        for nt in (0, 1):
+        for nt in (0, 1, 2):
             for unroll in (1, 2, 4, 8):
                 native.set_tuning("nt", nt)
                 native.set_tuning("unroll", unroll)
@@ -542,7 +542,7 @@ def test_lut_tuning_variants_do_not_change_results(lib):
     want = O.lut_quantize(x_np, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=1)
     x, t_d, tab, lut_d = _dev(x_np), _dev(thr), _table(lut), _dev(np.asarray(lut, dtype=np.float32))
     try:
-        for nt, hu, pers in [(n_, h_, p_) for n_ in (0, 1) for h_ in (1, 2, 4, 0) for p_ in (0, 1)]:
+        for nt, hu, pers in [(n_, h_, p_) for n_ in (0, 1, 2) for h_ in (1, 2, 4, 0) for p_ in (0, 1)]:
             if True:
                 native.set_tuning("nt", nt)
                 native.set_tuning("heavy_unroll", hu)
@@ -575,6 +575,26 @@ def test_lut_tuning_variants_do_not_change_results(lib):
         native.set_tuning("nt", 1)
         native.set_tuning("heavy_unroll", 0)
         native.set_tuning("heavy_persistent", 0)
+
+
+def test_cached_store_threshold_does_not_change_results(lib):
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    Q = mq.pytorch_quantizers
+    x = torch.randn(300, 2048, device="cuda")
+    xc = x.contiguous(memory_format=torch.contiguous_format)
+    qs = [Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.01 * i for i in range(300)], True, 0),
+          Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * i for i in range(2048)], True, 1),
+          Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1]),
+          Q.WeightsLUTSymmetricInferableQuantizer(4, LUTS["l16"], [4.0] * 300, True, 0, 2)]
+    base = [q(xc.clone()) for q in qs]
+    try:
+        native.set_tuning("cached_store_max_mb", 64)
+        for q, b in zip(qs, base):
+            assert torch.equal(q(xc.clone()), b)
+            assert torch.equal(q(xc.clone().bfloat16()).float(), q(xc.clone().bfloat16()).float())
+    finally:
+        native.set_tuning("cached_store_max_mb", 0)
 
 
 def test_side_stream_and_graph_capture(lib):
