@@ -202,7 +202,7 @@ int mctq_lutt_per_channel(const void* x, float* y,
  *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default), 2 = non-temporal
  *                  loads with cached stores
  *   key "cached_store_max_mb" : with nt = 1, outputs of at most this many MiB are stored through the caches
- *                  (mode 2) so that a consumer launched right after finds them in the Infinity Cache; 0 = never (default)
+ *                  (mode 2) so that a consumer launched right after finds them in L2 / the Infinity Cache; default 32, 0 = never
  *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
  *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.

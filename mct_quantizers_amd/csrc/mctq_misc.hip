@@ -5,7 +5,7 @@ namespace mctq {
 
 thread_local char g_err[256] = "";
 int g_nt = 1;
-int64_t g_cached_store_max_bytes = 0;
+int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggregate L2 stay cached for their consumer
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)

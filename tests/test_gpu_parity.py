@@ -594,7 +594,7 @@ def test_cached_store_threshold_does_not_change_results(lib):
             assert torch.equal(q(xc.clone()), b)
             assert torch.equal(q(xc.clone().bfloat16()).float(), q(xc.clone().bfloat16()).float())
     finally:
-        native.set_tuning("cached_store_max_mb", 0)
+        native.set_tuning("cached_store_max_mb", 32)
 
 
 def test_side_stream_and_graph_capture(lib):
