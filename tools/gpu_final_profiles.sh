@@ -4,6 +4,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 : > gpurun_out/bench_all_configs.jsonl
 for c in cfg1 cfg2 cfg4 cfg5; do timeout 300 python bench.py --no-cpu --config $c --steps 200 >> gpurun_out/bench_all_configs.jsonl 2>/dev/null; done
 for n in 1 8 64 256; do timeout 300 python bench.py --no-cpu --config cfg3 --batch $n --steps 300 >> gpurun_out/bench_all_configs.jsonl 2>/dev/null; done
+timeout 300 python bench.py --no-cpu --extras >> gpurun_out/bench_all_configs.jsonl 2>/dev/null
 timeout 300 python bench.py --no-cpu --streams 2 >> gpurun_out/bench_all_configs.jsonl 2>/dev/null
 timeout 300 python bench.py --no-cpu --ring 1 >> gpurun_out/bench_all_configs.jsonl 2>/dev/null
 cd /tmp
