@@ -746,6 +746,80 @@ def test_fuzz_shapes_axes_layouts_and_dtypes_against_aten_cpu(lib):
             assert got.stride() == xc.stride(), info
 
 
+def test_tensors_beyond_2_pow_31_elements(lib):
+    """64-bit indexing: more than 2^31 elements per tensor (8 GiB each), per-tensor, per-channel rows, per-channel
+    window (ragged inner) and channel-last shapes, against ATen's HIP operator (itself checked elsewhere)."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.skip("needs ~40 GiB of free HBM")
+    n = (1 << 31) + (1 << 22) + 3
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    x.uniform_(-3.0, 3.0)
+    qa = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    y = qa(x)
+    want = torch.fake_quantize_per_tensor_affine(x, qa.scale, qa.zero_point, 0, 255)
+    assert torch.equal(y, want)
+    del y, want
+    # rows: [C=2051][inner=1048576 + ...]: take a prefix that factors
+    C, inner = 2051, 1048576
+    xv = x[: C * inner].view(C, inner)
+    thr = [1.0 + 0.001 * (i % 500) for i in range(C)]
+    qw = Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)
+    y = qw(xv)
+    want = torch.fake_quantize_per_channel_affine(xv, qw.scales, qw.zero_points, 0, -128, 127)
+    assert torch.equal(y, want)
+    del y, want
+    # window shape beyond 2^32 bytes: inner = 1021 (ragged), C = 2103443 rows
+    inner = 1021
+    C = (1 << 31) // inner + 3
+    xv = x[: C * inner].view(C, inner)
+    qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * (i % 500) for i in range(C)], True, 0)
+    y = qw(xv)
+    want = torch.fake_quantize_per_channel_affine(xv, qw.scales, qw.zero_points, 0, -128, 127)
+    assert torch.equal(y, want)
+    del y, want
+    # channel-last beyond 2^31 elements
+    C = 4096
+    rows = n // C
+    xv = x[: rows * C].view(rows, C)
+    qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * (i % 500) for i in range(C)], True, 1)
+    y = qw(xv)
+    want = torch.fake_quantize_per_channel_affine(xv, qw.scales, qw.zero_points, 1, -128, 127)
+    assert torch.equal(y, want)
+    del y, want, x, xv
+
+    # beyond 2^32 elements (16 GiB per tensor): the 64-bit index variants of the window / lastaxis kernels
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * (1 << 30):
+        print("second phase (> 2^32 elements) skipped: free HBM", free >> 30, "GiB")
+        return
+    print("running the > 2^32-element phase")
+    n = (1 << 32) + (1 << 22) + 5
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    x.uniform_(-3.0, 3.0)
+    y = qa(x)
+    want = torch.fake_quantize_per_tensor_affine(x, qa.scale, qa.zero_point, 0, 255)
+    assert torch.equal(y, want)
+    del y, want
+    inner = 1021
+    C = (1 << 32) // inner + 3
+    xv = x[: C * inner].view(C, inner)
+    qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * (i % 500) for i in range(C)], True, 0)
+    y = qw(xv)
+    want = torch.fake_quantize_per_channel_affine(xv, qw.scales, qw.zero_points, 0, -128, 127)
+    assert torch.equal(y, want)
+    del y, want
+    C = 4096
+    rows = n // C
+    xv = x[: rows * C].view(rows, C)
+    qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.001 * (i % 500) for i in range(C)], True, 1)
+    y = qw(xv)
+    want = torch.fake_quantize_per_channel_affine(xv, qw.scales, qw.zero_points, 1, -128, 127)
+    assert torch.equal(y, want)
+
+
 def test_loud_failures(lib, monkeypatch):
     import mct_quantizers_amd as mq
     from mct_quantizers_amd.hip import native
