@@ -26,6 +26,7 @@ import torch.fx
 
 import mct_quantizers_amd as _pkg
 from mct_quantizers_amd.common import constants as _constants
+from mct_quantizers_amd import logger as _logger
 from mct_quantizers_amd.common import registry as _registry
 from mct_quantizers_amd.hip import ops as _ops  # noqa: F401  (registers torch.ops.mctq_amd)
 from mct_quantizers_amd.pytorch import containers as _containers
@@ -46,6 +47,8 @@ REFERENCE_MODULES: Dict[str, object] = {
     "mct_quantizers.common.base_inferable_quantizer": _registry,
     "mct_quantizers.common.quant_info": _registry,
     "mct_quantizers.common.get_quantizers": _registry,
+    "mct_quantizers.common.get_all_subclasses": _registry,
+    "mct_quantizers.logger": _logger,
     "mct_quantizers.pytorch": _pkg.pytorch,
     "mct_quantizers.pytorch.quantizer_utils": _utils,
     "mct_quantizers.pytorch.load_model": _load_model,
