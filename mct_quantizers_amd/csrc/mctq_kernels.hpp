@@ -1064,22 +1064,10 @@ static LutOp<LP> make_lut_op(const float* thr, float eps, const float* lut, int 
   return op;
 }
 
-inline float lut_literal_host(float t, const float* lut, int n) {
-  float best_c = lut[0];
-  float best_d = fabsf(t - lut[0]);
-  for (int j = 1; j < n; ++j) {
-    const float d = fabsf(t - lut[j]);
-    if (d < best_d) { best_d = d; best_c = lut[j]; }
-  }
-  return best_c;
-}
-inline uint32_t f2ord(float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-inline float ord2f(uint32_t o) { uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; memcpy(&f, &u, 4); return f; }
-
-inline int table_entries(float cmin, float cmax) {
+inline int table_entries(float cmin, float cmax) {        // same rule as mctq_tb::table_entries (host builder)
   if (!(cmin < cmax) || cmin != floorf(cmin) || cmax != floorf(cmax)) return -1;
   const double k = 2.0 * ((double)cmax - (double)cmin) + 1.0;
-  if (k > 2048.0) return -1;                 // the table must stay well inside LDS
+  if (k > 2048.0) return -1;
   return (int)k;
 }
 

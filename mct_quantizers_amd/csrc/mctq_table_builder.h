@@ -1,0 +1,110 @@
+// mctq_table_builder.h -- host-only construction of the LUT decision table (no HIP dependency).
+//
+// Pure C++ so that it can be compiled on its own (tests/native/table_builder_check.cpp builds it with
+// g++ -fsanitize=address,undefined); mctq_lut_table.hip wraps it behind the C ABI.  The algorithm and its
+// correctness argument are described at LutTableOp in mctq_kernels.hpp and in DESIGN.md.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace mctq_tb {
+
+// first-minimum argmin over fl32(|t - lut[j]|) in list order: the reference's literal scan
+inline float literal(float t, const float* lut, int n) {
+  float best_c = lut[0];
+  float best_d = fabsf(t - lut[0]);
+  for (int j = 1; j < n; ++j) {
+    const float d = fabsf(t - lut[j]);
+    if (d < best_d) { best_d = d; best_c = lut[j]; }
+  }
+  return best_c;
+}
+
+// order-preserving map float <-> uint32 (finite values)
+inline uint32_t f2ord(float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+inline float ord2f(uint32_t o) { uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; memcpy(&f, &u, 4); return f; }
+
+// IEEE binary16 <-> binary32 (round to nearest even; enough for the finite values used here)
+inline uint16_t f32_to_f16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t abs = u & 0x7fffffffu;
+  if (abs >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((abs > 0x7f800000u) ? 0x200u : 0u));   // inf / NaN
+  if (abs >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                          // overflow -> inf
+  if (abs < 0x33000001u) return (uint16_t)sign;                                                        // underflow -> 0
+  int e = (int)(abs >> 23) - 127;
+  uint32_t m = (abs & 0x7fffffu) | 0x800000u;
+  int shift = (e < -14) ? (13 + (-14 - e)) : 13;
+  uint32_t half = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+  if (rem > mid || (rem == mid && (half & 1u))) ++half;
+  uint32_t he = (e < -14) ? 0u : (uint32_t)(e + 15);
+  // `half` holds the 11-bit significand (implicit bit included for normals); adding lets a carry bump the exponent
+  const uint32_t out = (e < -14) ? half : ((he << 10) + (half - 0x400u));
+  return (uint16_t)(sign | out);
+}
+inline float f16_to_f32(uint16_t h) {
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+  if (e == 0) {
+    if (m == 0) { u = sign; }
+    else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } u = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3ffu) << 13); }
+  } else if (e == 31) { u = sign | 0x7f800000u | (m << 13); }
+  else { u = sign | ((e + 112u) << 23) | (m << 13); }
+  float f; memcpy(&f, &u, 4); return f;
+}
+
+// number of table points for a clip range, or -1 if unsupported
+inline int table_entries(float cmin, float cmax) {
+  if (!(cmin < cmax) || cmin != floorf(cmin) || cmax != floorf(cmax)) return -1;
+  const double k = 2.0 * ((double)cmax - (double)cmin) + 1.0;
+  if (k > 2048.0) return -1;                 // the table must stay well inside LDS
+  return (int)k;
+}
+
+// Fills table[2 * (K + 1)] words; returns NULL on success or a static message.
+inline const char* build(const float* lut, int n_lut, float mult, float clip_min, float clip_max, float* table) {
+  if (!lut || !table) return "NULL pointer";
+  if (n_lut < 1 || n_lut > 4096) return "n_lut must be in [1, 4096]";
+  int e = 0;
+  if (!(mult > 0.0f) || frexpf(mult, &e) != 0.5f) return "mult must be a positive power of two";
+  const int K = table_entries(clip_min, clip_max);
+  if (K < 0) return "decision table unsupported for this clip range";
+  for (int j = 0; j < n_lut; ++j)
+    if (!(lut[j] == floorf(lut[j])) || fabsf(lut[j]) > 16777216.0f) return "decision table needs an integer codebook";
+  uint32_t rng = 0x9E3779B9u;
+  for (int k = 0; k < K; ++k) {
+    const float P = clip_min + 0.5f * (float)k;
+    const float lo = fmaxf(clip_min, P - 0.25f), hi = fminf(clip_max, P + 0.25f);
+    const float cb = literal(lo, lut, n_lut), ca = literal(hi, lut, n_lut);
+    float T = -INFINITY;
+    if (cb != ca) {
+      uint32_t a = f2ord(lo), b = f2ord(hi);          // F(a) == cb, F(b) == ca; find the smallest b with F == ca
+      while (b - a > 1) {
+        const uint32_t m = a + (b - a) / 2;
+        if (literal(ord2f(m), lut, n_lut) == ca) b = m; else a = m;
+      }
+      T = ord2f(b);
+      if (literal(ord2f(b - 1), lut, n_lut) != cb || literal(T, lut, n_lut) != ca) return "codebook decision is not a single step";
+    }
+    // spot-check the single-step model on pseudo-random points of the cell
+    const uint32_t span = f2ord(hi) - f2ord(lo);
+    for (int r = 0; r < 32; ++r) {
+      rng = rng * 1664525u + 1013904223u;
+      const float t = ord2f(f2ord(lo) + (span ? rng % (span + 1u) : 0u));
+      if (literal(t, lut, n_lut) != ((t >= T) ? ca : cb)) return "codebook decision is not a single step";
+    }
+    const float qb = cb / mult, qa = ca / mult;
+    const uint16_t hb = f32_to_f16(qb), ha = f32_to_f16(qa);
+    if (f16_to_f32(hb) != qb || f16_to_f32(ha) != qa) return "codebook centre not exact in fp16";
+    const uint32_t pair = (uint32_t)hb | ((uint32_t)ha << 16);
+    table[2 * k + 0] = T;
+    memcpy(&table[2 * k + 1], &pair, 4);
+  }
+  table[2 * K + 0] = lut[0] / mult;                  // NaN input: every distance is NaN, argmin = index 0
+  table[2 * K + 1] = (float)K;
+  return nullptr;
+}
+
+}  // namespace mctq_tb

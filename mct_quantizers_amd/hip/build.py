@@ -17,7 +17,8 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 SOURCES = [os.path.join(CSRC, f) for f in ("mctq_misc.hip", "mctq_affine.hip", "mctq_codes.hip", "mctq_lut_scan.hip",
                                              "mctq_lut_table.hip")]
-HEADERS = [os.path.join(REPO, "include", "mctq_hip.h"), os.path.join(CSRC, "mctq_kernels.hpp")]
+HEADERS = [os.path.join(REPO, "include", "mctq_hip.h"), os.path.join(CSRC, "mctq_kernels.hpp"),
+           os.path.join(CSRC, "mctq_table_builder.h")]
 OUT = os.path.join(PKG, "lib", "libmctq_hip.so")
 
 # -ffp-contract=off / no fast-math: the kernels must reproduce IEEE float32 results bit for bit.

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import REPO
 
 
@@ -76,3 +78,21 @@ def test_decision_table_builder_matches_the_oracle_scan():
         assert tab[511, 0] == np.float32(lut[0]) / np.float32(128.0)        # NaN input -> codebook entry 0
     assert native.build_lut_table([0.5, 1.0], 128.0, -128.0, 127.0) is None          # non-integer codebook
     assert native.build_lut_table([1.0], 2.0 ** 12, -2048.0, 2047.0) is None         # too wide for LDS
+
+
+def test_table_builder_under_address_and_ub_sanitizers(tmp_path):
+    """The host half of the library (decision-table construction) is plain C++: build it alone with
+    AddressSanitizer + UBSan and run its self-check (GPU sanitizers are unavailable on this pool)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not found")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "table_builder_check")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(repo, "mct_quantizers_amd", "csrc"), "-o", exe,
+                    os.path.join(repo, "tests", "native", "table_builder_check.cpp")], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "table builder ok" in out.stdout
