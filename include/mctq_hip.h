@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 2
+#define MCTQ_ABI_VERSION 3
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
@@ -196,6 +196,31 @@ int mctq_lutt_per_channel(const void* x, float* y,
                           const float* table, int32_t entries,
                           float mult, float clip_min, float clip_max,
                           void* stream);
+
+/*
+ * Export-time arithmetic: what the reference's quantizers compute while an ONNX export traces them
+ * (`self._use_custom_impl and torch.jit.is_tracing()`), a different last-ulp contract from the fake-quant
+ * entry points above: clip, TRUE division by the step, round half even, scale back.
+ *     c = x < lo ? lo : x;   c = x > hi ? hi : c;                 (NaN and signed zeros pass through)
+ *     y = shifted ? step * rint((c - lo) / step) + lo  :  rint(c / step) * step
+ * Replaces (relative to mct_quantizers/pytorch/quantizers/):
+ *   weights_inferable_quantizers/weights_symmetric_inferable_quantizer.py:32-70  quantize_sym_weights_torch
+ *       (lo = -thr, hi = thr - scale, step = scale = thr / 2^(n-1); also weights_pot_inferable_quantizer.py:106-122)
+ *   weights_inferable_quantizers/weights_uniform_inferable_quantizer.py:34-78   quantize_uniform_weights_torch
+ *       (lo, hi = range adjusted to contain 0, step = (hi - lo) / (2^n - 1), shifted = 0)
+ *   activation_inferable_quantizers/activation_symmetric_inferable_quantizer.py:29-54  quantize_sym_activations_torch
+ *   activation_inferable_quantizers/activation_uniform_inferable_quantizer.py:32-65   quantize_uniform_activations_torch
+ *       (shifted = 1)
+ * float32 in and out; per-channel tables are DEVICE float32[channels]; layout arguments as mctq_fq_per_channel.
+ */
+int mctq_grid_per_tensor_f32(const float* x, float* y, int64_t n,
+                             float lo, float hi, float step, int32_t shifted,
+                             void* stream);
+
+int mctq_grid_per_channel_f32(const float* x, float* y,
+                              int64_t outer, int64_t channels, int64_t inner,
+                              const float* los, const float* his, const float* steps, int32_t shifted,
+                              void* stream);
 
 /*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.

@@ -28,3 +28,8 @@ INPUT_RANK = 'input_rank'
 LUT_VALUES = 'lut_values'
 
 FOUND_TORCH = True
+
+# ONNX export (common/constants.py:90,96): custom-op domain and the version attribute of every exported node
+ONNX_CUSTOM_OP_DOMAIN = "mct_quantizers"
+MCTQ_VERSION = "mctq_version"
+REFERENCE_API_VERSION = "1.6.0"          # mct_quantizers.__version__ whose op set the exported nodes target

@@ -179,6 +179,58 @@ struct AffineCodesOp : AffineOp {
   }
 };
 
+// Export-time arithmetic (the reference's ONNX branch, `_use_custom_impl and torch.jit.is_tracing()`):
+// clip to [lo, hi], TRUE division by the step, round half even, scale back -- a different last-ulp
+// contract from ATen's fake-quant (weights_symmetric...py:32-70, weights_uniform...py:34-78,
+// activation_symmetric...py:29-54, activation_uniform...py:32-65).  Runs once per export: plain streaming,
+// IEEE division per element.
+struct GridOp {
+  const float* __restrict__ los;       // [C] lower clip bounds   (per-channel launches only)
+  const float* __restrict__ his;       // [C] upper clip bounds
+  const float* __restrict__ steps;     // [C] grid steps
+  int shifted;                         // 0: rint(c / d) * d;   1: d * rint((c - lo) / d) + lo
+
+  struct Param { float lo, hi, d; };
+  typedef NoBook Book;
+  static constexpr int kWords = 3;
+  static constexpr bool kHeavy = false;
+  static constexpr bool kFallback = false;
+
+  __host__ __device__ __forceinline__ static Param make(float lo, float hi, float d) {
+    Param p; p.lo = lo; p.hi = hi; p.d = d; return p;
+  }
+  __device__ __forceinline__ Param fetch(uint32_t c) const { return make(los[c], his[c], steps[c]); }
+  template <int N>
+  __device__ __forceinline__ void fetch_vec(uint32_t c, Param* p) const {
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(los + c + j);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(his + c + j);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(steps + c + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[j + i] = make(a4[i], b4[i], d4[i]);
+    }
+  }
+  __host__ bool tables_aligned16() const { return (((uintptr_t)los | (uintptr_t)his | (uintptr_t)steps) & 15u) == 0; }
+  __device__ __forceinline__ static void put(float* lds, uint32_t i, uint32_t stride, const Param& p) {
+    lds[i] = p.lo; lds[stride + i] = p.hi; lds[2 * stride + i] = p.d;
+  }
+  __device__ __forceinline__ static Param get(const float* lds, uint32_t i, uint32_t stride) {
+    Param p; p.lo = lds[i]; p.hi = lds[stride + i]; p.d = lds[2 * stride + i]; return p;
+  }
+  __device__ __forceinline__ uint32_t book_words() const { return 0; }
+  __device__ __forceinline__ Book setup(float*) const { return Book(); }
+  __device__ __forceinline__ static bool can_fast(const Param&) { return true; }
+
+  template <bool FAST = true>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book&) const {
+    float c = (x < p.lo) ? p.lo : x;                  // torch.where(x < lo, lo, x): NaN and -0.0 == lo pass through
+    c = (x > p.hi) ? p.hi : c;                        // torch.where(x > hi, hi, c)
+    if (shifted) return p.d * __builtin_rintf((c - p.lo) / p.d) + p.lo;
+    return __builtin_rintf(c / p.d) * p.d;
+  }
+};
+
 // Shared by the two LUT ops: per-channel parameters and the shared-divisor division.
 struct LutCommon {
   const float* __restrict__ thr;       // [C] thresholds (per-channel launches only)

@@ -14,7 +14,7 @@ import ctypes
 import os
 import threading
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 CODE_I8, CODE_U8 = 0, 1
 LIB_NAME = "libmctq_hip.so"
@@ -66,6 +66,10 @@ SIGNATURES = {
     "mctq_lutt_per_channel": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int32, _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+    "mctq_grid_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
+    "mctq_grid_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                 _c_f32p, _c_f32p, _c_f32p, ctypes.c_int32, ctypes.c_void_p]),
     "mctq_lut_table_entries": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float]),
     "mctq_lut_build_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_void_p]),

@@ -234,6 +234,38 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
     return y
 
 
+def _hip_grid_per_tensor(x, lo: float, hi: float, step: float, shifted: bool):
+    """Export-time arithmetic (include/mctq_hip.h: mctq_grid_per_tensor_f32), float32 only."""
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"export-time quantizer arithmetic on the GPU takes float32 tensors, got {x.dtype}")
+    lib = native.load()
+    x = _dense_input(x)
+    y = torch.empty_like(x)
+    with _maybe_on_device(x):
+        rc = _launch(lib.mctq_grid_per_tensor_f32, x.data_ptr(), y.data_ptr(), x.numel(), lo, hi, step, int(shifted),
+                     _stream(x))
+    if rc:
+        native.check(rc, "mctq_grid_per_tensor_f32")
+    return y
+
+
+def _hip_grid_per_channel(x, los, his, steps, axis: int, shifted: bool):
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"export-time quantizer arithmetic on the GPU takes float32 tensors, got {x.dtype}")
+    _check_axis(x, steps.numel(), axis)
+    lib = native.load()
+    x = _dense_input(x)
+    y = torch.empty_like(x)
+    outer, c, inner = _channel_view(x, axis)
+    los, his, steps = (t.to(device=x.device, dtype=torch.float32).contiguous() for t in (los, his, steps))
+    with _maybe_on_device(x):
+        rc = _launch(lib.mctq_grid_per_channel_f32, x.data_ptr(), y.data_ptr(), outer, c, inner, los.data_ptr(),
+                     his.data_ptr(), steps.data_ptr(), int(shifted), _stream(x))
+    if rc:
+        native.check(rc, "mctq_grid_per_channel_f32")
+    return y
+
+
 def _code_dtype(qmin: int, qmax: int):
     if qmin >= 0 and qmax <= 255:
         return torch.uint8, native.CODE_U8
@@ -327,6 +359,16 @@ def _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax):
     return _cpu_lut(x, lut, thr + eps, thr, mult, cmin, cmax)
 
 
+def _cpu_grid(x, lo, hi, step, shifted: bool):
+    # the reference's export-time chains on a CPU tensor (weights_symmetric...py:67-68, activation_uniform...py:60-64);
+    # lo / hi / step: Python floats or broadcastable float32 tensors
+    c = torch.where(x < lo, lo, x)
+    c = torch.where(x > hi, hi, c)
+    if shifted:
+        return step * torch.round((c - lo) / step) + lo
+    return torch.round(c / step) * step
+
+
 # ------------------------------------------------------------------------------------------
 # torch.library registration (fx tracing / FakeTensor / torch.compile see one opaque op)
 # ------------------------------------------------------------------------------------------
@@ -399,3 +441,22 @@ def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin
             _cpu_route_allowed()
             return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
     return torch.ops.mctq_amd.lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
+
+
+def grid_per_tensor(x, lo: float, hi: float, step: float, shifted: bool = False):
+    """clip -> true division -> round half even -> scale back, one parameter set (export-time arithmetic)."""
+    if x.is_cuda:
+        return _hip_grid_per_tensor(x, lo, hi, step, shifted)
+    _cpu_route_allowed()
+    f32 = lambda v: torch.tensor(v, dtype=torch.float64).to(torch.float32)    # noqa: E731  (scalar -> float32, RNE)
+    return _cpu_grid(x, f32(lo), f32(hi), f32(step), shifted)
+
+
+def grid_per_channel(x, los, his, steps, axis: int, shifted: bool = False):
+    """Same with float32 parameter vectors along ``axis``."""
+    if x.is_cuda:
+        return _hip_grid_per_channel(x, los, his, steps, axis, shifted)
+    _cpu_route_allowed()
+    shape = [1] * x.dim()
+    shape[axis] = -1
+    return _cpu_grid(x, los.reshape(shape), his.reshape(shape), steps.reshape(shape), shifted)

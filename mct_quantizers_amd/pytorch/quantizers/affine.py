@@ -11,8 +11,8 @@ messages, reuse cache, side effects) -- see, relative to /root/reference/mct_qua
 
 What differs is underneath ``__call__``: a GPU tensor goes through ONE fused gfx950 kernel
 (mct_quantizers_amd/csrc/mctq_kernels.hip) instead of ATen's fake_quantize_*_cachemask kernels.
-The ONNX-export branch of the reference (``_use_custom_impl and torch.jit.is_tracing()``) is out
-of scope; ``enable_custom_impl`` only records the flag.
+The ONNX-export branch of the reference (``_use_custom_impl and torch.jit.is_tracing()``) lives in
+onnx_export.py; the quantizers below only switch into it.
 """
 from typing import List
 
@@ -220,9 +220,15 @@ class WeightsSymmetricInferableQuantizer(_WeightsAffineMixin, BaseSymmetricInfer
         self.scales = to_torch_tensor(self.scales).to(dev)
         self.zero_points = torch.zeros(len(threshold), dtype=torch.int32).to(dev)
 
+    _export_function = "WeightsSymmetricF"
+
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached(inputs):
             return self.resue_outputs
+        if self._use_custom_impl and torch.jit.is_tracing():
+            from mct_quantizers_amd.pytorch.quantizers import onnx_export
+            return self._remember(getattr(onnx_export, self._export_function).apply(
+                inputs, self.num_bits, self.threshold_np, self.per_channel, self.channel_axis))
         return self._remember(self._quantize_weights(inputs))
 
 
@@ -231,6 +237,7 @@ class WeightsSymmetricInferableQuantizer(_WeightsAffineMixin, BaseSymmetricInfer
                 identifier=QuantizerID.INFERABLE)
 class WeightsPOTInferableQuantizer(WeightsSymmetricInferableQuantizer):
     """Symmetric weights quantizer whose thresholds must be powers of two."""
+    _export_function = "WeightsPOTF"
 
     def __init__(self, num_bits: int, threshold: List[float], per_channel: bool, channel_axis: int = None):
         super().__init__(num_bits=num_bits, threshold=threshold, per_channel=per_channel, channel_axis=channel_axis)
@@ -277,6 +284,11 @@ class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferable
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached(inputs):
             return self.resue_outputs
+        if self._use_custom_impl and torch.jit.is_tracing():
+            from mct_quantizers_amd.pytorch.quantizers.onnx_export import WeightsUniformF
+            return self._remember(WeightsUniformF.apply(inputs, self.num_bits, self.adjusted_min_range_np,
+                                                        self.adjusted_max_range_np, self.per_channel,
+                                                        self.channel_axis))
         return self._remember(self._quantize_weights(inputs))
 
 
@@ -304,7 +316,13 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
                              self.scales, self.zero_points)
         return codes, self.scales, self.zero_points
 
+    _export_function = "ActivationSymF"
+
     def __call__(self, inputs: torch.Tensor):
+        if self._use_custom_impl and torch.jit.is_tracing():
+            from mct_quantizers_amd.pytorch.quantizers import onnx_export
+            return getattr(onnx_export, self._export_function).apply(inputs, self.threshold_np, self.signed,
+                                                                     self.num_bits)
         if type(inputs) is torch.Tensor and inputs.is_cuda:
             # the HIP launch records nothing for autograd: no need for the no_grad context on this path
             return ops._hip_fq_per_tensor(inputs, self.scales, self.zero_points,
@@ -319,6 +337,7 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
                 identifier=QuantizerID.INFERABLE)
 class ActivationPOTInferableQuantizer(ActivationSymmetricInferableQuantizer):
     """Symmetric activation quantizer whose threshold must be a power of two."""
+    _export_function = "ActivationPOTF"
 
     def __init__(self, num_bits: int, threshold: List[float], signed: bool):
         super().__init__(num_bits=num_bits, signed=signed, threshold=threshold)
@@ -350,6 +369,9 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
         return codes, self.scale, self.zero_point
 
     def __call__(self, inputs: torch.Tensor):
+        if self._use_custom_impl and torch.jit.is_tracing():
+            from mct_quantizers_amd.pytorch.quantizers.onnx_export import ActivationUniformF
+            return ActivationUniformF.apply(inputs, self.min_range, self.max_range, self.num_bits)
         if type(inputs) is torch.Tensor and inputs.is_cuda:
             return ops._hip_fq_per_tensor(inputs, self.scale, self.zero_point,
                                           self.min_quantized_domain, self.max_quantized_domain)

@@ -97,9 +97,16 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(self.lut_values_bitwidth, True),
                                                    dev)
 
+    _export_function = "WeightsLUTSymmetricF"
+
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached(inputs):
             return self.resue_outputs
+        if self._use_custom_impl and torch.jit.is_tracing():
+            from mct_quantizers_amd.pytorch.quantizers import onnx_export
+            return self._remember(getattr(onnx_export, self._export_function).apply(
+                inputs, self.num_bits, self._lut_values_np, self._threshold_np, self.lut_values_bitwidth, self.eps,
+                self.per_channel, self.channel_axis, self.input_rank))
         inputs.requires_grad = False
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, True)
         if self.per_channel:
@@ -119,6 +126,7 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
                 identifier=QuantizerID.INFERABLE)
 class WeightsLUTPOTInferableQuantizer(WeightsLUTSymmetricInferableQuantizer):
     """Weights codebook quantizer whose thresholds must be powers of two."""
+    _export_function = "WeightsLUTPOTF"
 
     def __init__(self, num_bits: int, lut_values: List[float], threshold: List[float], per_channel: bool,
                  channel_axis: int = None, input_rank: int = None, lut_values_bitwidth: int = LUT_VALUES_BITWIDTH,

@@ -49,3 +49,25 @@ def oracle_call(cls_name: str, kwargs: dict, x: np.ndarray, return_index: bool =
                               kw.get("lut_values_bitwidth", O.LUT_VALUES_BITWIDTH), kw.get("eps", O.EPS),
                               return_index=return_index)
     raise KeyError(cls_name)
+
+
+def oracle_export_call(cls_name: str, kwargs: dict, x: np.ndarray):
+    """What the reference's ``q.enable_custom_impl(); q(x)`` returns while ``torch.jit`` is tracing."""
+    kw = dict(kwargs)
+    nb = kw["num_bits"]
+    axis = kw.get("channel_axis") if kw.get("per_channel") else None
+    if axis is not None:
+        axis %= x.ndim
+    if cls_name in ("WeightsSymmetricInferableQuantizer", "WeightsPOTInferableQuantizer"):
+        return O.export_weights_symmetric(x, nb, kw["threshold"], axis)
+    if cls_name == "WeightsUniformInferableQuantizer":
+        _, _, _, _, a, b = O.weights_uniform_params(nb, kw["min_range"], kw["max_range"])
+        return O.export_weights_uniform(x, nb, a, b, axis)
+    if cls_name in ("ActivationSymmetricInferableQuantizer", "ActivationPOTInferableQuantizer"):
+        return O.export_activation_symmetric(x, nb, float(np.asarray(kw["threshold"])[0]), kw["signed"])
+    if cls_name == "ActivationUniformInferableQuantizer":
+        _, _, _, _, a, b = O.activation_uniform_params(nb, kw["min_range"], kw["max_range"])
+        return O.export_activation_uniform(x, nb, a, b)
+    if cls_name in ("WeightsLUTSymmetricInferableQuantizer", "WeightsLUTPOTInferableQuantizer"):
+        return oracle_call(cls_name, kwargs, x)        # the LUT export branch runs the same chain
+    raise KeyError(cls_name)

@@ -271,3 +271,79 @@ def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
     if return_index:
         return y, idx_out.reshape(x.shape)
     return y
+
+
+# --------------------------------------------------------------------------
+# export-time arithmetic (`_use_custom_impl and torch.jit.is_tracing()`)
+# --------------------------------------------------------------------------
+
+def export_grid(x: np.ndarray, lo, hi, step, axis=None, shifted: bool = False) -> np.ndarray:
+    """clip -> TRUE division -> round half even -> scale back, float32 throughout.
+
+    weights_symmetric_inferable_quantizer.py:67-68 and weights_uniform_inferable_quantizer.py:75-77
+    (``torch.where`` clip, ``round(c / step) * step``); activation_symmetric_inferable_quantizer.py:53
+    (``torch.clip``, same formula); activation_uniform_inferable_quantizer.py:60-64
+    (``step * round((c - lo) / step) + lo``).  NaN passes through; a value equal to a bound keeps its own
+    sign of zero.  ``lo`` / ``hi`` / ``step``: float32 vectors along ``axis`` or scalars (rounded to float32).
+    """
+    x = np.asarray(x, dtype=F32)
+    lo, hi, step = (np.asarray(v, dtype=np.float64).astype(F32) for v in (lo, hi, step))
+    if axis is not None:
+        shape = _channel_shape(x.ndim, axis)
+        lo, hi, step = lo.reshape(shape), hi.reshape(shape), step.reshape(shape)
+    else:
+        lo, hi, step = lo.reshape(-1)[0], hi.reshape(-1)[0], step.reshape(-1)[0]
+    with np.errstate(all="ignore"):
+        c = np.where(x < lo, lo, x).astype(F32)
+        c = np.where(x > hi, hi, c).astype(F32)
+        if shifted:
+            return ((step * np.rint(((c - lo).astype(F32) / step).astype(F32))).astype(F32) + lo).astype(F32)
+        return (np.rint((c / step).astype(F32)) * step).astype(F32)
+
+
+def export_weights_symmetric(x, num_bits: int, threshold, axis=None):
+    """quantize_sym_weights_torch (weights_symmetric_inferable_quantizer.py:32-70): float32 parameter math."""
+    thr = np.asarray(threshold, dtype=np.float64).astype(F32)
+    step = (thr / F32(2 ** (num_bits - 1))).astype(F32)
+    return export_grid(x, -thr, (thr - step).astype(F32), step, axis)
+
+
+def export_weights_uniform(x, num_bits: int, adj_min, adj_max, axis=None):
+    """quantize_uniform_weights_torch (weights_uniform_inferable_quantizer.py:34-78) on the quantizer's
+    ALREADY adjusted ranges (``:143-148`` passes adjusted_{min,max}_range_np); the range fix runs again."""
+    a, b = fix_range_to_include_zero(adj_min, adj_max, num_bits)
+    step = ((b - a) / F32(2 ** num_bits - 1)).astype(F32)
+    return export_grid(x, a, b, step, axis)
+
+
+def export_activation_symmetric(x, num_bits: int, threshold: float, signed: bool):
+    """quantize_sym_activations_torch (activation_symmetric_inferable_quantizer.py:29-54): double parameters."""
+    threshold = float(threshold)
+    if signed:
+        step = threshold / (2 ** (num_bits - 1))
+        lo, hi = -threshold, threshold - step
+    else:
+        step = threshold / (2 ** num_bits)
+        lo, hi = 0.0, threshold - step
+    return export_grid(x, lo, hi, step)
+
+
+def adjust_range_to_include_zero_f64(range_min: float, range_max: float, n_bits: int):
+    """common/quant_utils.py:20-50 on Python floats (double arithmetic, final clamp to lo <= 0 <= hi)."""
+    rmin, rmax = np.float64(range_min), np.float64(range_max)
+    scale = (rmax - rmin) / (2 ** n_bits - 1)
+    a = scale * np.round(rmin / scale)
+    b = rmax - rmin + a
+    pos, neg = rmin > 0, rmax < 0
+    mid = (not pos) and (not neg)
+    a = a * mid + neg * rmin
+    b = b * mid + pos * rmax
+    return float(np.minimum(a, 0)), float(np.maximum(b, 0))
+
+
+def export_activation_uniform(x, num_bits: int, min_range: float, max_range: float):
+    """quantize_uniform_activations_torch (activation_uniform_inferable_quantizer.py:32-65) on the
+    quantizer's adjusted Python-float range (``:121``)."""
+    a, b = adjust_range_to_include_zero_f64(min_range, max_range, num_bits)
+    step = (b - a) / (2 ** num_bits - 1)
+    return export_grid(x, a, b, step, shifted=True)

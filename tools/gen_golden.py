@@ -524,13 +524,165 @@ def gen_pickled_reference_models():
     print("pickled reference model:", os.path.getsize(os.path.join(OUT, "ref_model.pth")), "bytes")
 
 
+# ------------------------------------------------------------------------------------------
+# ONNX-export branch (enable_custom_impl + tracing): outputs of the export-time arithmetic and the
+# nodes the symbolic functions emit
+# ------------------------------------------------------------------------------------------
+
+def traced_call(q, xt):
+    """q(xt) evaluated while torch.jit is tracing (the reference's switch into its export arithmetic)."""
+    box = {}
+
+    def fn(t):
+        box["y"] = q(t)
+        return box["y"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.jit.trace(fn, xt, check_trace=False)
+    return box["y"].detach()
+
+
+def onnx_nodes(module, example):
+    """[(kind, {attr: value})] of the ONNX graph the TorchScript exporter builds (no `onnx` package needed)."""
+    from torch.onnx._internal.torchscript_exporter import utils
+    from torch.onnx._internal.torchscript_exporter._globals import GLOBALS
+    GLOBALS.export_onnx_opset_version = 16
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with utils.exporter_context(module, torch.onnx.TrainingMode.EVAL, False):
+            graph, _, _ = utils._model_to_graph(module, (example,), do_constant_folding=False)
+    out = []
+    for n in graph.nodes():
+        attrs = {}
+        for a in n.attributeNames():
+            kind = n.kindOf(a)
+            attrs[a] = dict(i=n.i, f=n.f, s=n.s, t=lambda k: n.t(k).tolist(), is_=n.is_, fs=n.fs)[
+                "is_" if kind == "is" else kind](a)
+        out.append([n.kind(), attrs, len(list(n.inputs()))])
+    return out
+
+
+def export_configs():
+    """(name, class, kwargs, input shape, holder?) for every quantizer with an export branch."""
+    er = np.random.default_rng(20251004)
+    u = lambda lo, hi, n: [float(v) for v in er.uniform(lo, hi, size=n)]   # noqa: E731
+    lut16 = [-128., -96., -64., -40., -24., -12., -5., 0., 5., 12., 24., 40., 64., 96., 120., 127.]
+    cfgs = []
+    for bits in (2, 4, 8):
+        cfgs += [
+            ("wsym_pc0", "WeightsSymmetricInferableQuantizer", dict(num_bits=bits, threshold=u(0.05, 7, 6), per_channel=True, channel_axis=0), (6, 37)),
+            ("wsym_pc1", "WeightsSymmetricInferableQuantizer", dict(num_bits=bits, threshold=u(0.05, 7, 7), per_channel=True, channel_axis=1), (5, 7, 11)),
+            ("wsym_pclast", "WeightsSymmetricInferableQuantizer", dict(num_bits=bits, threshold=u(0.05, 7, 8), per_channel=True, channel_axis=-1), (3, 9, 8)),
+            ("wsym_pt", "WeightsSymmetricInferableQuantizer", dict(num_bits=bits, threshold=u(0.3, 5, 1), per_channel=False), (7, 33, 5)),
+            ("wpot_pc", "WeightsPOTInferableQuantizer", dict(num_bits=bits, threshold=[float(2.0 ** e) for e in er.integers(-4, 4, size=6)], per_channel=True, channel_axis=0), (6, 40)),
+            ("wpot_pt", "WeightsPOTInferableQuantizer", dict(num_bits=bits, threshold=[2.0], per_channel=False), (9, 9)),
+            ("wuni_pc", "WeightsUniformInferableQuantizer", dict(num_bits=bits, min_range=u(-4, -0.1, 6), max_range=u(0.2, 6, 6), per_channel=True, channel_axis=0), (6, 37)),
+            ("wuni_pc_mixed", "WeightsUniformInferableQuantizer", dict(num_bits=bits, min_range=[-1.0, 0.5, -3.0, -0.2], max_range=[2.0, 4.0, -1.0, 0.7], per_channel=True, channel_axis=1), (5, 4, 9)),
+            ("wuni_pt", "WeightsUniformInferableQuantizer", dict(num_bits=bits, min_range=[-1.3], max_range=[2.9], per_channel=False), (11, 13)),
+            ("asym_s", "ActivationSymmetricInferableQuantizer", dict(num_bits=bits, threshold=u(0.5, 6, 1), signed=True), (2, 3, 17, 9)),
+            ("asym_u", "ActivationSymmetricInferableQuantizer", dict(num_bits=bits, threshold=u(0.5, 6, 1), signed=False), (2, 3, 17, 9)),
+            ("apot_s", "ActivationPOTInferableQuantizer", dict(num_bits=bits, threshold=[4.0], signed=True), (3, 50)),
+            ("apot_u", "ActivationPOTInferableQuantizer", dict(num_bits=bits, threshold=[0.5], signed=False), (3, 50)),
+        ]
+        for lo, hi in ((-2.5, 3.1), (3.0, 10.0), (-7.0, -1.0), (-0.37, 0.91)):
+            cfgs.append((f"auni_{lo}_{hi}", "ActivationUniformInferableQuantizer", dict(num_bits=bits, min_range=[lo], max_range=[hi]), (2, 3, 12, 12)))
+    cfgs += [
+        ("wlut_pc", "WeightsLUTSymmetricInferableQuantizer", dict(num_bits=4, lut_values=lut16, threshold=u(0.5, 3, 6), per_channel=True, channel_axis=0, input_rank=2), (6, 50)),
+        ("wlut_pt", "WeightsLUTSymmetricInferableQuantizer", dict(num_bits=3, lut_values=[22., -53., 62., 0., -66., -21., 44., -40.], threshold=[1.7], per_channel=False), (8, 31)),
+        ("wlutpot_pc", "WeightsLUTPOTInferableQuantizer", dict(num_bits=4, lut_values=lut16, threshold=[0.5, 1.0, 2.0, 4.0], per_channel=True, channel_axis=1, input_rank=3), (3, 4, 20)),
+        ("wlutpot_pt", "WeightsLUTPOTInferableQuantizer", dict(num_bits=2, lut_values=[-25., 25., 0., 100.], threshold=[2.0], per_channel=False), (8, 31)),
+    ]
+    return cfgs
+
+
+def export_input(er, q, cls_name, kwargs, shape):
+    """Ties, clip edges and values beyond them on the export grid of each channel."""
+    n = int(np.prod(shape))
+    if "LUT" in cls_name:
+        thr = np.asarray(kwargs["threshold"], dtype=np.float32)
+        x = er.uniform(-1.6, 1.6, size=n).astype(np.float32).reshape(shape)
+        if kwargs.get("per_channel"):
+            bs = [1] * len(shape)
+            bs[kwargs["channel_axis"]] = -1
+            x = x * thr.reshape(bs)
+        else:
+            x = x * thr[0]
+        return np.ascontiguousarray(x.astype(np.float32))
+    bits = kwargs["num_bits"]
+    if "threshold" in kwargs:
+        thr = np.asarray(kwargs["threshold"], dtype=np.float64)
+        signed = kwargs.get("signed", True)
+        step = thr / (2 ** (bits - 1) if signed else 2 ** bits)
+        lo = -thr if signed else np.zeros_like(thr)
+    else:
+        lo = np.asarray(kwargs["min_range"], dtype=np.float64)
+        hi = np.asarray(kwargs["max_range"], dtype=np.float64)
+        step = (hi - lo) / (2 ** bits - 1)
+    axis = kwargs.get("channel_axis") if kwargs.get("per_channel") else None
+    if axis is None:
+        sb, lb = np.broadcast_to(step[0], shape), np.broadcast_to(lo[0], shape)
+    else:
+        bs = [1] * len(shape)
+        bs[axis] = -1
+        sb, lb = np.broadcast_to(step.reshape(bs), shape), np.broadcast_to(lo.reshape(bs), shape)
+    k = er.integers(-3, 2 ** bits + 3, size=shape).astype(np.float64)
+    frac = er.choice([0.0, 0.5, 0.5, 0.49999, 0.50001, 0.25], size=shape)
+    x = (lb + (k + frac) * sb)
+    x32 = x.astype(np.float32)
+    bump = er.integers(-2, 3, size=shape)                      # neighbours of the tie, in ulps
+    x32 = (x32.view(np.int32) + bump.astype(np.int32)).view(np.float32)
+    flat = x32.reshape(-1)
+    specials = np.asarray([0.0, -0.0, 1e-30, -1e-30, 1e30, -1e30, np.inf, -np.inf, np.nan], dtype=np.float32)
+    if flat.size >= 4 * specials.size:
+        flat[er.choice(flat.size, size=specials.size, replace=False)] = specials
+    return np.ascontiguousarray(flat.reshape(shape))
+
+
+def gen_export():
+    er = np.random.default_rng(20251005)
+    ecases, earrays, nodes = [], {}, []
+    for name, cls_name, kwargs, shape in export_configs():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(refq, cls_name)(**kwargs)
+        q.enable_custom_impl()
+        x = export_input(er, q, cls_name, kwargs, shape)
+        y = traced_call(q, torch.from_numpy(x.copy()))
+        cid = f"e{len(ecases):03d}"
+        earrays[cid + "_x"], earrays[cid + "_y"] = x, y.numpy().copy()
+        ecases.append(dict(id=cid, name=name, cls=cls_name, kwargs=kwargs, shape=list(shape)))
+        # the node(s) this quantizer exports as
+        if cls_name.startswith("Weights"):
+            class Holder(torch.nn.Module):
+                def __init__(self, quant, shp):
+                    super().__init__()
+                    self.q = quant
+                    self.w = torch.nn.Parameter(torch.zeros(shp))
+
+                def forward(self, t):
+                    return t + self.q(self.w).sum()
+            mod, ex = Holder(q, shape), torch.zeros(3)
+        else:
+            mod, ex = ref.PytorchActivationQuantizationHolder(q), torch.zeros(shape)
+        nodes.append(dict(id=cid, nodes=[n for n in onnx_nodes(mod, ex) if n[0].startswith("mct_quantizers::") or n[0] == "onnx::Constant"]))
+    np.savez_compressed(os.path.join(OUT, "export_cases.npz"), **earrays)
+    meta = dict(reference="sony/mct_quantizers v%s" % ref.__version__, torch=torch.__version__,
+                generator="tools/gen_golden.py --export-only")
+    with open(os.path.join(OUT, "export_cases.json"), "w") as f:
+        json.dump(dict(meta=meta, cases=ecases, onnx_nodes=nodes), f, indent=1)
+    print(f"{len(ecases)} export cases, {sum(a.nbytes for a in earrays.values())} array bytes")
+
+
 if __name__ == "__main__":
     if "--pickles-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         gen_pickled_reference_models()
     elif "--half-only" in sys.argv:
         gen_half_cases()
+    elif "--export-only" in sys.argv:
+        gen_export()
     else:
         main()
         gen_half_cases()
         gen_pickled_reference_models()
+        gen_export()
