@@ -223,12 +223,31 @@ int mctq_grid_per_channel_f32(const float* x, float* y,
                               void* stream);
 
 /*
+ * Integer consumer of the codes (extension; the reference has no counterpart): the product a wrapped
+ * torch.nn.Linear computes on fake-quantized operands -- PytorchQuantizationWrapper.forward
+ * (pytorch/quantize_wrapper.py:231-257: quantize the weight, then self.layer(x)) fed by an activation holder
+ * (pytorch/activation_quantization_holder.py:53) -- evaluated on the 8-bit clamp indices instead:
+ *     y[m][n] = float( sum_k (a[m][k] - a_zero_point) * w[n][k] ) * (a_scale * w_scales[n]) + bias[n]
+ * with exact int32 accumulation on the integer matrix cores; float32 multiply, then float32 add, each
+ * rounded once.  a_codes [M][K] int8 or uint8 (a_code_dtype = MCTQ_CODE_I8 / MCTQ_CODE_U8, from
+ * mctq_fq_codes_per_tensor), w_codes [N][K] int8 with zero point 0 (symmetric / power-of-two weights, from
+ * mctq_fq_codes_per_channel with axis 0 or _per_tensor), w_scales float32[N], w_rowsum int32[N] =
+ * sum_k w[n][k] (computed once per weight), bias float32[N] or NULL, y float32 [M][N]; all DEVICE pointers,
+ * code matrices 16-byte aligned, K % 16 == 0, K <= 32768.  The result differs from the float32 product of
+ * the dequantized operands only by that product's own rounding (it is the exact sum, scaled once).
+ */
+int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                    const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                    float* y, int64_t M, int64_t N, int64_t K, void* stream);
+
+/*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.
  *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default), 2 = non-temporal
  *                  loads with cached stores
  *   key "cached_store_max_mb" : with nt = 1, outputs of at most this many MiB are stored through the caches
  *                  (mode 2) so that a consumer launched right after finds them in L2 / the Infinity Cache; default 32, 0 = never
  *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
+ *   key "ql_variant" : mctq_qlinear_i8 launch shape, <waves per block><16-row tiles per pass> (41 ... 84); 0 = automatic
  *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */

@@ -17,8 +17,9 @@ from mct_quantizers_amd.pytorch.load_model import pytorch_load_quantized_model
 
 
 def __getattr__(name):
-    # lazily loaded helpers: mctq.compat (reference pickles / fx routing), mctq.sharded (dim-0 shards + all-gather)
-    if name in ("compat", "sharded", "workloads"):
+    # lazily loaded helpers: mctq.compat (reference pickles / fx routing), mctq.sharded (dim-0 shards + all-gather),
+    # mctq.consumers (integer GEMM on the codes)
+    if name in ("compat", "sharded", "workloads", "consumers"):
         import importlib
         return importlib.import_module(f"mct_quantizers_amd.{name}")
     raise AttributeError(f"module 'mct_quantizers_amd' has no attribute {name!r}")

@@ -1,0 +1,149 @@
+"""Integer consumers of the quantizers' codes (extension; SURVEY §8(f) row 2 -- not part of the reference API).
+
+The reference re-quantizes a wrapped layer's weight on every forward and then runs the float32 layer on the
+dequantized tensors (``PytorchQuantizationWrapper.forward``, pytorch/quantize_wrapper.py:231-257, fed by
+``PytorchActivationQuantizationHolder.forward``, pytorch/activation_quantization_holder.py:53).  Both operands of
+that product are integers times a scale, so on MI355X the product itself can run on the 8-bit clamp indices:
+
+    y[m][n] = float(sum_k (qa[m][k] - za) * qw[n][k]) * (sa * sw[n]) + bias[n]
+
+``QuantizedLinear`` keeps the weight's int8 codes (refreshed when the weight tensor changes), turns the incoming
+activation into codes with the activation quantizer's own parameters (``mctq_fq_codes_per_tensor``) and calls
+``mctq_qlinear_i8`` (include/mctq_hip.h): 1 byte per weight streamed instead of 4 B read + 4 B written by the
+fake-quant kernel and 4 B read again by the float32 GEMM.  The result is the exact integer sum scaled once; it
+differs from the reference's float32 product only by that product's own accumulation rounding.
+
+CPU tensors run the same integer arithmetic with torch ops (host logic for tests, bit-identical to the kernel).
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from mct_quantizers_amd.hip import native, ops
+from mct_quantizers_amd.pytorch.containers import PytorchActivationQuantizationHolder, PytorchQuantizationWrapper
+
+_MAX_K = 32768
+
+
+def _activation_code_params(q):
+    """(scale, zero_point, qmin, qmax) of an affine activation quantizer."""
+    if hasattr(q, "scale") and hasattr(q, "zero_point"):              # ActivationUniform
+        return float(q.scale), int(q.zero_point), q.min_quantized_domain, q.max_quantized_domain
+    if hasattr(q, "scales") and hasattr(q, "zero_points") and not isinstance(q.scales, torch.Tensor):
+        return float(q.scales), int(q.zero_points), q.min_quantized_domain, q.max_quantized_domain
+    raise TypeError(f"{type(q).__name__} is not an affine per-tensor activation quantizer")
+
+
+def qlinear_i8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes: torch.Tensor,
+               w_scales: torch.Tensor, w_rowsum: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """a_codes [M, K] int8/uint8, w_codes [N, K] int8 (zero point 0) -> float32 [M, N]."""
+    M, K = a_codes.shape
+    N = w_codes.shape[0]
+    if w_codes.shape[1] != K:
+        raise RuntimeError(f"shape mismatch: activations have K={K}, weights K={w_codes.shape[1]}")
+    if a_codes.is_cuda:
+        if K % 16 or K > _MAX_K:
+            raise NotImplementedError(f"mctq_qlinear_i8 needs K % 16 == 0 and K <= {_MAX_K}, got K={K}")
+        lib = native.load()
+        a_codes, w_codes = a_codes.contiguous(), w_codes.contiguous()
+        y = torch.empty((M, N), dtype=torch.float32, device=a_codes.device)
+        code = native.CODE_U8 if a_codes.dtype == torch.uint8 else native.CODE_I8
+        with ops._maybe_on_device(a_codes):
+            rc = ops._launch(lib.mctq_qlinear_i8, a_codes.data_ptr(), code, int(a_zero_point), float(a_scale),
+                             w_codes.data_ptr(), w_scales.data_ptr(), w_rowsum.data_ptr(),
+                             None if bias is None else bias.data_ptr(), y.data_ptr(), M, N, K, ops._stream(a_codes))
+        if rc:
+            native.check(rc, "mctq_qlinear_i8")
+        return y
+    ops._cpu_route_allowed()
+    acc = (a_codes.to(torch.int32) - int(a_zero_point)) @ w_codes.to(torch.int32).t()
+    y = acc.to(torch.float32) * (torch.tensor(a_scale, dtype=torch.float64).to(torch.float32) * w_scales)
+    return y if bias is None else y + bias
+
+
+class QuantizedLinear(nn.Module):
+    """``activation quantizer -> PytorchQuantizationWrapper(nn.Linear)`` evaluated on integer codes.
+
+    ``weights_quantizer``: WeightsSymmetric / WeightsPOT (zero point 0), per tensor or per output channel
+    (``channel_axis`` 0), at most 8 bits.  ``activation_quantizer``: ActivationSymmetric / POT / Uniform, at most
+    8 bits.  The float weight stays the module's parameter; its codes are rebuilt when it changes."""
+
+    def __init__(self, linear: nn.Linear, weights_quantizer, activation_quantizer):
+        super().__init__()
+        if not isinstance(linear, nn.Linear):
+            raise TypeError("QuantizedLinear wraps torch.nn.Linear")
+        if not hasattr(weights_quantizer, "quantize_to_codes") or not hasattr(weights_quantizer, "threshold_np"):
+            raise TypeError("the weights quantizer must be symmetric or power-of-two (zero point 0)")
+        if weights_quantizer.per_channel and weights_quantizer.channel_axis % 2 != 0:
+            raise NotImplementedError("per-channel weight scales must run along the output channels (axis 0)")
+        if weights_quantizer.num_bits > 8 or activation_quantizer.num_bits > 8:
+            raise NotImplementedError("codes wider than 8 bits")
+        self.weight = linear.weight
+        self.bias = linear.bias
+        self.in_features, self.out_features = linear.in_features, linear.out_features
+        self.weights_quantizer = weights_quantizer
+        self.activation_quantizer = activation_quantizer
+        self._a_scale, self._a_zp, self._a_qmin, self._a_qmax = _activation_code_params(activation_quantizer)
+        self._w_key = None
+        self._w_codes = self._w_scales = self._w_rowsum = None
+
+    @classmethod
+    def from_wrapper(cls, wrapper: PytorchQuantizationWrapper, activation_quantizer) -> "QuantizedLinear":
+        quantizers = wrapper.weights_quantizers
+        if list(quantizers) != ["weight"] or not isinstance(wrapper.layer, nn.Linear):
+            raise TypeError("expected a wrapped torch.nn.Linear with one quantizer on 'weight'")
+        lin = nn.Linear(wrapper.layer.in_features, wrapper.layer.out_features, bias=wrapper.layer.bias is not None,
+                        device=wrapper.weight.device, dtype=wrapper.weight.dtype)
+        lin.weight = wrapper.weight                     # the wrapper owns the float weight as its parameter
+        lin.bias = wrapper.layer.bias
+        return cls(lin, quantizers["weight"], activation_quantizer)
+
+    def _refresh_weight_codes(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if key == self._w_key:
+            return
+        codes, scales, _ = self.weights_quantizer.quantize_to_codes(w.detach())
+        if codes.dtype != torch.int8:
+            raise RuntimeError("symmetric weight codes are expected to be int8")
+        scales = scales.to(device=w.device, dtype=torch.float32).reshape(-1)
+        if scales.numel() == 1:
+            scales = scales.expand(self.out_features)
+        self._w_codes = codes.contiguous()
+        self._w_scales = scales.contiguous()
+        self._w_rowsum = codes.sum(dim=1, dtype=torch.int32).contiguous()
+        self._w_key = key
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._refresh_weight_codes()
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.in_features)
+        a_codes = ops.fq_codes(x2, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
+        y = qlinear_i8(a_codes, self._a_zp, self._a_scale, self._w_codes, self._w_scales, self._w_rowsum,
+                       None if self.bias is None else self.bias.detach())
+        return y.reshape(*lead, self.out_features)
+
+
+def fuse_linear_consumers(model: nn.Module) -> int:
+    """In every ``nn.Sequential`` of ``model``: an activation holder directly followed by a wrapped ``nn.Linear`` with
+    a symmetric weights quantizer becomes (Identity, QuantizedLinear).  Returns the number of pairs replaced.
+    Pairs the integer consumer cannot take (other layers, LUT / uniform weights, K % 16 != 0) are left alone."""
+    replaced = 0
+    for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
+        for i in range(len(seq) - 1):
+            holder, wrapper = seq[i], seq[i + 1]
+            if type(holder) is not PytorchActivationQuantizationHolder or not isinstance(wrapper, PytorchQuantizationWrapper):
+                continue
+            if not isinstance(getattr(wrapper, "layer", None), nn.Linear) or list(wrapper.weights_quantizers) != ["weight"]:
+                continue
+            if wrapper.layer.in_features % 16 or wrapper.layer.in_features > _MAX_K:
+                continue
+            try:
+                fused = QuantizedLinear.from_wrapper(wrapper, holder.activation_holder_quantizer)
+            except (TypeError, NotImplementedError):
+                continue
+            seq[i] = nn.Identity()
+            seq[i + 1] = fused
+            replaced += 1
+    return replaced

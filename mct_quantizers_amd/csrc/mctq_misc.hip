@@ -8,6 +8,7 @@ int g_nt = 1;
 int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggregate L2 stay cached for their consumer
 int g_unroll = 4;
 int g_heavy_unroll = 0;
+int g_ql_variant = 0;
 int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)
 
 int fail_arg(const char* msg) {
@@ -94,6 +95,12 @@ int mctq_set_tuning(const char* key, int32_t value) {
   if (!strcmp(key, "heavy_persistent")) {
     if (value != 0 && value != 1) return fail_arg("heavy_persistent must be 0 or 1");
     g_heavy_persistent = value;
+    return 0;
+  }
+  if (!strcmp(key, "ql_variant")) {
+    if (value != 0 && value != 41 && value != 42 && value != 44 && value != 81 && value != 82 && value != 84)
+      return fail_arg("ql_variant must be 0 or <waves><row tiles>: 41, 42, 44, 81, 82, 84");
+    g_ql_variant = value;
     return 0;
   }
   return fail_arg("unknown tuning key");

@@ -1,0 +1,207 @@
+// mctq_qlinear.hip -- part of libmctq_hip.so (C ABI: include/mctq_hip.h).
+//
+// Integer consumer of the quantizers' codes: y = dequant(A) . dequant(W)^T + bias computed on the 8-bit
+// clamp indices the fake-quant kernels would have dequantized (mctq_fq_codes_*), with the gfx950 integer
+// matrix cores (v_mfma_i32_16x16x64_i8) and exact int32 accumulation:
+//     y[m][n] = float( sum_k (qa[m][k] - za) * qw[n][k] ) * (sa * sw[n]) + bias[n]
+// For the small batches of inference the product is bound by streaming the weight codes once (1 B per weight
+// instead of re-quantizing 4 B -> 4 B and then reading 4 B again in an fp32 GEMM), so the layout serves the
+// memory system first: both operands are K-contiguous, per 256-byte K block every lane fetches four
+// 16-byte pieces of one row, the four lanes of a row covering one 64-byte sector per load instruction (the
+// pieces feed four MFMA steps; A and B use the same k assignment, which is all an exact integer sum needs), the 8 waves of a block interleave K blocks so that a row is read in 2 KiB
+// runs, and the partial sums meet in LDS.  One block = 16 output columns x all rows x all of K; no split-K
+// atomics, so the result does not depend on scheduling.
+#include "mctq_kernels.hpp"
+
+namespace mctq {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kQlKBlock = 256;          // bytes of K per wave step: 4 lane groups x 64 B
+extern int g_ql_variant;                // tuning hook "ql_variant": 0 = automatic
+
+template <bool NT>
+__device__ __forceinline__ i32x4 ql_load16(const int8_t* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p));
+  else return *reinterpret_cast<const i32x4*>(p);
+}
+
+// 4 x 16 B of one row, 64 B apart, starting at k: piece p of the four lanes that share a row covers one
+// contiguous 64-byte sector.  FULL: the whole 256-byte K block lies inside K (no guards, straight-line loads);
+// otherwise pieces that start at or beyond K read as zero (K % 16 == 0).
+template <bool NT, bool FULL>
+__device__ __forceinline__ void ql_load_row(const int8_t* row, int64_t k, int64_t K, i32x4* out) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if constexpr (FULL) {
+      out[p] = ql_load16<NT>(row + k + 64 * p);
+    } else {
+      const i32x4 z = {0, 0, 0, 0};
+      out[p] = (k + 64 * p < K) ? ql_load16<NT>(row + k + 64 * p) : z;
+    }
+  }
+}
+
+// MT: 16-row tiles of A per pass (1..4).  A_U8: activation codes are uint8 (re-biased to int8 by ^0x80).
+template <int kQlWaves, int MT, bool A_U8, bool W_NT>
+__global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
+    const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, float* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa) {
+  constexpr int kQlThreads = kQlWaves * 64;
+  __shared__ int red[kQlWaves][MT][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  // rows beyond N / M are clamped to the last valid row: they are loaded and multiplied, never stored
+  const int8_t* wrow = w + (int64_t)min(n0 + r, N - 1) * K;
+  const int64_t kblocks = (K + kQlKBlock - 1) / kQlKBlock;
+  const int64_t full_blocks = K / kQlKBlock;
+
+  for (int m0 = 0; m0 < M; m0 += 16 * MT) {
+    i32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = i32x4{0, 0, 0, 0};
+    const int8_t* arow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) arow[t] = a + (int64_t)min(m0 + 16 * t + r, M - 1) * K;
+
+    i32x4 wf0[4], wf1[4], af0[MT][4], af1[MT][4];       // two register buffers, swapped by unrolling
+    // blocks walk K from different starting points so that they do not all ask L2 for the same lines of A at once
+    const int64_t rot = full_blocks ? (int64_t)blockIdx.x % full_blocks : 0;
+    auto fetch = [&](int64_t i, i32x4* wf, i32x4 (*af)[4]) {            // i-th full K block of this wave
+      int64_t kblk = wave + i * kQlWaves + rot;
+      if (kblk >= full_blocks) kblk -= full_blocks;
+      const int64_t k = kblk * kQlKBlock + 16 * g;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#ifdef MCTQ_QL_ABLATE_A                      // timing experiment (tools/kbench_ql.hip): no activation traffic
+#pragma unroll
+        for (int p = 0; p < 4; ++p) af[t][p] = i32x4{t, p, t, p};
+#else
+        ql_load_row<false, true>(arow[t], k, K, af[t]);
+#endif
+      }
+      ql_load_row<W_NT, true>(wrow, k, K, wf);      // L2-resident activations first, the HBM stream behind them
+    };
+    auto multiply = [&](const i32x4* wf, const i32x4 (*af)[4]) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          i32x4 av = af[t][p];
+          if constexpr (A_U8) av = av ^ (int)0x80808080;          // u8 code c -> int8 (c - 128)
+#ifdef MCTQ_QL_ABLATE_MFMA                   // timing experiment: loads only
+          acc[t] += av ^ wf[p];
+#else
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wf[p], acc[t], 0, 0, 0);
+#endif
+        }
+      }
+    };
+    // full K blocks wave, wave + W, ...: straight-line loads, next block in flight while this one multiplies
+    const int64_t n_i = full_blocks > wave ? (full_blocks - wave + kQlWaves - 1) / kQlWaves : 0;
+    int64_t i = 0;
+    if (n_i > 0) fetch(0, wf0, af0);
+    while (i + 2 < n_i) {
+      fetch(i + 1, wf1, af1);
+      multiply(wf0, af0);
+      fetch(i + 2, wf0, af0);
+      multiply(wf1, af1);
+      i += 2;
+    }
+    if (n_i - i == 2) {
+      fetch(i + 1, wf1, af1);
+      multiply(wf0, af0);
+      multiply(wf1, af1);
+    } else if (n_i - i == 1) {
+      multiply(wf0, af0);
+    }
+    if (full_blocks != kblocks && wave == kQlWaves - 1) {          // ragged end of K: guarded loads, one wave
+      const int64_t k = full_blocks * kQlKBlock + 16 * g;
+      ql_load_row<W_NT, false>(wrow, k, K, wf0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) ql_load_row<false, false>(arow[t], k, K, af0[t]);
+      multiply(wf0, af0);
+    }
+
+    // partial sums of the 8 waves meet in LDS
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wave][t][lane][i] = acc[t][i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < MT * 256; e += kQlThreads) {
+      const int t = e >> 8, rem = e & 255;
+      const int mi = rem >> 4, ni = rem & 15;                    // row / column inside the 16 x 16 tile
+      const int src_lane = (mi >> 2) * 16 + ni, src_reg = mi & 3;  // C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+      int v = 0;
+#pragma unroll
+      for (int wv = 0; wv < kQlWaves; ++wv) v += red[wv][t][src_lane][src_reg];
+      const int m = m0 + 16 * t + mi, n = n0 + ni;
+      if (m < M && n < N) {
+        v -= za * w_rowsum[n];
+        float out = (float)v * (sa * w_scales[n]);
+        if (bias) out = out + bias[n];
+        y[(int64_t)m * N + n] = out;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int WAVES, int MT, bool A_U8>
+static int launch_qlinear(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
+                          const float* bias, float* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                          hipStream_t stream) {
+  const dim3 grid((unsigned)((N + 15) / 16));
+  const bool one_pass = M <= 16 * MT;             // weights read exactly once: keep them out of the caches
+  if (one_pass)
+    hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, true>), grid, dim3(WAVES * 64), 0, stream,
+                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa);
+  else
+    hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, false>), grid, dim3(WAVES * 64), 0, stream,
+                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa);
+  return check_launch("mctq_qlinear_i8");
+}
+
+}  // namespace mctq
+
+using namespace mctq;
+
+extern "C" {
+
+int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                    const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                    float* y, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return fail_arg("negative extent");
+  if (a_code_dtype != MCTQ_CODE_I8 && a_code_dtype != MCTQ_CODE_U8) return fail_arg("bad a_code_dtype");
+  if (M == 0 || N == 0) return 0;
+  if (!a_codes || !w_codes || !w_scales || !w_rowsum || !y) return fail_arg("NULL pointer");
+  if (K % 16 != 0) return fail_arg("K must be a multiple of 16");
+  if ((((uintptr_t)a_codes | (uintptr_t)w_codes) & 15u) != 0) return fail_arg("code matrices must be 16-byte aligned");
+  if (K > (1 << 15)) return fail_arg("K > 32768 could overflow the int32 accumulator");
+  if (M > INT32_MAX / 2 || N > INT32_MAX / 2) return fail_arg("M or N too large");
+  const bool u8 = a_code_dtype == MCTQ_CODE_U8;
+  const int za = u8 ? a_zero_point - 128 : a_zero_point;
+  const hipStream_t s = (hipStream_t)stream;
+#define MCTQ_QL(W_, MT_)                                                                                         \
+  (u8 ? launch_qlinear<W_, MT_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s)    \
+      : launch_qlinear<W_, MT_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s))
+  switch (g_ql_variant) {                           // experiments (mctq_set_tuning "ql_variant")
+    case 81: return MCTQ_QL(8, 1);
+    case 82: return MCTQ_QL(8, 2);
+    case 84: return MCTQ_QL(8, 4);
+    case 41: return MCTQ_QL(4, 1);
+    case 42: return MCTQ_QL(4, 2);
+    case 44: return MCTQ_QL(4, 4);
+    default: break;
+  }
+  if (M <= 16) return MCTQ_QL(8, 1);
+  if (M <= 32) return MCTQ_QL(8, 2);
+  return MCTQ_QL(8, 4);
+#undef MCTQ_QL
+}
+
+}  // extern "C"

@@ -347,3 +347,24 @@ def export_activation_uniform(x, num_bits: int, min_range: float, max_range: flo
     a, b = adjust_range_to_include_zero_f64(min_range, max_range, num_bits)
     step = (b - a) / (2 ** num_bits - 1)
     return export_grid(x, a, b, step, shifted=True)
+
+
+# --------------------------------------------------------------------------
+# integer consumer of the codes (extension: no counterpart in the reference)
+# --------------------------------------------------------------------------
+
+def qlinear_i8(a_codes: np.ndarray, a_zero_point: int, a_scale: float, w_codes: np.ndarray, w_scales,
+               bias=None) -> np.ndarray:
+    """y[m][n] = float32(sum_k (a[m][k] - za) * w[n][k]) * (float32(sa) * sw[n]) (+ bias[n]); exact integer sum,
+    one rounding per float32 operation -- the contract of include/mctq_hip.h: mctq_qlinear_i8.
+
+    It evaluates what PytorchQuantizationWrapper.forward (quantize_wrapper.py:231-257) computes for a wrapped
+    torch.nn.Linear fed by an activation holder, F.linear(fake_quant(x), fake_quant(W), bias), on the clamp
+    indices instead of the dequantized float32 values (the two differ by float32 rounding of the long sum)."""
+    acc = (np.asarray(a_codes).astype(np.int64) - int(a_zero_point)) @ np.asarray(w_codes).astype(np.int64).T
+    assert np.all(np.abs(acc) < 2 ** 31)
+    sc = (F32(a_scale) * np.asarray(w_scales, dtype=F32).reshape(-1)).astype(F32)
+    y = (acc.astype(np.int32).astype(F32) * sc[None, :]).astype(F32)
+    if bias is not None:
+        y = (y + np.asarray(bias, dtype=F32)[None, :]).astype(F32)
+    return y

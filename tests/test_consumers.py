@@ -1,0 +1,225 @@
+"""Integer consumer of the codes (mctq_qlinear_i8 / consumers.QuantizedLinear).
+
+Oracle: exact int64 product of the codes, scaled once in float32 (oracle/mctq_oracle.py::qlinear_i8).  Bar: the
+kernel is bit-identical to it for every shape / tail / code type / launch variant; against the reference-style
+float32 path (fake-quant both operands, F.linear) it agrees to the float32 rounding of that path's long sum.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal, first_mismatch
+
+
+def _problem(rng, M, N, K, u8, with_bias=True):
+    a = rng.integers(0, 256, (M, K)).astype(np.uint8) if u8 else rng.integers(-128, 128, (M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    za = int(rng.integers(0, 256)) if u8 else int(rng.integers(-128, 128))
+    sa = float(rng.uniform(0.001, 0.1))
+    ws = rng.uniform(0.001, 0.1, N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if with_bias else None
+    return a, za, sa, w, ws, bias
+
+
+def _model(K=64, N=24, bits_w=8, bits_a=8, per_channel=True, act="uniform", seed=0):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(seed)
+    lin = torch.nn.Linear(K, N)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if per_channel:
+            thr = [float(v) for v in lin.weight.detach().abs().max(1).values]
+            wq = Q.WeightsSymmetricInferableQuantizer(num_bits=bits_w, threshold=thr, per_channel=True, channel_axis=0)
+        else:
+            wq = Q.WeightsPOTInferableQuantizer(num_bits=bits_w, threshold=[0.25], per_channel=False)
+        if act == "uniform":
+            aq = Q.ActivationUniformInferableQuantizer(num_bits=bits_a, min_range=[-2.5], max_range=[3.1])
+        elif act == "signed":
+            aq = Q.ActivationSymmetricInferableQuantizer(num_bits=bits_a, threshold=[3.3], signed=True)
+        else:
+            aq = Q.ActivationPOTInferableQuantizer(num_bits=bits_a, threshold=[4.0], signed=False)
+    return torch.nn.Sequential(mq.PytorchActivationQuantizationHolder(aq),
+                               mq.PytorchQuantizationWrapper(lin, {"weight": wq}))
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU
+# ------------------------------------------------------------------------------------------------
+
+def test_oracle_is_the_exact_product_of_the_dequantized_operands():
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(3)
+    for u8 in (False, True):
+        a, za, sa, w, ws, bias = _problem(rng, 9, 20, 96, u8)
+        y = O.qlinear_i8(a, za, sa, w, ws, bias)
+        exact = ((a.astype(np.float64) - za) * np.float32(sa).astype(np.float64)) @ (w.astype(np.float64) * ws.astype(np.float64)[:, None]).T + bias
+        assert np.allclose(y, exact, rtol=3e-7, atol=1e-6 * np.abs(exact).max())
+
+
+@pytest.mark.parametrize("act", ["uniform", "signed", "unsigned_pot"])
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_quantized_linear_on_cpu_matches_oracle_and_reference_path(act, per_channel):
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd import consumers
+    from mct_quantizers_amd.hip import ops
+    model = _model(act=act, per_channel=per_channel)
+    x = torch.randn(3, 5, 64) * 1.5
+    ref = model(x)                                                  # fake-quant + float32 F.linear
+    assert consumers.fuse_linear_consumers(model) == 1
+    ql = model[1]
+    assert isinstance(model[0], torch.nn.Identity) and isinstance(ql, consumers.QuantizedLinear)
+    y = model(x)
+    assert y.shape == ref.shape == (3, 5, 24)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=2e-6 * float(ref.detach().abs().max()))
+    a_codes = ops.fq_codes(x.reshape(-1, 64), None, None, None, ql._a_qmin, ql._a_qmax, ql._a_scale, ql._a_zp)
+    want = O.qlinear_i8(a_codes.numpy(), ql._a_zp, ql._a_scale, ql._w_codes.numpy(), ql._w_scales.numpy(),
+                        ql.bias.detach().numpy())
+    assert bits_equal(y.detach().reshape(-1, 24).numpy(), want)
+
+
+def test_weight_codes_follow_in_place_weight_updates():
+    from mct_quantizers_amd import consumers
+    model = _model()
+    consumers.fuse_linear_consumers(model)
+    ql = model[1]
+    x = torch.randn(4, 64)
+    y0 = model(x)
+    codes0 = ql._w_codes.clone()
+    with torch.no_grad():
+        ql.weight.mul_(0.5)
+    y1 = model(x)
+    assert not torch.equal(codes0, ql._w_codes) and not torch.equal(y0, y1)
+
+
+def test_fuse_leaves_unsupported_pairs_alone():
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd import consumers
+    Q = mq.pytorch_quantizers
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        aq = Q.ActivationSymmetricInferableQuantizer(num_bits=8, threshold=[2.0], signed=True)
+        conv = mq.PytorchQuantizationWrapper(torch.nn.Conv2d(3, 4, 3), {"weight": Q.WeightsSymmetricInferableQuantizer(
+            num_bits=8, threshold=[1.0], per_channel=False)})
+        odd = mq.PytorchQuantizationWrapper(torch.nn.Linear(24, 8), {"weight": Q.WeightsSymmetricInferableQuantizer(
+            num_bits=8, threshold=[1.0], per_channel=False)})                    # K % 16 != 0
+        uni = mq.PytorchQuantizationWrapper(torch.nn.Linear(32, 8), {"weight": Q.WeightsUniformInferableQuantizer(
+            num_bits=8, min_range=[-1.0], max_range=[1.0], per_channel=False)})   # zero point != 0
+    model = torch.nn.Sequential(mq.PytorchActivationQuantizationHolder(aq), conv,
+                                torch.nn.Sequential(mq.PytorchActivationQuantizationHolder(aq), odd),
+                                torch.nn.Sequential(mq.PytorchActivationQuantizationHolder(aq), uni))
+    assert consumers.fuse_linear_consumers(model) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------
+
+def _run_kernel(lib, native, a, u8, za, sa, w, ws, bias):
+    from oracle import mctq_oracle as O  # noqa: F401
+    dev = torch.device("cuda")
+    M, K = a.shape
+    N = w.shape[0]
+    at, wt, wst = (torch.from_numpy(v).to(dev) for v in (a, w, ws))
+    rs = wt.sum(dim=1, dtype=torch.int32)
+    bt = None if bias is None else torch.from_numpy(bias).to(dev)
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    rc = lib.mctq_qlinear_i8(at.data_ptr(), native.CODE_U8 if u8 else native.CODE_I8, za, sa, wt.data_ptr(), wst.data_ptr(),
+                             rs.data_ptr(), None if bt is None else bt.data_ptr(), y.data_ptr(), M, N, K,
+                             torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.mctq_last_error()
+    return y.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 41, 42, 44, 81, 82, 84])
+def test_qlinear_kernel_is_bit_exact_against_the_integer_oracle(variant):
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd.hip import native
+    lib = native.load()
+    rng = np.random.default_rng(100 + variant)
+    assert lib.mctq_set_tuning(b"ql_variant", variant) == 0
+    try:
+        shapes = [(1, 16, 16), (5, 100, 256), (16, 33, 272), (17, 16, 4096), (33, 64, 2048), (64, 4096, 1024),
+                  (100, 48, 11008), (7, 1000, 4112), (130, 20, 528), (2, 3, 32768)]
+        for (M, N, K) in shapes:
+            for u8 in (False, True):
+                a, za, sa, w, ws, bias = _problem(rng, M, N, K, u8, with_bias=(M + N) % 2 == 1)
+                if K == 32768:                                  # extreme codes: the accumulator's worst case
+                    a[:] = 255 if u8 else -128
+                    w[:] = -128
+                    za = 0 if u8 else 127
+                got = _run_kernel(lib, native, a, u8, za, sa, w, ws, bias)
+                want = O.qlinear_i8(a, za, sa, w, ws, bias)
+                assert bits_equal(got, want), f"variant {variant} M={M} N={N} K={K} u8={u8}: {first_mismatch(got, want)}"
+    finally:
+        lib.mctq_set_tuning(b"ql_variant", 0)
+
+
+@pytest.mark.gpu
+def test_qlinear_rejects_bad_arguments():
+    from mct_quantizers_amd.hip import native
+    lib = native.load()
+    dev = torch.device("cuda")
+    a = torch.zeros(4, 64, dtype=torch.int8, device=dev)
+    w = torch.zeros(8, 64, dtype=torch.int8, device=dev)
+    s = torch.ones(8, device=dev)
+    r = torch.zeros(8, dtype=torch.int32, device=dev)
+    y = torch.zeros(4, 8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    E = native.MCTQ_E_ARG
+    call = lambda *args: lib.mctq_qlinear_i8(*args)   # noqa: E731
+    assert call(a.data_ptr(), native.CODE_I8, 0, 1.0, w.data_ptr(), s.data_ptr(), r.data_ptr(), None, y.data_ptr(), 4, 8, 24, st) == E
+    assert b"multiple of 16" in lib.mctq_last_error()
+    assert call(a.data_ptr(), 77, 0, 1.0, w.data_ptr(), s.data_ptr(), r.data_ptr(), None, y.data_ptr(), 4, 8, 64, st) == E
+    assert call(a.data_ptr() + 1, native.CODE_I8, 0, 1.0, w.data_ptr(), s.data_ptr(), r.data_ptr(), None, y.data_ptr(), 4, 8, 64, st) == E
+    assert call(a.data_ptr(), native.CODE_I8, 0, 1.0, w.data_ptr(), s.data_ptr(), r.data_ptr(), None, y.data_ptr(), 4, 8, 65536, st) == E
+    assert call(a.data_ptr(), native.CODE_I8, 0, 1.0, None, s.data_ptr(), r.data_ptr(), None, y.data_ptr(), 4, 8, 64, st) == E
+    assert call(None, native.CODE_I8, 0, 1.0, None, None, None, None, None, 0, 8, 64, st) == 0        # empty
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ["uniform", "signed", "unsigned_pot"])
+@pytest.mark.parametrize("K,N,batch", [(64, 24, (3, 5)), (4096, 512, (64,)), (1024, 1000, (1,))])
+def test_quantized_linear_on_gpu(act, K, N, batch):
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd import consumers
+    model = _model(K=K, N=N, act=act).cuda()
+    x = (torch.randn(*batch, K) * 1.5).cuda()
+    ref = model(x)                                                  # HIP fake-quant kernels + float32 GEMM
+    assert consumers.fuse_linear_consumers(model) == 1
+    ql = model[1]
+    y = model(x)
+    assert y.is_cuda and y.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert torch.allclose(y, ref, rtol=1e-4, atol=3e-6 * scale * (K / 64) ** 0.5), float((y - ref).abs().max())
+    # and bit-exact against the oracle on the codes the module produced
+    from mct_quantizers_amd.hip import ops
+    a_codes = ops.fq_codes(x.reshape(-1, K), None, None, None, ql._a_qmin, ql._a_qmax, ql._a_scale, ql._a_zp)
+    want = O.qlinear_i8(a_codes.cpu().numpy(), ql._a_zp, ql._a_scale, ql._w_codes.cpu().numpy(),
+                        ql._w_scales.cpu().numpy(), ql.bias.detach().cpu().numpy())
+    got = y.detach().reshape(-1, N).cpu().numpy()
+    assert bits_equal(got, want), first_mismatch(got, want)
+
+
+@pytest.mark.gpu
+def test_quantized_linear_replays_in_a_hip_graph():
+    from mct_quantizers_amd import consumers
+    model = _model(K=1024, N=256).cuda()
+    consumers.fuse_linear_consumers(model)
+    x = torch.randn(16, 1024, device="cuda")
+    want = model(x)
+    static_x = x.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        model(static_x)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = model(static_x)
+    static_x.copy_(x * 0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, model(x * 0.5)) and not torch.equal(out, want)

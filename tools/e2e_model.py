@@ -46,6 +46,18 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
             for q in mod.weights_quantizers.values():
                 q.enable_versioned_reuse()
     reuse, y3 = timeit(m3, x)
+    # integer consumers: every (activation holder, wrapped Linear) pair runs on the codes (mctq_qlinear_i8)
+    from mct_quantizers_amd import consumers
+    m4 = build(layers, d, False)
+    nf = consumers.fuse_linear_consumers(m4)
+    fused, y4 = timeit(m4, x)
+    # later layers amplify single quantization-step flips; compare where the two paths first differ: after the
+    # first fused pair (wrapped Linear 0, holder 0 / QuantizedLinear 1)
+    with torch.no_grad():
+        r3 = build(layers, d, False)[:3](x)
+        f3 = m4[:3](x)
+    err = float((f3 - r3).abs().max() / r3.abs().max())
     print(f"{layers} x Linear({d},{d}) batch {batch}: this package {ours:7.3f} ms/forward, ATen fake-quant ops {aten:7.3f} ms/forward "
-          f"(x{aten/ours:.2f}), with versioned weight reuse {reuse:7.3f} ms; outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3)}",
+          f"(x{aten/ours:.2f}), with versioned weight reuse {reuse:7.3f} ms; outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3)}; "
+          f"{nf} layer pairs on integer codes {fused:7.3f} ms (x{aten/fused:.2f} vs ATen path, max rel diff after the first pair {err:.1e})",
           flush=True)
