@@ -166,6 +166,160 @@ static int launch_qlinear(const void* a, const int8_t* w, const float* w_scales,
   return check_launch("mctq_qlinear_i8");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large row counts (M > 64): a conventional LDS-tiled product.  Block tile BM x BN over K in steps of 128 bytes,
+// 4 waves in a 2 x 2 arrangement, each wave (BM/2) x (BN/2) as 16 x 16 MFMA tiles; operands staged through LDS
+// (double buffered, next tile's global loads in flight while the current one multiplies).  Tiles are stored as
+// 16-byte chunks, chunk c of row r at slot c ^ ((r >> 1) & 7): the 16 lanes that read one k position of 16
+// consecutive rows then touch 16 different bank groups.
+// ------------------------------------------------------------------------------------------------
+template <int CPR>
+__device__ __forceinline__ int ql_swizzle(int row) {            // CPR = 16-byte chunks per tile row
+  if constexpr (CPR == 8) return (row >> 1) & 7;                // 128-byte rows: two rows span the 64 banks
+  else return row & (CPR - 1);                                  // 256-byte rows: every row starts on bank 0
+}
+
+template <int BM, int BN, int kTileBK, bool A_U8>
+__global__ __launch_bounds__(256) void qgemm_i8_tiled_kernel(
+    const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, float* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks) {
+  constexpr int TM = BM / 32, TN = BN / 32;          // 16 x 16 tiles per wave in each direction
+  constexpr int CPR = kTileBK / 16;                  // 16-byte chunks per tile row
+  constexpr int LA = BM * CPR / 256, LB = BN * CPR / 256;   // chunks each thread moves per tile
+  __shared__ i32x4 lds_a[2][BM * CPR];
+  __shared__ i32x4 lds_b[2][BN * CPR];
+
+  // consecutive block ids go round-robin over the 8 XCDs: give each XCD a contiguous range of tiles so that
+  // its L2 sees the same rows of A again and again
+  const int total = m_blocks * n_blocks;
+  int id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int mb = id / n_blocks, nb = id - mb * n_blocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  // global -> register staging: chunk q = tid + 256 j of the tile: row q / 8, chunk q % 8
+  const int8_t* ga[LA];
+  const int8_t* gb[LB];
+  int sa_slot[LA], sb_slot[LB], ca[LA], cb[LB];
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int q = tid + 256 * j, row = q / CPR, c = q % CPR;
+    ga[j] = a + (int64_t)min(m0 + row, M - 1) * K + 16 * c;
+    sa_slot[j] = row * CPR + (c ^ ql_swizzle<CPR>(row));
+    ca[j] = 16 * c;
+  }
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int q = tid + 256 * j, row = q / CPR, c = q % CPR;
+    gb[j] = w + (int64_t)min(n0 + row, N - 1) * K + 16 * c;
+    sb_slot[j] = row * CPR + (c ^ ql_swizzle<CPR>(row));
+    cb[j] = 16 * c;
+  }
+
+  i32x4 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) acc[t][u] = i32x4{0, 0, 0, 0};
+
+  i32x4 ra[LA], rb[LB];
+  const i32x4 zero = {0, 0, 0, 0};
+  auto gload = [&](int64_t k0) {
+    if (k0 + kTileBK <= K) {
+#pragma unroll
+      for (int j = 0; j < LA; ++j) ra[j] = *reinterpret_cast<const i32x4*>(ga[j] + k0);
+#pragma unroll
+      for (int j = 0; j < LB; ++j) rb[j] = *reinterpret_cast<const i32x4*>(gb[j] + k0);
+    } else {                                      // ragged end of K (K % 16 == 0): missing chunks are zero
+#pragma unroll
+      for (int j = 0; j < LA; ++j) ra[j] = (k0 + ca[j] < K) ? *reinterpret_cast<const i32x4*>(ga[j] + k0) : zero;
+#pragma unroll
+      for (int j = 0; j < LB; ++j) rb[j] = (k0 + cb[j] < K) ? *reinterpret_cast<const i32x4*>(gb[j] + k0) : zero;
+    }
+  };
+  auto lstore = [&](int buf, bool ragged, int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      i32x4 v = ra[j];
+      if constexpr (A_U8) {                      // u8 code c -> int8 (c - 128); padding must stay 0 - (za - 128)... see below
+        v = v ^ (int)0x80808080;
+        if (ragged && !(k0 + ca[j] < K)) v = zero;
+      }
+      lds_a[buf][sa_slot[j]] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) lds_b[buf][sb_slot[j]] = rb[j];
+  };
+
+  const int64_t kt_n = (K + kTileBK - 1) / kTileBK;
+  gload(0);
+  lstore(0, kTileBK > K, 0);
+  __syncthreads();
+  for (int64_t kt = 0; kt < kt_n; ++kt) {
+    const int buf = (int)(kt & 1);
+    const bool more = kt + 1 < kt_n;
+    if (more) gload((kt + 1) * (int64_t)kTileBK);
+#pragma unroll
+    for (int ks = 0; ks < kTileBK / 64; ++ks) {
+      i32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int row = wm * (BM / 2) + 16 * t + r;
+        fa[t] = lds_a[buf][row * CPR + ((ks * 4 + g) ^ ql_swizzle<CPR>(row))];
+      }
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        const int row = wn * (BN / 2) + 16 * u + r;
+        fb[u] = lds_b[buf][row * CPR + ((ks * 4 + g) ^ ql_swizzle<CPR>(row))];
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], acc[t][u], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1, (kt + 2) * kTileBK > K, (kt + 1) * kTileBK);
+    __syncthreads();
+  }
+
+  // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int n = n0 + wn * (BN / 2) + 16 * u + r;
+    if (n >= N) continue;
+    const int corr = za * w_rowsum[n];
+    const float sc = sa * w_scales[n];
+    const float bs = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * (BM / 2) + 16 * t + 4 * g + i;
+        if (m < M) {
+          float out = (float)(acc[t][u][i] - corr) * sc;
+          if (bias) out = out + bs;
+          y[(int64_t)m * N + n] = out;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, bool A_U8>
+static int launch_tiled(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
+                        const float* bias, float* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                        hipStream_t stream) {
+  const int mbl = (int)((M + BM - 1) / BM), nbl = (int)((N + BN - 1) / BN);
+  hipLaunchKernelGGL((qgemm_i8_tiled_kernel<BM, BN, BK, A_U8>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl);
+  return check_launch("mctq_qlinear_i8 (tiled)");
+}
+
 }  // namespace mctq
 
 using namespace mctq;
@@ -198,9 +352,27 @@ int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_po
     case 44: return MCTQ_QL(4, 4);
     default: break;
   }
+#define MCTQ_QT(BM_, BN_, BK_)                                                                                     \
+  (u8 ? launch_tiled<BM_, BN_, BK_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s)  \
+      : launch_tiled<BM_, BN_, BK_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s))
+  switch (g_ql_variant) {
+    case 1212: return MCTQ_QT(128, 128, 128);
+    case 612: return MCTQ_QT(64, 128, 128);
+    case 66: return MCTQ_QT(64, 64, 128);
+    case 662: return MCTQ_QT(64, 64, 256);
+    case 6122: return MCTQ_QT(64, 128, 256);
+    default: break;
+  }
   if (M <= 16) return MCTQ_QL(8, 1);
   if (M <= 32) return MCTQ_QL(8, 2);
-  return MCTQ_QL(8, 4);
+  if (M <= 128) return MCTQ_QL(8, 4);
+  {                                                  // tiled: the largest tile that still gives every CU two blocks
+    const int64_t cus = cu_count();
+    if (((M + 127) / 128) * ((N + 127) / 128) >= 2 * cus) return MCTQ_QT(128, 128, 128);
+    if (((M + 63) / 64) * ((N + 63) / 64) >= 2 * cus) return MCTQ_QT(64, 64, 128);
+    return MCTQ_QT(64, 64, 256);                     // few blocks: longer K steps hide the load latency instead
+  }
+#undef MCTQ_QT
 #undef MCTQ_QL
 }
 

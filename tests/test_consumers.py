@@ -134,7 +134,7 @@ def _run_kernel(lib, native, a, u8, za, sa, w, ws, bias):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 41, 42, 44, 81, 82, 84])
+@pytest.mark.parametrize("variant", [0, 41, 42, 44, 81, 82, 84, 1212, 612, 66, 662, 6122])
 def test_qlinear_kernel_is_bit_exact_against_the_integer_oracle(variant):
     from oracle import mctq_oracle as O
     from mct_quantizers_amd.hip import native
@@ -143,7 +143,8 @@ def test_qlinear_kernel_is_bit_exact_against_the_integer_oracle(variant):
     assert lib.mctq_set_tuning(b"ql_variant", variant) == 0
     try:
         shapes = [(1, 16, 16), (5, 100, 256), (16, 33, 272), (17, 16, 4096), (33, 64, 2048), (64, 4096, 1024),
-                  (100, 48, 11008), (7, 1000, 4112), (130, 20, 528), (2, 3, 32768)]
+                  (100, 48, 11008), (7, 1000, 4112), (130, 20, 528), (2, 3, 32768), (129, 130, 144), (300, 257, 1040),
+                  (512, 256, 4096)]
         for (M, N, K) in shapes:
             for u8 in (False, True):
                 a, za, sa, w, ws, bias = _problem(rng, M, N, K, u8, with_bias=(M + N) % 2 == 1)
