@@ -247,7 +247,7 @@ int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_po
  *   key "cached_store_max_mb" : with nt = 1, outputs of at most this many MiB are stored through the caches
  *                  (mode 2) so that a consumer launched right after finds them in L2 / the Infinity Cache; default 32, 0 = never
  *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
- *   key "ql_variant" : mctq_qlinear_i8 launch shape, <waves per block><16-row tiles per pass> (41 ... 84); 0 = automatic
+ *   key "ql_variant" : mctq_qlinear_i8 launch shape, <waves per block><16-row tiles per pass> (41 ... 84) or a tile (1212, 612, 66, 662, 12122); 0 = automatic
  *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */

@@ -1,12 +1,14 @@
 // mctq_kernels.hpp -- gfx950 (MI355X / CDNA4) kernels and launch helpers of libmctq_hip.so.
-// Included by the translation units that hold the C ABI (mctq_affine.hip, mctq_codes.hip,
-// mctq_lut_scan.hip, mctq_lut_table.hip, mctq_misc.hip); they are compiled in parallel and linked into one library.
+// Included by the translation units that hold the C ABI (mctq_affine.hip, mctq_codes.hip, mctq_grid.hip,
+// mctq_lut_scan.hip, mctq_lut_table.hip, mctq_misc.hip; mctq_qlinear.hip uses only the shared helpers); they are
+// compiled in parallel and linked into one library.
 //
 // Hot path of sony/mct_quantizers' PyTorch inferable quantizers, written for CDNA4:
 // one fused load -> scale -> round-half-even -> clamp -> dequant -> store pass (8 algorithmic
 // bytes per float32 element) for the affine quantizers, and one fused divide -> clamp -> codebook
 // decision -> dequant pass for the LUT quantizers.  The work is elementwise and HBM-bound, so
-// there is no MFMA here; what matters is 16-byte-per-lane coalesced traffic (1 KiB per wave
+// there is no MFMA here (the one matrix-core kernel, the integer consumer of the codes, lives in
+// mctq_qlinear.hip); what matters is 16-byte-per-lane coalesced traffic (1 KiB per wave
 // instruction), enough loads in flight per lane, and keeping the per-channel parameters out of the
 // vector memory pipe (SGPR broadcast or an LDS window).
 //

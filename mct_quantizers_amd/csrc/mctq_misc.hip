@@ -98,9 +98,10 @@ int mctq_set_tuning(const char* key, int32_t value) {
     return 0;
   }
   if (!strcmp(key, "ql_variant")) {
-    if (value != 0 && value != 41 && value != 42 && value != 44 && value != 81 && value != 82 && value != 84 &&
-        value != 1212 && value != 612 && value != 66 && value != 662 && value != 6122)
-      return fail_arg("ql_variant must be 0, <waves><row tiles> (41, 42, 44, 81, 82, 84) or a tile (1212, 612, 66, 662, 6122)");
+    static const int ok[] = {0, 41, 42, 44, 81, 82, 84, 1212, 612, 66, 662, 12122};
+    bool found = false;
+    for (int v : ok) found = found || v == value;
+    if (!found) return fail_arg("ql_variant must be 0, <waves><row tiles> (41 ... 84) or a tile (1212, 612, 66, 662, 12122)");
     g_ql_variant = value;
     return 0;
   }
