@@ -721,33 +721,39 @@ __global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op:
 
 // ------------------------------------------------------------------------------------------
 // lastaxis: the channel axis is the fastest-varying one (inner == 1: NHWC activations, [tokens, hidden],
-// weights quantized along their last axis) and C % N == 0.  Every element has its own parameters, so no
-// staging can amortise them; a lane's N consecutive elements are N consecutive channels and their
-// parameters are fetched with 16-byte loads straight from the (L1/L2-resident) tables.
+// weights quantized along their last axis) and C % N == 0.  A lane's N consecutive elements are N
+// consecutive channels.  The lanes of `bps` neighbouring blocks are laid over k whole rows (k * vc lane
+// vectors, contiguous in memory) and step DOWN the tensor k rows at a time, so every lane keeps the same N
+// channels: their parameters are fetched (16-byte table loads) and inverted once per lane, not per element.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, int NT, typename IdxT>
-__global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT nv,
-                                                            uint32_t channels) {
+template <class Op, class TI, class TO, int U, int NT>
+__global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
+                                                            uint64_t rows, uint32_t vc, uint32_t k, uint32_t bps) {
   typedef IO<TI, TO> io;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const IdxT base = (IdxT)blockIdx.x * (kThreads * U) + threadIdx.x;
+  const uint32_t g = (blockIdx.x % bps) * kThreads + threadIdx.x;      // lane inside the k-row group
+  const uint32_t ro = g / vc, col = g - ro * vc;
+  const bool lane_ok = ro < k;
+  const uint64_t row0 = (uint64_t)(blockIdx.x / bps) * ((uint64_t)U * k) + ro;
   typename io::VI v[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (base + u * kThreads < nv) v[u] = io::template load<NT>(xs + (base + u * kThreads) * io::N);
+  for (int u = 0; u < U; ++u) {
+    const uint64_t row = row0 + (uint64_t)u * k;
+    if (lane_ok && row < rows) v[u] = io::template load<NT>(xs + (row * vc + col) * io::N);
+  }
   const typename Op::Book book = op.setup(smem);
+  if (!lane_ok) return;
+  typename Op::Param p[io::N];
+  op.template fetch_vec<io::N>(col * io::N, p);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const IdxT i = base + u * kThreads;
-    if (i < nv) {
-      const uint32_t c0 = (uint32_t)((i * io::N) % channels);
-      typename Op::Param p[io::N];
-      op.template fetch_vec<io::N>(c0, p);
+    const uint64_t row = row0 + (uint64_t)u * k;
+    if (row < rows) {
       float in[io::N], out[io::N];
       io::unpack(v[u], in);
 #pragma unroll
       for (int j = 0; j < io::N; ++j) out[j] = op.template apply<false>(in[j], p[j], book);
-      io::template store<NT>(ys + i * io::N, io::pack(out));
+      io::template store<NT>(ys + (row * vc + col) * io::N, io::pack(out));
     }
   }
 }
@@ -1040,17 +1046,21 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
 
   // lastaxis shape.
   if (vec_ok && inner == 1 && (channels % io::N) == 0 && channels <= 0x7fffffffLL && op.tables_aligned16()) {
-    constexpr int LU = 4;
-    const int64_t nv = n / io::N;
-    const int64_t blocks = (nv + kThreads * LU - 1) / (kThreads * LU);
-    if (blocks <= 0x7fffffffLL) {
+    constexpr int LU = sizeof(TI) == 4 ? 4 : 8;
+    const int64_t vc = channels / io::N;                              // lane vectors per row
+    // rows per step: enough lanes (>= 2048) that the idle tail of the last block is small; among the next few
+    // candidates take the one that wastes the fewest lanes
+    int64_t k = (2048 + vc - 1) / vc, best_waste = -1;
+    for (int64_t c = k; c < k + 16; ++c) {
+      const int64_t waste = (kThreads - (c * vc) % kThreads) % kThreads * 4096 / (c * vc);
+      if (best_waste < 0 || waste < best_waste) { best_waste = waste; k = c; }
+    }
+    const int64_t bps = (k * vc + kThreads - 1) / kThreads;
+    const int64_t blocks = bps * ((outer + LU * k - 1) / (LU * k));
+    if (blocks <= 0x7fffffffLL && k * vc <= 0x7fffffffLL) {
       MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
-        if (nv <= 0x7fffffffLL / (int64_t)io::N)
-          hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT, uint32_t>), dim3((unsigned)blocks), dim3(kThreads),
-                             book_bytes, st, op, x, y, (uint32_t)nv, (uint32_t)channels);
-        else
-          hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT, uint64_t>), dim3((unsigned)blocks), dim3(kThreads),
-                             book_bytes, st, op, x, y, (uint64_t)nv, (uint32_t)channels);
+        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                           op, x, y, (uint64_t)outer, (uint32_t)vc, (uint32_t)k, (uint32_t)bps);
       });
       return check_launch("lastaxis launch");
     }

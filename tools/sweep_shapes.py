@@ -20,7 +20,8 @@ for dt in (torch.float32, torch.bfloat16):
                         ((16384, 1024), 0), ((16384, 1020), 0), ((65536, 256), 0), ((262144, 64), 0), ((1048576, 16), 0),
                         ((2048, 8192), 1), ((256, 65536), 0), ((8, 2097152), 0), ((1, 16777216), 0),
                         ((64, 256, 56, 56), 1), ((64, 56, 56, 256), 3), ((512, 512, 3, 3), 0), ((2048, 2048, 3, 3), 0),
-                        ((32, 3, 224, 224), 1), ((50257, 768), 0), ((50257, 768), 1)):
+                        ((32, 3, 224, 224), 1), ((50257, 768), 0), ((50257, 768), 1), ((1048576, 16), 1), ((65536, 200), 1),
+                        ((8192, 2056), 1)):
         C = shape[axis]
         q = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + (i % 97) * 0.01 for i in range(C)], True, axis)
         x = torch.randn(*shape, device="cuda").to(dt)
