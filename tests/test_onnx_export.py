@@ -204,12 +204,15 @@ def test_grid_kernel_all_float32_inputs_against_torch_cpu_chain():
     from mct_quantizers_amd.hip import ops
     lo, hi, step = np.float32(-1.3), np.float32(1.3 - 1.3 / 128), np.float32(1.3 / 128)
     lo_t, hi_t, st_t = (torch.tensor(float(v), dtype=torch.float32) for v in (lo, hi, step))
-    chunk = 1 << 26
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    chunk = 1 << 27
+    torch.set_num_threads(min(32, torch.get_num_threads()))       # more threads than that only thrash
     for start in range(0, 1 << 32, chunk):
-        bits = torch.arange(start, start + chunk, dtype=torch.int64).to(torch.int32)   # wraps to all patterns
-        x = bits.view(torch.float32)
-        y = ops.grid_per_tensor(x.cuda(), float(lo), float(hi), float(step), False).cpu()
+        bits = torch.arange(start, start + chunk, dtype=torch.int64, device="cuda").to(torch.int32)   # wraps: all patterns
+        xd = bits.view(torch.float32)
+        del bits
+        y = ops.grid_per_tensor(xd, float(lo), float(hi), float(step), False).cpu()
+        x = xd.cpu()
+        del xd
         c = torch.where(x < lo_t, lo_t, x)
         want = torch.round(torch.where(x > hi_t, hi_t, c) / st_t) * st_t
         same = (y.view(torch.int32) == want.view(torch.int32)) | (torch.isnan(y) & torch.isnan(want))
