@@ -57,6 +57,12 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
   const int8_t* wrow = w + (int64_t)min(n0 + r, N - 1) * K;
   const int64_t kblocks = (K + kQlKBlock - 1) / kQlKBlock;
   const int64_t full_blocks = K / kQlKBlock;
+  // this thread's output column in the epilogue is fixed (block size % 16 == 0): fetch its constants now, not
+  // at the end of the dependency chain
+  const int en = min(n0 + (int)(threadIdx.x & 15), N - 1);
+  const int e_corr = za * w_rowsum[en];
+  const float e_scale = sa * w_scales[en];
+  const float e_bias = bias ? bias[en] : 0.0f;
 
   for (int m0 = 0; m0 < M; m0 += 16 * MT) {
     i32x4 acc[MT];
@@ -141,9 +147,8 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
       for (int wv = 0; wv < kQlWaves; ++wv) v += red[wv][t][src_lane][src_reg];
       const int m = m0 + 16 * t + mi, n = n0 + ni;
       if (m < M && n < N) {
-        v -= za * w_rowsum[n];
-        float out = (float)v * (sa * w_scales[n]);
-        if (bias) out = out + bias[n];
+        float out = (float)(v - e_corr) * e_scale;
+        if (bias) out = out + e_bias;
         y[(int64_t)m * N + n] = out;
       }
     }
@@ -237,6 +242,15 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
 
   const int64_t kt_n = (K + kTileBK - 1) / kTileBK;
   copy_tile(0, 0);
+  int e_corr[TN];                                    // epilogue constants of this lane's columns, fetched early
+  float e_scale[TN], e_bias[TN];
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int n = min(n0 + wn * (BN / 2) + 16 * u + r, N - 1);
+    e_corr[u] = za * w_rowsum[n];
+    e_scale[u] = sa * w_scales[n];
+    e_bias[u] = bias ? bias[n] : 0.0f;
+  }
   for (int64_t kt = 0; kt < kt_n; ++kt) {
     const int buf = (int)(kt & 1);
     __syncthreads();                                  // tile kt has landed; buffer buf ^ 1 is free
@@ -267,17 +281,14 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
   for (int u = 0; u < TN; ++u) {
     const int n = n0 + wn * (BN / 2) + 16 * u + r;
     if (n >= N) continue;
-    const int corr = za * w_rowsum[n];
-    const float sc = sa * w_scales[n];
-    const float bs = bias ? bias[n] : 0.0f;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * (BM / 2) + 16 * t + 4 * g + i;
         if (m < M) {
-          float out = (float)(acc[t][u][i] - corr) * sc;
-          if (bias) out = out + bs;
+          float out = (float)(acc[t][u][i] - e_corr[u]) * e_scale[u];
+          if (bias) out = out + e_bias[u];
           y[(int64_t)m * N + n] = out;
         }
       }
