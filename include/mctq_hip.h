@@ -241,6 +241,18 @@ int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_po
                     float* y, int64_t M, int64_t N, int64_t K, void* stream);
 
 /*
+ * Same product, but the result leaves as the NEXT layer's activation codes: the float32 value y[m][n] above is
+ * quantized in registers exactly as mctq_fq_codes_per_tensor would quantize it,
+ *     code = clamp(rint(y * (1.0f / y_scale)) + y_zero_point, y_quant_min, y_quant_max),
+ * and stored as int8 / uint8 (y_code_dtype) -- for chains activation holder -> wrapped Linear -> activation
+ * holder -> wrapped Linear, where the float32 tensor between two layers is only ever quantized again.
+ */
+int mctq_qlinear_i8_codes(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                          const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                          void* y_codes, int32_t y_code_dtype, float y_scale, int32_t y_zero_point, int32_t y_quant_min,
+                          int32_t y_quant_max, int64_t M, int64_t N, int64_t K, void* stream);
+
+/*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.
  *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default), 2 = non-temporal
  *                  loads with cached stores

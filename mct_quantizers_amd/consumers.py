@@ -36,8 +36,11 @@ def _activation_code_params(q):
 
 
 def qlinear_i8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes: torch.Tensor,
-               w_scales: torch.Tensor, w_rowsum: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """a_codes [M, K] int8/uint8, w_codes [N, K] int8 (zero point 0) -> float32 [M, N]."""
+               w_scales: torch.Tensor, w_rowsum: torch.Tensor, bias: Optional[torch.Tensor],
+               out_codes=None) -> torch.Tensor:
+    """a_codes [M, K] int8/uint8, w_codes [N, K] int8 (zero point 0) -> float32 [M, N]; with
+    ``out_codes = (scale, zero_point, qmin, qmax)`` the result leaves as the codes of that activation quantizer
+    (int8 / uint8 [M, N]), bit-identical to quantizing the float32 result with ``ops.fq_codes``."""
     M, K = a_codes.shape
     N = w_codes.shape[0]
     if w_codes.shape[1] != K:
@@ -47,19 +50,34 @@ def qlinear_i8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes
             raise NotImplementedError(f"mctq_qlinear_i8 needs K % 16 == 0 and K <= {_MAX_K}, got K={K}")
         lib = native.load()
         a_codes, w_codes = a_codes.contiguous(), w_codes.contiguous()
-        y = torch.empty((M, N), dtype=torch.float32, device=a_codes.device)
         code = native.CODE_U8 if a_codes.dtype == torch.uint8 else native.CODE_I8
+        bias_ptr = None if bias is None else bias.data_ptr()
         with ops._maybe_on_device(a_codes):
-            rc = ops._launch(lib.mctq_qlinear_i8, a_codes.data_ptr(), code, int(a_zero_point), float(a_scale),
-                             w_codes.data_ptr(), w_scales.data_ptr(), w_rowsum.data_ptr(),
-                             None if bias is None else bias.data_ptr(), y.data_ptr(), M, N, K, ops._stream(a_codes))
+            if out_codes is None:
+                y = torch.empty((M, N), dtype=torch.float32, device=a_codes.device)
+                rc = ops._launch(lib.mctq_qlinear_i8, a_codes.data_ptr(), code, int(a_zero_point), float(a_scale),
+                                 w_codes.data_ptr(), w_scales.data_ptr(), w_rowsum.data_ptr(), bias_ptr, y.data_ptr(),
+                                 M, N, K, ops._stream(a_codes))
+            else:
+                o_scale, o_zp, o_qmin, o_qmax = out_codes
+                tdt, ocode = ops._code_dtype(o_qmin, o_qmax)
+                y = torch.empty((M, N), dtype=tdt, device=a_codes.device)
+                rc = ops._launch(lib.mctq_qlinear_i8_codes, a_codes.data_ptr(), code, int(a_zero_point), float(a_scale),
+                                 w_codes.data_ptr(), w_scales.data_ptr(), w_rowsum.data_ptr(), bias_ptr, y.data_ptr(),
+                                 ocode, float(o_scale), int(o_zp), int(o_qmin), int(o_qmax), M, N, K,
+                                 ops._stream(a_codes))
         if rc:
             native.check(rc, "mctq_qlinear_i8")
         return y
     ops._cpu_route_allowed()
     acc = (a_codes.to(torch.int32) - int(a_zero_point)) @ w_codes.to(torch.int32).t()
     y = acc.to(torch.float32) * (torch.tensor(a_scale, dtype=torch.float64).to(torch.float32) * w_scales)
-    return y if bias is None else y + bias
+    if bias is not None:
+        y = y + bias
+    if out_codes is None:
+        return y
+    o_scale, o_zp, o_qmin, o_qmax = out_codes
+    return ops.fq_codes(y, None, None, None, o_qmin, o_qmax, o_scale, o_zp)
 
 
 class QuantizedLinear(nn.Module):
@@ -87,6 +105,9 @@ class QuantizedLinear(nn.Module):
         self._a_scale, self._a_zp, self._a_qmin, self._a_qmax = _activation_code_params(activation_quantizer)
         self._w_key = None
         self._w_codes = self._w_scales = self._w_rowsum = None
+        # chaining (fuse_linear_consumers(chain=True)): parameters of the activation quantizer that would quantize
+        # this layer's output next; the output then leaves as that quantizer's codes
+        self.emit_codes_for = None
 
     @classmethod
     def from_wrapper(cls, wrapper: PytorchQuantizationWrapper, activation_quantizer) -> "QuantizedLinear":
@@ -119,16 +140,29 @@ class QuantizedLinear(nn.Module):
         self._refresh_weight_codes()
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.in_features)
-        a_codes = ops.fq_codes(x2, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
+        if x2.dtype in (torch.uint8, torch.int8):          # already this layer's activation codes (chained layers)
+            if x2.dtype != ops._code_dtype(self._a_qmin, self._a_qmax)[0]:
+                raise TypeError(f"activation codes of type {x2.dtype} do not match this layer's quantizer")
+            a_codes = x2
+        else:
+            a_codes = ops.fq_codes(x2, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
         y = qlinear_i8(a_codes, self._a_zp, self._a_scale, self._w_codes, self._w_scales, self._w_rowsum,
-                       None if self.bias is None else self.bias.detach())
+                       None if self.bias is None else self.bias.detach(), self.emit_codes_for)
         return y.reshape(*lead, self.out_features)
 
 
-def fuse_linear_consumers(model: nn.Module) -> int:
+class _FusedAway(nn.Identity):
+    """Placeholder left where an activation holder was folded into the QuantizedLinear after it."""
+
+
+def fuse_linear_consumers(model: nn.Module, chain: bool = False) -> int:
     """In every ``nn.Sequential`` of ``model``: an activation holder directly followed by a wrapped ``nn.Linear`` with
     a symmetric weights quantizer becomes (Identity, QuantizedLinear).  Returns the number of pairs replaced.
-    Pairs the integer consumer cannot take (other layers, LUT / uniform weights, K % 16 != 0) are left alone."""
+    Pairs the integer consumer cannot take (other layers, LUT / uniform weights, K % 16 != 0) are left alone.
+
+    ``chain=True``: where one QuantizedLinear feeds the next directly, the float32 tensor between them is never
+    materialised -- the first emits the second's activation codes from its epilogue (same codes, bit for bit, as
+    quantizing the float32 output).  Modules or hooks that look at that intermediate tensor then see uint8/int8 codes."""
     replaced = 0
     for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
         for i in range(len(seq) - 1):
@@ -143,7 +177,12 @@ def fuse_linear_consumers(model: nn.Module) -> int:
                 fused = QuantizedLinear.from_wrapper(wrapper, holder.activation_holder_quantizer)
             except (TypeError, NotImplementedError):
                 continue
-            seq[i] = nn.Identity()
+            seq[i] = _FusedAway()
             seq[i + 1] = fused
             replaced += 1
+        if chain:
+            for i in range(len(seq) - 2):
+                first, gap, second = seq[i], seq[i + 1], seq[i + 2]
+                if isinstance(first, QuantizedLinear) and isinstance(gap, _FusedAway) and isinstance(second, QuantizedLinear):
+                    first.emit_codes_for = (second._a_scale, second._a_zp, second._a_qmin, second._a_qmax)
     return replaced

@@ -20,6 +20,23 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQlKBlock = 256;          // bytes of K per wave step: 4 lane groups x 64 B
 extern int g_ql_variant;                // tuning hook "ql_variant": 0 = automatic
 
+// Output form: float32 values, or the next layer's activation codes (the fake-quant arithmetic of
+// mctq_fq_codes_per_tensor applied to the float32 value in registers: clamp(rint(v * inv) + zp, lo, hi)).
+struct QlOut {
+  int mode;                 // 0 float32, 1 int8 codes, 2 uint8 codes
+  float inv, zf, lo, hi;
+};
+__device__ __forceinline__ void ql_store(void* __restrict__ y, int64_t idx, float v, const QlOut& o) {
+  if (o.mode == 0) {
+    static_cast<float*>(y)[idx] = v;
+  } else {
+    float q = __builtin_rintf(v * o.inv) + o.zf;
+    q = fminf(fmaxf(q, o.lo), o.hi);                  // NaN -> lo, as the codes kernel
+    if (o.mode == 1) static_cast<int8_t*>(y)[idx] = (int8_t)(int)q;
+    else static_cast<uint8_t*>(y)[idx] = (uint8_t)(int)q;
+  }
+}
+
 template <bool NT>
 __device__ __forceinline__ i32x4 ql_load16(const int8_t* p) {
   if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p));
@@ -46,8 +63,8 @@ __device__ __forceinline__ void ql_load_row(const int8_t* row, int64_t k, int64_
 template <int kQlWaves, int MT, bool A_U8, bool W_NT>
 __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
-    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, float* __restrict__ y,
-    int M, int N, int64_t K, int za, float sa) {
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa, QlOut oq) {
   constexpr int kQlThreads = kQlWaves * 64;
   __shared__ int red[kQlWaves][MT][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
       if (m < M && n < N) {
         float out = (float)(v - e_corr) * e_scale;
         if (bias) out = out + e_bias;
-        y[(int64_t)m * N + n] = out;
+        ql_store(y, (int64_t)m * N + n, out, oq);
       }
     }
     __syncthreads();
@@ -158,16 +175,16 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
 
 template <int WAVES, int MT, bool A_U8>
 static int launch_qlinear(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
-                          const float* bias, float* y, int64_t M, int64_t N, int64_t K, int za, float sa,
-                          hipStream_t stream) {
+                          const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                          const QlOut& oq, hipStream_t stream) {
   const dim3 grid((unsigned)((N + 15) / 16));
   const bool one_pass = M <= 16 * MT;             // weights read exactly once: keep them out of the caches
   if (one_pass)
     hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, true>), grid, dim3(WAVES * 64), 0, stream,
-                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa);
+                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
   else
     hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, false>), grid, dim3(WAVES * 64), 0, stream,
-                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa);
+                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
   return check_launch("mctq_qlinear_i8");
 }
 
@@ -196,8 +213,8 @@ __device__ __attribute__((aligned(16))) const int8_t g_ql_zero_chunk[16] = {0};
 template <int BM, int BN, int kTileBK, bool A_U8>
 __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
-    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, float* __restrict__ y,
-    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks) {
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, QlOut oq) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int CPR = kTileBK / 16;
   constexpr int SA = BM * CPR, SB = BN * CPR;        // slots of the A and of the B image
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
         if (m < M) {
           float out = (float)(acc[t][u][i] - e_corr[u]) * e_scale[u];
           if (bias) out = out + e_bias[u];
-          y[(int64_t)m * N + n] = out;
+          ql_store(y, (int64_t)m * N + n, out, oq);
         }
       }
     }
@@ -298,11 +315,11 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
 
 template <int BM, int BN, int BK, bool A_U8>
 static int launch_glds(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
-                       const float* bias, float* y, int64_t M, int64_t N, int64_t K, int za, float sa,
-                       hipStream_t stream) {
+                       const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                       const QlOut& oq, hipStream_t stream) {
   const int mbl = (int)((M + BM - 1) / BM), nbl = (int)((N + BN - 1) / BN);
   hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
-                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl);
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, oq);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
 }
 
@@ -310,11 +327,9 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
 
 using namespace mctq;
 
-extern "C" {
-
-int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
-                    const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
-                    float* y, int64_t M, int64_t N, int64_t K, void* stream) {
+static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                            const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                            void* y, const QlOut& oq, int64_t M, int64_t N, int64_t K, void* stream) {
   if (M < 0 || N < 0 || K < 0) return fail_arg("negative extent");
   if (a_code_dtype != MCTQ_CODE_I8 && a_code_dtype != MCTQ_CODE_U8) return fail_arg("bad a_code_dtype");
   if (M == 0 || N == 0) return 0;
@@ -327,8 +342,8 @@ int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_po
   const int za = u8 ? a_zero_point - 128 : a_zero_point;
   const hipStream_t s = (hipStream_t)stream;
 #define MCTQ_QL(W_, MT_)                                                                                         \
-  (u8 ? launch_qlinear<W_, MT_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s)    \
-      : launch_qlinear<W_, MT_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s))
+  (u8 ? launch_qlinear<W_, MT_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)    \
+      : launch_qlinear<W_, MT_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
   switch (g_ql_variant) {                           // experiments (mctq_set_tuning "ql_variant")
     case 81: return MCTQ_QL(8, 1);
     case 82: return MCTQ_QL(8, 2);
@@ -339,8 +354,8 @@ int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_po
     default: break;
   }
 #define MCTQ_QG(BM_, BN_, BK_)                                                                                    \
-  (u8 ? launch_glds<BM_, BN_, BK_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s)  \
-      : launch_glds<BM_, BN_, BK_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, s))
+  (u8 ? launch_glds<BM_, BN_, BK_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
+      : launch_glds<BM_, BN_, BK_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
   switch (g_ql_variant) {
     case 1212: return MCTQ_QG(128, 128, 128);
     case 612: return MCTQ_QG(64, 128, 128);
@@ -362,6 +377,33 @@ int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_po
   }
 #undef MCTQ_QG
 #undef MCTQ_QL
+}
+
+extern "C" {
+
+int mctq_qlinear_i8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                    const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                    float* y, int64_t M, int64_t N, int64_t K, void* stream) {
+  QlOut oq;
+  oq.mode = 0; oq.inv = oq.zf = oq.lo = oq.hi = 0.0f;
+  return qlinear_dispatch(a_codes, a_code_dtype, a_zero_point, a_scale, w_codes, w_scales, w_rowsum, bias, y, oq, M, N, K,
+                          stream);
+}
+
+int mctq_qlinear_i8_codes(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                          const int8_t* w_codes, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                          void* y_codes, int32_t y_code_dtype, float y_scale, int32_t y_zero_point, int32_t y_quant_min,
+                          int32_t y_quant_max, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (y_code_dtype != MCTQ_CODE_I8 && y_code_dtype != MCTQ_CODE_U8) return fail_arg("bad y_code_dtype");
+  if (y_quant_min > y_quant_max) return fail_arg("quant_min > quant_max");
+  if (y_code_dtype == MCTQ_CODE_I8 ? (y_quant_min < -128 || y_quant_max > 127) : (y_quant_min < 0 || y_quant_max > 255))
+    return fail_arg("clamp domain does not fit the code type");
+  QlOut oq;
+  oq.mode = y_code_dtype == MCTQ_CODE_I8 ? 1 : 2;
+  oq.inv = 1.0f / y_scale;                           // host IEEE division == the codes kernel's
+  oq.zf = (float)y_zero_point; oq.lo = (float)y_quant_min; oq.hi = (float)y_quant_max;
+  return qlinear_dispatch(a_codes, a_code_dtype, a_zero_point, a_scale, w_codes, w_scales, w_rowsum, bias, y_codes, oq, M,
+                          N, K, stream);
 }
 
 }  // extern "C"

@@ -224,3 +224,62 @@ def test_quantized_linear_replays_in_a_hip_graph():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, model(x * 0.5)) and not torch.equal(out, want)
+
+
+def _stack(layers=3, d=64, seed=1):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(seed)
+    mods = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(layers):
+            lin = torch.nn.Linear(d, d)
+            thr = [float(v) for v in lin.weight.detach().abs().max(1).values]
+            aq = (Q.ActivationUniformInferableQuantizer(num_bits=8, min_range=[-2.0], max_range=[2.5]) if i % 2 == 0
+                  else Q.ActivationSymmetricInferableQuantizer(num_bits=8, threshold=[2.0], signed=True))
+            mods += [mq.PytorchActivationQuantizationHolder(aq),
+                     mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(
+                         num_bits=8, threshold=thr, per_channel=True, channel_axis=0)})]
+    return torch.nn.Sequential(*mods)
+
+
+def _check_chain(device):
+    from mct_quantizers_amd import consumers
+    plain, chained = _stack().to(device), _stack().to(device)
+    assert consumers.fuse_linear_consumers(plain) == 3
+    assert consumers.fuse_linear_consumers(chained, chain=True) == 3
+    assert chained[1].emit_codes_for is not None and chained[3].emit_codes_for is not None
+    assert chained[5].emit_codes_for is None                       # last layer: float32 out
+    x = (torch.randn(7, 64) * 1.5).to(device)
+    y0, y1 = plain(x), chained(x)
+    assert y1.dtype == torch.float32 and torch.equal(y0, y1)       # same codes in between, bit for bit
+    mid = chained[:2](x)
+    assert mid.dtype == torch.int8                                  # layer 1 feeds a signed 8-bit quantizer
+
+
+def test_chained_consumers_pass_codes_between_layers_cpu():
+    _check_chain("cpu")
+
+
+@pytest.mark.gpu
+def test_chained_consumers_pass_codes_between_layers_gpu():
+    _check_chain("cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [5, 64, 300])
+def test_requantizing_epilogue_equals_the_codes_kernel(M):
+    from mct_quantizers_amd import consumers
+    from mct_quantizers_amd.hip import ops
+    rng = np.random.default_rng(M)
+    N, K = 200, 512
+    a, za, sa, w, ws, bias = _problem(rng, M, N, K, True)
+    dev = torch.device("cuda")
+    at, wt, wst, bt = (torch.from_numpy(v).to(dev) for v in (a, w, ws, bias))
+    rs = wt.sum(dim=1, dtype=torch.int32)
+    y = consumers.qlinear_i8(at, za, sa, wt, wst, rs, bt)
+    for out in ((0.05, 3, -128, 127), (0.11, 100, 0, 255), (0.5, 0, -8, 7)):
+        got = consumers.qlinear_i8(at, za, sa, wt, wst, rs, bt, out)
+        want = ops.fq_codes(y, None, None, None, out[2], out[3], out[0], out[1])
+        assert got.dtype == want.dtype and torch.equal(got, want), out

@@ -57,7 +57,12 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
         r3 = build(layers, d, False)[:3](x)
         f3 = m4[:3](x)
     err = float((f3 - r3).abs().max() / r3.abs().max())
+    m5 = build(layers, d, False)
+    consumers.fuse_linear_consumers(m5, chain=True)
+    # build()'s order is wrapper, holder, wrapper, ...: every QuantizedLinear but the last feeds the next one
+    chained, y5 = timeit(m5, x)
     print(f"{layers} x Linear({d},{d}) batch {batch}: this package {ours:7.3f} ms/forward, ATen fake-quant ops {aten:7.3f} ms/forward "
           f"(x{aten/ours:.2f}), with versioned weight reuse {reuse:7.3f} ms; outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3)}; "
-          f"{nf} layer pairs on integer codes {fused:7.3f} ms (x{aten/fused:.2f} vs ATen path, max rel diff after the first pair {err:.1e})",
+          f"{nf} layer pairs on integer codes {fused:7.3f} ms (x{aten/fused:.2f} vs ATen path, max rel diff after the first pair {err:.1e}); "
+          f"chained (codes passed between layers) {chained:7.3f} ms (x{aten/chained:.2f}), equal to unchained={torch.equal(y4, y5)}",
           flush=True)
