@@ -50,7 +50,7 @@ print("exactness failures:", bad)
 
 # timings: cold weights (ring larger than the 256 MiB Infinity Cache)
 res = {}
-for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (64, 11008, 4096), (128, 4096, 4096), (256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (2048, 11008, 4096), (4096, 4096, 11008)]:
+for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (32, 4096, 4096), (64, 11008, 4096), (128, 4096, 4096), (128, 11008, 4096), (256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (2048, 11008, 4096), (4096, 4096, 11008)]:
     ring = max(2, int(np.ceil(400e6 / (N * K))))
     ws_ = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(ring)]
     a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)
