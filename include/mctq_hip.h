@@ -53,6 +53,8 @@ extern "C" {
 /* storage types of the integer-code outputs */
 #define MCTQ_CODE_I8 0
 #define MCTQ_CODE_U8 1
+#define MCTQ_CODE_I4 2   /* two codes per byte: element 2j in the low nibble, 2j+1 in the high one */
+#define MCTQ_CODE_U4 3
 
 /* ABI version of the loaded library (== MCTQ_ABI_VERSION it was built with). */
 int mctq_abi_version(void);
@@ -93,6 +95,10 @@ int mctq_fq_per_channel(const void* x, void* y,
  * (codes - zero_point) * scale equals the fake-quantized value of mctq_fq_* bit for bit.  This is the
  * "integer domain" the reference never materialises; consumers that dequantize inside their GEMM
  * read 1 B per element instead of 4.
+ * MCTQ_CODE_I4 (domain within [-8, 7], two's-complement nibbles) / MCTQ_CODE_U4 (within [0, 15]): two codes per
+ * byte in storage order, element 2j in the low nibble and 2j + 1 in the high nibble; `codes` then holds n / 2
+ * bytes (4-byte aligned).  Supported layouts: per tensor with n % 8 == 0; per channel with inner % 8 == 0, or
+ * inner == 1 with channels % 8 == 0; anything else returns MCTQ_E_ARG.
  */
 int mctq_fq_codes_per_tensor(const void* x, void* codes, int64_t n, int32_t dtype, int32_t code_dtype,
                              float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,

@@ -16,7 +16,7 @@ import threading
 
 ABI_VERSION = 3
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
-CODE_I8, CODE_U8 = 0, 1
+CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
 LIB_NAME = "libmctq_hip.so"
 LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
 MCTQ_E_ARG = -10001

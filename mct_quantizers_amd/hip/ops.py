@@ -274,12 +274,41 @@ def _code_dtype(qmin: int, qmax: int):
     raise ValueError(f"clamp domain [{qmin}, {qmax}] does not fit an 8-bit code")
 
 
-def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float = None, zp0: int = None):
+def _packed_shape(x):
+    return tuple(x.shape[:-1]) + (x.shape[-1] // 2,) if x.dim() and x.shape[-1] % 2 == 0 and x.is_contiguous() \
+        else (x.numel() // 2,)
+
+
+def pack4(q: torch.Tensor) -> torch.Tensor:
+    """Integer codes in [-8, 15] (any integer dtype, storage order) -> two per byte, element 2j in the low nibble."""
+    flat = q.reshape(-1).to(torch.int16) & 0xF
+    return (flat[0::2] | (flat[1::2] << 4)).to(torch.uint8)
+
+
+def unpack4(packed: torch.Tensor, signed: bool, shape=None) -> torch.Tensor:
+    """Inverse of the 4-bit packing: uint8 [n/2] (any shape) -> int8 codes [n] (or ``shape``)."""
+    b = packed.reshape(-1).to(torch.int16)
+    both = torch.stack((b & 0xF, (b >> 4) & 0xF), dim=1).reshape(-1)
+    if signed:
+        both = torch.where(both > 7, both - 16, both)
+    both = both.to(torch.int8)
+    return both if shape is None else both.reshape(shape)
+
+
+def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float = None, zp0: int = None,
+             packed4: bool = False):
     """Integer clamp indices of the affine quantizers as int8 / uint8 (extension, not in the reference).
 
     ``axis`` None = per-tensor (scale0 / zp0 are the host copies of the single scale and zero point).
     ``(codes - zero_point) * scale`` is bit-identical to the fake-quantized tensor.
+    ``packed4``: clamp domains within [-8, 7] or [0, 15] leave as two codes per byte (uint8 tensor of half the
+    elements: last dimension halved for contiguous tensors; element 2j of the storage order in the low nibble).
     """
+    if packed4:
+        if not ((qmin >= -8 and qmax <= 7) or (qmin >= 0 and qmax <= 15)):
+            raise ValueError(f"clamp domain [{qmin}, {qmax}] does not fit a 4-bit code")
+        if x.numel() % 2:
+            raise ValueError("4-bit packing needs an even number of elements")
     tdt, code = _code_dtype(qmin, qmax)
     if not x.is_cuda:
         # CPU tensors: the same arithmetic with torch ops (float32 math, as ATen's CPU kernel)
@@ -289,13 +318,25 @@ def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float =
         else:
             shape = [1] * x.dim()
             shape[axis] = -1
-            q = torch.round(xf * (1.0 / scales.float()).reshape(shape)) + zero_points.reshape(shape).float()
-        return torch.clamp(torch.nan_to_num(q, nan=float(qmin)), qmin, qmax).to(tdt)
+            q = torch.round(xf * (1.0 / scales.float().to(x.device)).reshape(shape)) + \
+                zero_points.to(x.device).reshape(shape).float()
+        q = torch.clamp(torch.nan_to_num(q, nan=float(qmin)), qmin, qmax)
+        if packed4:
+            if x.is_contiguous() or not _is_dense(x):
+                return pack4(q.contiguous()).reshape(_packed_shape(x))
+            flat = torch.empty(x.numel(), dtype=torch.int16)          # dense, permuted storage: pack in STORAGE order
+            torch.as_strided(flat, x.shape, x.stride()).copy_(q.to(torch.int16))
+            return pack4(flat).reshape(_packed_shape(x))
+        return q.to(tdt)
     dt = _dtype_code(x, "fq_codes")
     lib = native.load()
     if not x.is_contiguous():
         x = _dense_input(x)
-    y = torch.empty_like(x, dtype=tdt)
+    if packed4:
+        code = native.CODE_I4 if qmin < 0 else native.CODE_U4
+        y = torch.empty(_packed_shape(x), dtype=torch.uint8, device=x.device)
+    else:
+        y = torch.empty_like(x, dtype=tdt)
     idx = x.get_device()
     with (_NOOP if idx == _current_device() else _on_device(idx)):
         if axis is None:

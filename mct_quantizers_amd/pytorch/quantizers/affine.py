@@ -171,16 +171,17 @@ class _WeightsAffineMixin:
         self._zps_flat = self.zero_points.flatten().contiguous()
         self._zps_all_zero = not bool(torch.any(self._zps_flat != 0).item())     # symmetric: skip the table
 
-    def quantize_to_codes(self, inputs: torch.Tensor):
+    def quantize_to_codes(self, inputs: torch.Tensor, packed4: bool = False):
         """Extension (not in the reference): the integer clamp indices as int8/uint8 plus the parameters that
         dequantize them, ``(codes - zero_points) * scales`` == ``self(inputs)`` bit for bit.
+        ``packed4`` (num_bits <= 4): two codes per byte (``ops.unpack4`` undoes it).
         Returns (codes, scales float32 [C or 1], zero_points int32 [C or 1])."""
         src = self.__dict__.get("_flat_src")
         if src is None or src[0] is not self.scales or src[1] is not self.zero_points:
             self._flat_params()
         axis = self.channel_axis if self.per_channel else None
         codes = ops.fq_codes(inputs, self._scales_flat, self._zps_flat, axis, self.min_quantized_domain,
-                             self.max_quantized_domain, self._scale0, self._zp0)
+                             self.max_quantized_domain, self._scale0, self._zp0, packed4)
         return codes, self._scales_flat, self._zps_flat
 
     def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
@@ -309,11 +310,11 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
         self.scales = float(self.scales[0])      # stays a Python double; narrowed to float32 at launch
         self.zero_points = 0
 
-    def quantize_to_codes(self, inputs: torch.Tensor):
+    def quantize_to_codes(self, inputs: torch.Tensor, packed4: bool = False):
         """Extension: (codes int8/uint8, scale float, zero_point int) with (codes - zero_point) * float32(scale)
-        == self(inputs)."""
+        == self(inputs); ``packed4``: two 4-bit codes per byte."""
         codes = ops.fq_codes(inputs, None, None, None, self.min_quantized_domain, self.max_quantized_domain,
-                             self.scales, self.zero_points)
+                             self.scales, self.zero_points, packed4)
         return codes, self.scales, self.zero_points
 
     _export_function = "ActivationSymF"
@@ -361,11 +362,11 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
         self.scale = float((self.max_range - self.min_range) / ((2 ** num_bits) - 1))
         self.zero_point = int(-np.round(self.min_range / self.scale))   # round half even, in double
 
-    def quantize_to_codes(self, inputs: torch.Tensor):
+    def quantize_to_codes(self, inputs: torch.Tensor, packed4: bool = False):
         """Extension: (codes uint8, scale float, zero_point int) with (codes - zero_point) * float32(scale)
-        == self(inputs)."""
+        == self(inputs); ``packed4``: two 4-bit codes per byte."""
         codes = ops.fq_codes(inputs, None, None, None, self.min_quantized_domain, self.max_quantized_domain,
-                             self.scale, self.zero_point)
+                             self.scale, self.zero_point, packed4)
         return codes, self.scale, self.zero_point
 
     def __call__(self, inputs: torch.Tensor):

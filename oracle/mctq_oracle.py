@@ -368,3 +368,10 @@ def qlinear_i8(a_codes: np.ndarray, a_zero_point: int, a_scale: float, w_codes: 
     if bias is not None:
         y = (y + np.asarray(bias, dtype=F32)[None, :]).astype(F32)
     return y
+
+
+def pack4(q: np.ndarray) -> np.ndarray:
+    """4-bit code packing of include/mctq_hip.h (MCTQ_CODE_I4 / _U4): integer codes in storage order, element 2j in
+    the low nibble of byte j, element 2j + 1 in the high nibble; signed codes as two's-complement nibbles."""
+    flat = np.asarray(q).reshape(-1).astype(np.int64) & 0xF
+    return (flat[0::2] | (flat[1::2] << 4)).astype(np.uint8)

@@ -834,3 +834,65 @@ def test_loud_failures(lib, monkeypatch):
     monkeypatch.setenv("MCTQ_HIP_LIB", "/nonexistent/libmctq_hip.so")
     with pytest.raises(native.NativeLibraryError):
         q(torch.zeros(8, device="cuda"))
+
+
+# ---------------------------------------------------------------------------------------------
+# 4-bit packed codes (MCTQ_CODE_I4 / MCTQ_CODE_U4)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,axis", [((64, 4096), 0), ((3, 5, 64), 1), ((7, 40), 1), ((33, 1024), 1), ((5, 8, 16), 0),
+                                        ((4096,), None), ((3, 7, 8), None)])
+def test_packed_4bit_codes_match_the_oracle_index(lib, dtype, shape, axis):
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    from oracle import oracle_call, mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(int(np.prod(shape)) + (axis or 0))
+    x32 = torch.from_numpy((rng.standard_normal(shape) * 1.5).astype(np.float32)).to(dtype)
+    x_np = x32.float().numpy()
+    if axis is None:
+        for cls, kw in ((Q.ActivationPOTInferableQuantizer, dict(num_bits=4, threshold=[2.0], signed=True)),
+                        (Q.ActivationUniformInferableQuantizer, dict(num_bits=4, min_range=[-1.0], max_range=[2.0])),
+                        (Q.ActivationSymmetricInferableQuantizer, dict(num_bits=3, threshold=[1.7], signed=False))):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                q = cls(**kw)
+            packed, scale, zp = q.quantize_to_codes(x32.cuda(), packed4=True)
+            _, idx = oracle_call(cls.__name__, kw, x_np, return_index=True)
+            assert packed.dtype == torch.uint8 and packed.numel() == x32.numel() // 2
+            assert np.array_equal(packed.cpu().numpy().reshape(-1), O.pack4(idx)), cls.__name__
+            # and the CPU route packs identically
+            assert torch.equal(q.quantize_to_codes(x32, packed4=True)[0].reshape(-1), packed.cpu().reshape(-1))
+            # unpacked codes dequantize to the fake-quantized tensor (computed in float32, as the codes contract says)
+            codes = ops.unpack4(packed.cpu(), q.min_quantized_domain < 0, shape)
+            deq = (codes.float() - zp) * torch.tensor(scale, dtype=torch.float64).to(torch.float32)
+            assert torch.equal(deq.to(dtype), q(x32.cuda()).cpu())
+    else:
+        C = shape[axis]
+        thr = [float(v) for v in rng.uniform(0.5, 3.0, C)]
+        kw = dict(num_bits=4, threshold=thr, per_channel=True, channel_axis=axis)
+        q = Q.WeightsSymmetricInferableQuantizer(**kw)
+        packed, scales, zps = q.quantize_to_codes(x32.cuda(), packed4=True)
+        _, idx = oracle_call("WeightsSymmetricInferableQuantizer", kw, x_np, return_index=True)
+        assert np.array_equal(packed.cpu().numpy().reshape(-1), O.pack4(idx))
+        assert torch.equal(q.quantize_to_codes(x32, packed4=True)[0].reshape(-1), packed.cpu().reshape(-1))
+        if x32.shape[-1] % 2 == 0:
+            assert packed.shape == tuple(shape[:-1]) + (shape[-1] // 2,)
+
+
+def test_packed_4bit_codes_reject_unsupported_layouts_and_domains(lib):
+    from mct_quantizers_amd.hip import native, ops
+    x = torch.randn(6, 12, device="cuda")
+    s = torch.ones(6, device="cuda")
+    z = torch.zeros(6, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.fq_codes(x, s, z, 0, -128, 127, packed4=True)                  # 8-bit domain
+    with pytest.raises(RuntimeError, match="inner % 8"):
+        ops.fq_codes(x, s, z, 0, -8, 7, packed4=True)                      # inner = 12: not a multiple of 8
+    y = torch.empty(36, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mctq_fq_codes_per_tensor(x.data_ptr(), y.data_ptr(), 72, native.DT_F32, native.CODE_I4, 0.1, 0, -9, 7, st) \
+        == native.MCTQ_E_ARG
+    assert lib.mctq_fq_codes_per_tensor(x.data_ptr(), y.data_ptr(), 70, native.DT_F32, native.CODE_U4, 0.1, 0, 0, 15, st) \
+        == native.MCTQ_E_ARG
