@@ -325,3 +325,32 @@ def test_reference_import_paths_exist():
         mod = importlib.import_module("mct_quantizers_amd." + rel)
         for n in names:
             assert hasattr(mod, n), (rel, n)
+
+
+def test_packed_4bit_codes_on_cpu_tensors_match_the_oracle_packing():
+    import warnings
+    import numpy as np
+    import torch
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    from oracle import oracle_call, mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy((rng.standard_normal((6, 16)) * 1.5).astype(np.float32))
+    kw = dict(num_bits=4, threshold=[float(v) for v in rng.uniform(0.5, 3, 6)], per_channel=True, channel_axis=0)
+    q = Q.WeightsSymmetricInferableQuantizer(**kw)
+    packed, scales, zps = q.quantize_to_codes(x, packed4=True)
+    _, idx = oracle_call("WeightsSymmetricInferableQuantizer", kw, x.numpy(), return_index=True)
+    assert packed.shape == (6, 8) and np.array_equal(packed.numpy().reshape(-1), O.pack4(idx))
+    codes = ops.unpack4(packed, True, (6, 16))
+    assert torch.equal(codes.float() * scales.cpu().reshape(-1, 1), q(x))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = Q.ActivationUniformInferableQuantizer(num_bits=3, min_range=[-1.0], max_range=[2.0])
+    packed, scale, zp = a.quantize_to_codes(x, packed4=True)
+    _, idx = oracle_call("ActivationUniformInferableQuantizer", dict(num_bits=3, min_range=[-1.0], max_range=[2.0]),
+                         x.numpy(), return_index=True)
+    assert np.array_equal(packed.numpy().reshape(-1), O.pack4(idx))
+    import pytest
+    with pytest.raises(ValueError):
+        Q.ActivationSymmetricInferableQuantizer(num_bits=8, threshold=[1.0], signed=True).quantize_to_codes(x, packed4=True)
