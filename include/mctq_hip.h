@@ -259,6 +259,19 @@ int mctq_qlinear_i8_codes(const void* a_codes, int32_t a_code_dtype, int32_t a_z
                           int32_t y_quant_max, int64_t M, int64_t N, int64_t K, void* stream);
 
 /*
+ * The same consumer for 4-bit weights (quantizers with num_bits <= 4), streamed at half a byte per weight: the
+ * weight-streaming kernel only, meant for few rows (every M is computed correctly; beyond ~64 rows the int8 tiled
+ * path is faster).  w_codes4 [N][K / 2] holds the codes in the CONSUMER layout, not the storage-order packing of
+ * MCTQ_CODE_I4: each group of 8 consecutive k is 4 bytes, byte j = (code[k = j] & 0xF) | (code[k = j + 4] << 4),
+ * two's-complement nibbles in [-8, 7]; 8-byte aligned rows (K % 16 == 0).  w_rowsum[n] = sum_k code[n][k].
+ * y_code_dtype < 0: y is float32 [M][N]; otherwise y holds the next layer's codes as in mctq_qlinear_i8_codes.
+ */
+int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                      const uint8_t* w_codes4, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                      void* y, int32_t y_code_dtype, float y_scale, int32_t y_zero_point, int32_t y_quant_min,
+                      int32_t y_quant_max, int64_t M, int64_t N, int64_t K, void* stream);
+
+/*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.
  *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default), 2 = non-temporal
  *                  loads with cached stores

@@ -80,6 +80,47 @@ def qlinear_i8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes
     return ops.fq_codes(y, None, None, None, o_qmin, o_qmax, o_scale, o_zp)
 
 
+def pack_w4(codes: torch.Tensor) -> torch.Tensor:
+    """int8 codes in [-8, 7], [N, K] with K % 8 == 0 -> the consumer's 4-bit layout, uint8 [N, K / 2]: per group of 8
+    consecutive k, byte j = (code[j] & 0xF) | (code[j + 4] << 4) (include/mctq_hip.h: mctq_qlinear_w4a8)."""
+    N, K = codes.shape
+    g = codes.reshape(N, K // 8, 8).to(torch.int16) & 0xF
+    return (g[..., 0:4] | (g[..., 4:8] << 4)).to(torch.uint8).reshape(N, K // 2).contiguous()
+
+
+def qlinear_w4a8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes4: torch.Tensor,
+                 w_scales: torch.Tensor, w_rowsum: torch.Tensor, bias: Optional[torch.Tensor],
+                 out_codes=None) -> torch.Tensor:
+    """As ``qlinear_i8`` with the weights as packed 4-bit codes (``pack_w4``); GPU tensors only."""
+    M, K = a_codes.shape
+    N = w_codes4.shape[0]
+    if w_codes4.shape[1] * 2 != K:
+        raise RuntimeError(f"shape mismatch: activations have K={K}, packed weights K={w_codes4.shape[1] * 2}")
+    if K % 16 or K > _MAX_K:
+        raise NotImplementedError(f"mctq_qlinear_w4a8 needs K % 16 == 0 and K <= {_MAX_K}, got K={K}")
+    lib = native.load()
+    a_codes, w_codes4 = a_codes.contiguous(), w_codes4.contiguous()
+    code = native.CODE_U8 if a_codes.dtype == torch.uint8 else native.CODE_I8
+    if out_codes is None:
+        y = torch.empty((M, N), dtype=torch.float32, device=a_codes.device)
+        ocode, o_scale, o_zp, o_qmin, o_qmax = -1, 1.0, 0, 0, 0
+    else:
+        o_scale, o_zp, o_qmin, o_qmax = out_codes
+        tdt, ocode = ops._code_dtype(o_qmin, o_qmax)
+        y = torch.empty((M, N), dtype=tdt, device=a_codes.device)
+    with ops._maybe_on_device(a_codes):
+        rc = ops._launch(lib.mctq_qlinear_w4a8, a_codes.data_ptr(), code, int(a_zero_point), float(a_scale),
+                         w_codes4.data_ptr(), w_scales.data_ptr(), w_rowsum.data_ptr(),
+                         None if bias is None else bias.data_ptr(), y.data_ptr(), ocode, float(o_scale), int(o_zp),
+                         int(o_qmin), int(o_qmax), M, N, K, ops._stream(a_codes))
+    if rc:
+        native.check(rc, "mctq_qlinear_w4a8")
+    return y
+
+
+_W4_MAX_ROWS = 32          # measured: beyond this the int8 kernels are faster than streaming half the bytes
+
+
 class QuantizedLinear(nn.Module):
     """``activation quantizer -> PytorchQuantizationWrapper(nn.Linear)`` evaluated on integer codes.
 
@@ -104,7 +145,7 @@ class QuantizedLinear(nn.Module):
         self.activation_quantizer = activation_quantizer
         self._a_scale, self._a_zp, self._a_qmin, self._a_qmax = _activation_code_params(activation_quantizer)
         self._w_key = None
-        self._w_codes = self._w_scales = self._w_rowsum = None
+        self._w_codes = self._w_scales = self._w_rowsum = self._w_codes4 = None
         # chaining (fuse_linear_consumers(chain=True)): parameters of the activation quantizer that would quantize
         # this layer's output next; the output then leaves as that quantizer's codes
         self.emit_codes_for = None
@@ -134,6 +175,9 @@ class QuantizedLinear(nn.Module):
         self._w_codes = codes.contiguous()
         self._w_scales = scales.contiguous()
         self._w_rowsum = codes.sum(dim=1, dtype=torch.int32).contiguous()
+        # weights of at most 4 bits: also keep them packed, to stream half the bytes when there are few rows
+        self._w_codes4 = pack_w4(self._w_codes) if (self.weights_quantizer.num_bits <= 4 and w.is_cuda
+                                                     and self.in_features % 16 == 0) else None
         self._w_key = key
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -146,8 +190,13 @@ class QuantizedLinear(nn.Module):
             a_codes = x2
         else:
             a_codes = ops.fq_codes(x2, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
-        y = qlinear_i8(a_codes, self._a_zp, self._a_scale, self._w_codes, self._w_scales, self._w_rowsum,
-                       None if self.bias is None else self.bias.detach(), self.emit_codes_for)
+        bias = None if self.bias is None else self.bias.detach()
+        if self._w_codes4 is not None and a_codes.is_cuda and a_codes.shape[0] <= _W4_MAX_ROWS:
+            y = qlinear_w4a8(a_codes, self._a_zp, self._a_scale, self._w_codes4, self._w_scales, self._w_rowsum, bias,
+                             self.emit_codes_for)
+        else:
+            y = qlinear_i8(a_codes, self._a_zp, self._a_scale, self._w_codes, self._w_scales, self._w_rowsum, bias,
+                           self.emit_codes_for)
         return y.reshape(*lead, self.out_features)
 
 

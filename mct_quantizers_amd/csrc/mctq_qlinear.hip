@@ -59,8 +59,29 @@ __device__ __forceinline__ void ql_load_row(const int8_t* row, int64_t k, int64_
   }
 }
 
+// 4-bit weights (W4): a row holds K / 2 bytes; each group of 8 consecutive k is one dword whose byte j carries
+// code k = j in its low and k = j + 4 in its high nibble (two's complement).  (x << 4) & 0xF0F0F0F0 and
+// x & 0xF0F0F0F0 are then the int8 values 16 * code of k = 0..3 and k = 4..7 in natural order: two VALU ops per
+// 8 weights, and the factor 16 leaves again by an exact shift of the int32 sum.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <bool NT, bool FULL>
+__device__ __forceinline__ void ql_load_row4(const int8_t* row, int64_t k, int64_t K, i32x2* out) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const i32x2 z = {0, 0};
+    const i32x2* q = reinterpret_cast<const i32x2*>(row + (k + 64 * p) / 2);
+    if (FULL || k + 64 * p < K) out[p] = NT ? __builtin_nontemporal_load(q) : *q;
+    else out[p] = z;
+  }
+}
+__device__ __forceinline__ i32x4 ql_unpack4(i32x2 x) {
+  return i32x4{(x[0] << 4) & (int)0xF0F0F0F0, x[0] & (int)0xF0F0F0F0, (x[1] << 4) & (int)0xF0F0F0F0, x[1] & (int)0xF0F0F0F0};
+}
+__device__ __forceinline__ i32x4 ql_unpack4(i32x4 x) { return x; }       // int8 weights: nothing to do
+
 // MT: 16-row tiles of A per pass (1..4).  A_U8: activation codes are uint8 (re-biased to int8 by ^0x80).
-template <int kQlWaves, int MT, bool A_U8, bool W_NT>
+// W4: weights are packed 4-bit codes (above).
+template <int kQlWaves, int MT, bool A_U8, bool W_NT, bool W4 = false>
 __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
@@ -71,7 +92,8 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
   // rows beyond N / M are clamped to the last valid row: they are loaded and multiplied, never stored
-  const int8_t* wrow = w + (int64_t)min(n0 + r, N - 1) * K;
+  const int8_t* wrow = w + (int64_t)min(n0 + r, N - 1) * (W4 ? K / 2 : K);
+  typedef typename std::conditional<W4, i32x2, i32x4>::type WF;     // a weight piece as loaded
   const int64_t kblocks = (K + kQlKBlock - 1) / kQlKBlock;
   const int64_t full_blocks = K / kQlKBlock;
   // this thread's output column in the epilogue is fixed (block size % 16 == 0): fetch its constants now, not
@@ -89,10 +111,11 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
 #pragma unroll
     for (int t = 0; t < MT; ++t) arow[t] = a + (int64_t)min(m0 + 16 * t + r, M - 1) * K;
 
-    i32x4 wf0[4], wf1[4], af0[MT][4], af1[MT][4];       // two register buffers, swapped by unrolling
+    WF wf0[4], wf1[4];
+    i32x4 af0[MT][4], af1[MT][4];                       // two register buffers, swapped by unrolling
     // blocks walk K from different starting points so that they do not all ask L2 for the same lines of A at once
     const int64_t rot = full_blocks ? (int64_t)blockIdx.x % full_blocks : 0;
-    auto fetch = [&](int64_t i, i32x4* wf, i32x4 (*af)[4]) {            // i-th full K block of this wave
+    auto fetch = [&](int64_t i, WF* wf, i32x4 (*af)[4]) {               // i-th full K block of this wave
       int64_t kblk = wave + i * kQlWaves + rot;
       if (kblk >= full_blocks) kblk -= full_blocks;
       const int64_t k = kblk * kQlKBlock + 16 * g;
@@ -105,19 +128,21 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
         ql_load_row<false, true>(arow[t], k, K, af[t]);
 #endif
       }
-      ql_load_row<W_NT, true>(wrow, k, K, wf);      // L2-resident activations first, the HBM stream behind them
+      if constexpr (W4) ql_load_row4<W_NT, true>(wrow, k, K, wf);      // L2-resident activations first, the HBM stream behind them
+      else ql_load_row<W_NT, true>(wrow, k, K, wf);
     };
-    auto multiply = [&](const i32x4* wf, const i32x4 (*af)[4]) {
+    auto multiply = [&](const WF* wf, const i32x4 (*af)[4]) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        const i32x4 wv = ql_unpack4(wf[p]);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           i32x4 av = af[t][p];
           if constexpr (A_U8) av = av ^ (int)0x80808080;          // u8 code c -> int8 (c - 128)
 #ifdef MCTQ_QL_ABLATE_MFMA                   // timing experiment: loads only
-          acc[t] += av ^ wf[p];
+          acc[t] += av ^ wv;
 #else
-          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wf[p], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wv, acc[t], 0, 0, 0);
 #endif
         }
       }
@@ -142,7 +167,8 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
     }
     if (full_blocks != kblocks && wave == kQlWaves - 1) {          // ragged end of K: guarded loads, one wave
       const int64_t k = full_blocks * kQlKBlock + 16 * g;
-      ql_load_row<W_NT, false>(wrow, k, K, wf0);
+      if constexpr (W4) ql_load_row4<W_NT, false>(wrow, k, K, wf0);
+      else ql_load_row<W_NT, false>(wrow, k, K, wf0);
 #pragma unroll
       for (int t = 0; t < MT; ++t) ql_load_row<false, false>(arow[t], k, K, af0[t]);
       multiply(wf0, af0);
@@ -162,6 +188,7 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
       int v = 0;
 #pragma unroll
       for (int wv = 0; wv < kQlWaves; ++wv) v += red[wv][t][src_lane][src_reg];
+      if constexpr (W4) v >>= 4;                                  // the weights entered as 16 * code: exact
       const int m = m0 + 16 * t + mi, n = n0 + ni;
       if (m < M && n < N) {
         float out = (float)(v - e_corr) * e_scale;
@@ -173,17 +200,17 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
   }
 }
 
-template <int WAVES, int MT, bool A_U8>
+template <int WAVES, int MT, bool A_U8, bool W4 = false>
 static int launch_qlinear(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
                           const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
                           const QlOut& oq, hipStream_t stream) {
   const dim3 grid((unsigned)((N + 15) / 16));
   const bool one_pass = M <= 16 * MT;             // weights read exactly once: keep them out of the caches
   if (one_pass)
-    hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, true>), grid, dim3(WAVES * 64), 0, stream,
+    hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, true, W4>), grid, dim3(WAVES * 64), 0, stream,
                        (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
   else
-    hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, false>), grid, dim3(WAVES * 64), 0, stream,
+    hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, false, W4>), grid, dim3(WAVES * 64), 0, stream,
                        (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
   return check_launch("mctq_qlinear_i8");
 }
@@ -406,6 +433,44 @@ int mctq_qlinear_i8_codes(const void* a_codes, int32_t a_code_dtype, int32_t a_z
   oq.zf = (float)y_zero_point; oq.lo = (float)y_quant_min; oq.hi = (float)y_quant_max;
   return qlinear_dispatch(a_codes, a_code_dtype, a_zero_point, a_scale, w_codes, w_scales, w_rowsum, bias, y_codes, oq, M,
                           N, K, stream);
+}
+
+
+int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_point, float a_scale,
+                      const uint8_t* w_codes4, const float* w_scales, const int32_t* w_rowsum, const float* bias,
+                      void* y, int32_t y_code_dtype, float y_scale, int32_t y_zero_point, int32_t y_quant_min,
+                      int32_t y_quant_max, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return fail_arg("negative extent");
+  if (a_code_dtype != MCTQ_CODE_I8 && a_code_dtype != MCTQ_CODE_U8) return fail_arg("bad a_code_dtype");
+  QlOut oq;
+  oq.mode = 0; oq.inv = oq.zf = oq.lo = oq.hi = 0.0f;
+  if (y_code_dtype >= 0) {
+    if (y_code_dtype != MCTQ_CODE_I8 && y_code_dtype != MCTQ_CODE_U8) return fail_arg("bad y_code_dtype");
+    if (y_quant_min > y_quant_max) return fail_arg("quant_min > quant_max");
+    if (y_code_dtype == MCTQ_CODE_I8 ? (y_quant_min < -128 || y_quant_max > 127) : (y_quant_min < 0 || y_quant_max > 255))
+      return fail_arg("clamp domain does not fit the code type");
+    oq.mode = y_code_dtype == MCTQ_CODE_I8 ? 1 : 2;
+    oq.inv = 1.0f / y_scale;
+    oq.zf = (float)y_zero_point; oq.lo = (float)y_quant_min; oq.hi = (float)y_quant_max;
+  }
+  if (M == 0 || N == 0) return 0;
+  if (!a_codes || !w_codes4 || !w_scales || !w_rowsum || !y) return fail_arg("NULL pointer");
+  if (K % 16 != 0) return fail_arg("K must be a multiple of 16");
+  if ((((uintptr_t)a_codes) & 15u) != 0 || (((uintptr_t)w_codes4) & 7u) != 0)
+    return fail_arg("a_codes must be 16-byte and w_codes4 8-byte aligned");
+  if (K > (1 << 15)) return fail_arg("K > 32768 could overflow the int32 accumulator");
+  if (M > INT32_MAX / 2 || N > INT32_MAX / 2) return fail_arg("M or N too large");
+  const bool u8 = a_code_dtype == MCTQ_CODE_U8;
+  const int za = u8 ? a_zero_point - 128 : a_zero_point;
+  const int8_t* w = reinterpret_cast<const int8_t*>(w_codes4);
+  const hipStream_t s = (hipStream_t)stream;
+#define MCTQ_QL4(MT_)                                                                                               \
+  (u8 ? launch_qlinear<8, MT_, true, true>(a_codes, w, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)     \
+      : launch_qlinear<8, MT_, false, true>(a_codes, w, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  if (M <= 16) return MCTQ_QL4(1);
+  if (M <= 32) return MCTQ_QL4(2);
+  return MCTQ_QL4(4);
+#undef MCTQ_QL4
 }
 
 }  // extern "C"

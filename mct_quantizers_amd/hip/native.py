@@ -77,6 +77,10 @@ SIGNATURES = {
                                              ctypes.c_void_p, _c_f32p, _c_i32p, _c_f32p, ctypes.c_void_p, ctypes.c_int32,
                                              ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "mctq_qlinear_w4a8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                         ctypes.c_void_p, _c_f32p, _c_i32p, _c_f32p, ctypes.c_void_p, ctypes.c_int32,
+                                         ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "mctq_lut_table_entries": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float]),
     "mctq_lut_build_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_void_p]),

@@ -85,3 +85,26 @@ for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (32, 4096
 lib.mctq_set_tuning(b"ql_variant", 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/qlinear_probe.json", "w"), indent=1)
+
+# 4-bit weights (consumer layout), streaming kernel: time against the int8 path on the same shapes
+from mct_quantizers_amd import consumers
+for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (32, 4096, 4096), (64, 4096, 4096), (16, 11008, 4096), (16, 4096, 11008), (64, 11008, 4096)]:
+    ring = max(2, int(np.ceil(400e6 / (N * K // 2))))
+    w4 = [torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device=dev) for _ in range(ring)]
+    a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)
+    sc = torch.rand(N, device=dev) * 0.01
+    wsum = torch.zeros(N, dtype=torch.int32, device=dev)
+    bias = torch.randn(N, device=dev)
+    y = torch.empty(M, N, dtype=torch.float32, device=dev)
+    for i in range(5):
+        consumers.qlinear_w4a8(a, 114, 0.02, w4[i % ring], sc, wsum, bias)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(50):
+        lib.mctq_qlinear_w4a8(a.data_ptr(), native.CODE_U8, 114, 0.02, w4[i % ring].data_ptr(), sc.data_ptr(), wsum.data_ptr(),
+                              bias.data_ptr(), y.data_ptr(), -1, 1.0, 0, 0, 0, M, N, K, S())
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1000 / 50
+    print(M, N, K, "w4a8", dict(us=round(us, 2), w_gbs=round(N * K / 2 / us / 1e3, 1)), flush=True)
+    del w4
