@@ -71,7 +71,22 @@ def main():
     dist = None
     if world > 1 or (args.gather and "RANK" in os.environ):
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        control_plane = "nccl"
+        try:
+            if os.environ.get("MCTQ_BENCH_FORCE_GLOO"):         # test hook for the fallback below
+                raise RuntimeError("forced")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.zeros(1, device="cuda")
+            dist.all_reduce(probe)                      # RCCL communicators are created lazily: fail here, not mid-run
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001  -- the path itself has no collective: keep the headline measurable
+            print(f"[bench] RCCL unavailable ({e!r:.200}); barrier / max-over-ranks go over gloo", file=sys.stderr, flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            dist.init_process_group("gloo")
+            control_plane = "gloo"
 
     import mct_quantizers_amd as mq
     from mct_quantizers_amd import workloads
@@ -141,7 +156,7 @@ def main():
     wall = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)            # events on the stream the kernels were launched on
     if dist:
-        tt = torch.tensor([wall, dev_ms], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([wall, dev_ms], device="cuda" if control_plane == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 
@@ -166,7 +181,8 @@ def main():
         "config": {"workload": wl.name, "shape": list(wl.shape), "quantizer": wl.quantizer,
                    "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
                    "launch": "hipGraph" if graph is not None else "eager", "streams": args.streams,
-                   "parallelism": f"replicated x{world} (weak, no collective)"},
+                   "parallelism": f"replicated x{world} (weak, no collective)",
+                   "control_plane": control_plane if dist else None},
         "achieved_gbs": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
@@ -250,7 +266,7 @@ def main():
     except OSError:
         pass
 
-    if dist and (args.gather or world > 1):
+    if dist and control_plane == "nccl" and (args.gather or world > 1):
         # Extras for N > 1 (outside the timed region, never allowed to break the main line):
         # BASELINE config 5, WeightsPOT 4-bit per-channel on 8192x8192, sharded by dim 0 across the ranks
         # (strong scaling: rank r quantizes rows [8192 r / N, 8192 (r+1) / N)), then ONE all-gather over xGMI.
