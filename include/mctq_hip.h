@@ -16,6 +16,10 @@
  *                             .../activation_lut_pot_inferable_quantizer.py:86 and
  *                             .../weights_lut_symmetric_inferable_quantizer.py:114 (per_channel=False)
  *   mctq_lut_per_channel_f32  lut_quantizer with a per-channel threshold, .../weights_lut_symmetric_inferable_quantizer.py:114
+ *   mctq_grid_per_*_f32       the export-time functions quantize_*_torch behind `_use_custom_impl and
+ *                             torch.jit.is_tracing()` (file:line at the declarations below)
+ *   (dtype-generic forms, the decision-table LUT entry points and the extensions -- integer codes, the integer
+ *    consumer mctq_qlinear_* -- are documented at their declarations; extensions have no reference call site)
  *
  * Conventions
  *   - x, y, scales, zero_points, thresholds and lut are DEVICE pointers owned by the caller
