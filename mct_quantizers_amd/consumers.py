@@ -235,3 +235,56 @@ def fuse_linear_consumers(model: nn.Module, chain: bool = False) -> int:
                 if isinstance(first, QuantizedLinear) and isinstance(gap, _FusedAway) and isinstance(second, QuantizedLinear):
                     first.emit_codes_for = (second._a_scale, second._a_zp, second._a_qmin, second._a_qmax)
     return replaced
+
+
+def fuse_linear_consumers_fx(model: nn.Module, chain: bool = False):
+    """The same rewrite on an arbitrary module graph (MCT-exported models are not ``nn.Sequential``): traces ``model``
+    with torch.fx keeping wrappers and holders as leaves, and wherever an activation holder's ONLY consumer is a
+    wrapped ``nn.Linear`` the integer consumer can take, replaces the pair by one ``QuantizedLinear`` node.
+    Returns ``(graph_module, pairs_replaced)``.  Holders with several consumers (residual branches) stay."""
+    import torch.fx as fx
+
+    class _Tracer(fx.Tracer):
+        def is_leaf_module(self, m, qualname):
+            return isinstance(m, (PytorchQuantizationWrapper, PytorchActivationQuantizationHolder, QuantizedLinear)) \
+                or super().is_leaf_module(m, qualname)
+
+    graph = _Tracer().trace(model)
+    gm = fx.GraphModule(model, graph)
+    mods = dict(gm.named_modules())
+    replaced = 0
+    for node in list(gm.graph.nodes):
+        if node.op != "call_module" or node.kwargs or len(node.args) != 1:
+            continue
+        wrapper = mods.get(node.target)
+        if not isinstance(wrapper, PytorchQuantizationWrapper) or not isinstance(getattr(wrapper, "layer", None), nn.Linear):
+            continue
+        src = node.args[0]
+        if not isinstance(src, fx.Node) or src.op != "call_module" or len(src.users) != 1 or len(src.args) != 1 or src.kwargs:
+            continue
+        holder = mods.get(src.target)
+        if type(holder) is not PytorchActivationQuantizationHolder or list(wrapper.weights_quantizers) != ["weight"]:
+            continue
+        if wrapper.layer.in_features % 16 or wrapper.layer.in_features > _MAX_K:
+            continue
+        try:
+            fused = QuantizedLinear.from_wrapper(wrapper, holder.activation_holder_quantizer)
+        except (TypeError, NotImplementedError):
+            continue
+        name = node.target.replace(".", "_") + "_qlinear"
+        gm.add_submodule(name, fused)
+        mods[name] = fused
+        node.target = name
+        node.args = (src.args[0],)
+        gm.graph.erase_node(src)
+        replaced += 1
+    if chain:
+        for node in gm.graph.nodes:
+            if node.op == "call_module" and isinstance(mods.get(node.target), QuantizedLinear) and len(node.users) == 1:
+                user = next(iter(node.users))
+                nxt = mods.get(user.target) if user.op == "call_module" else None
+                if isinstance(nxt, QuantizedLinear) and user.args == (node,):
+                    mods[node.target].emit_codes_for = (nxt._a_scale, nxt._a_zp, nxt._a_qmin, nxt._a_qmax)
+    gm.graph.lint()
+    gm.recompile()
+    return gm, replaced

@@ -339,3 +339,56 @@ def test_quantized_linear_streams_packed_4bit_weights_for_small_batches():
     y_small = model(x)
     y_big = model(torch.cat([x, x, x]))[:32]
     assert torch.equal(y_small, y_big)
+
+
+class _Branchy(torch.nn.Module):
+    """x -> holder -> wrapped Linear -> (+ x) -> holder -> {wrapped Linear, wrapped Linear}: the second holder has two
+    consumers and must stay; the first pair fuses."""
+
+    def __init__(self):
+        super().__init__()
+        import mct_quantizers_amd as mq
+        Q = mq.pytorch_quantizers
+        torch.manual_seed(5)
+
+        def wrapped(n_in, n_out):
+            lin = torch.nn.Linear(n_in, n_out)
+            thr = [float(v) for v in lin.weight.detach().abs().max(1).values]
+            return mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(
+                num_bits=8, threshold=thr, per_channel=True, channel_axis=0)})
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.h1 = mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.0], [2.5]))
+            self.l1 = wrapped(64, 64)
+            self.h2 = mq.PytorchActivationQuantizationHolder(Q.ActivationSymmetricInferableQuantizer(8, [4.0], True))
+            self.l2a, self.l2b = wrapped(64, 32), wrapped(64, 32)
+            self.h3 = mq.PytorchActivationQuantizationHolder(Q.ActivationSymmetricInferableQuantizer(8, [4.0], True))
+            self.l3 = wrapped(32, 16)
+
+    def forward(self, x):
+        y = self.l1(self.h1(x)) + x
+        q = self.h2(y)
+        z = self.l2a(q) * torch.sigmoid(self.l2b(q))
+        return self.l3(self.h3(z))
+
+
+def _check_fx_fusion(device):
+    from mct_quantizers_amd import consumers
+    model = _Branchy().to(device)
+    x = (torch.randn(9, 64) * 1.5).to(device)
+    ref = model(x)
+    gm, n = consumers.fuse_linear_consumers_fx(model, chain=True)
+    assert n == 2                                                  # (h1, l1) and (h3, l3); h2 feeds two layers
+    kinds = [type(m).__name__ for m in gm.modules()]
+    assert kinds.count("QuantizedLinear") == 2 and "PytorchActivationQuantizationHolder" in kinds
+    y = gm(x)
+    assert y.shape == ref.shape and torch.allclose(y, ref, rtol=1e-4, atol=1e-5 * float(ref.detach().abs().max()))
+
+
+def test_fx_fusion_on_a_branching_model_cpu():
+    _check_fx_fusion("cpu")
+
+
+@pytest.mark.gpu
+def test_fx_fusion_on_a_branching_model_gpu():
+    _check_fx_fusion("cuda")
