@@ -204,6 +204,11 @@ class _FusedAway(nn.Identity):
     """Placeholder left where an activation holder was folded into the QuantizedLinear after it."""
 
 
+def _plain_holder(m) -> bool:
+    """An activation holder that really quantizes (the FLN / preserving variants can be switched to pass-through)."""
+    return isinstance(m, PytorchActivationQuantizationHolder) and not getattr(m, "quantization_bypass", False)
+
+
 def fuse_linear_consumers(model: nn.Module, chain: bool = False) -> int:
     """In every ``nn.Sequential`` of ``model``: an activation holder directly followed by a wrapped ``nn.Linear`` with
     a symmetric weights quantizer becomes (Identity, QuantizedLinear).  Returns the number of pairs replaced.
@@ -216,7 +221,7 @@ def fuse_linear_consumers(model: nn.Module, chain: bool = False) -> int:
     for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
         for i in range(len(seq) - 1):
             holder, wrapper = seq[i], seq[i + 1]
-            if type(holder) is not PytorchActivationQuantizationHolder or not isinstance(wrapper, PytorchQuantizationWrapper):
+            if not _plain_holder(holder) or not isinstance(wrapper, PytorchQuantizationWrapper):
                 continue
             if not isinstance(getattr(wrapper, "layer", None), nn.Linear) or list(wrapper.weights_quantizers) != ["weight"]:
                 continue
@@ -263,7 +268,7 @@ def fuse_linear_consumers_fx(model: nn.Module, chain: bool = False):
         if not isinstance(src, fx.Node) or src.op != "call_module" or len(src.users) != 1 or len(src.args) != 1 or src.kwargs:
             continue
         holder = mods.get(src.target)
-        if type(holder) is not PytorchActivationQuantizationHolder or list(wrapper.weights_quantizers) != ["weight"]:
+        if not _plain_holder(holder) or list(wrapper.weights_quantizers) != ["weight"]:
             continue
         if wrapper.layer.in_features % 16 or wrapper.layer.in_features > _MAX_K:
             continue
