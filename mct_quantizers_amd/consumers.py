@@ -169,6 +169,7 @@ class QuantizedLinear(nn.Module):
         codes, scales, _ = self.weights_quantizer.quantize_to_codes(w.detach())
         if codes.dtype != torch.int8:
             raise RuntimeError("symmetric weight codes are expected to be int8")
+        codes = codes.reshape(self.out_features, self.in_features)       # [O, C, 1, 1] of a pointwise convolution too
         scales = scales.to(device=w.device, dtype=torch.float32).reshape(-1)
         if scales.numel() == 1:
             scales = scales.expand(self.out_features)
@@ -200,6 +201,68 @@ class QuantizedLinear(nn.Module):
         return y.reshape(*lead, self.out_features)
 
 
+class QuantizedConv1x1(QuantizedLinear):
+    """``activation quantizer -> PytorchQuantizationWrapper(nn.Conv2d 1x1)`` on integer codes: a pointwise convolution
+    (kernel 1x1, stride 1, no padding / dilation / groups -- most of the multiply-accumulates of MobileNet-style
+    networks) is the same product over the channel axis for every pixel, so it runs on the same kernels with
+    M = batch x height x width rows.  Channels-last inputs are consumed in place; NCHW inputs pay one transposition
+    of their 1-byte codes.  The result has the NCHW shape with channels-last strides."""
+
+    def __init__(self, conv: nn.Conv2d, weights_quantizer, activation_quantizer):
+        if not self.eligible(conv):
+            raise TypeError("QuantizedConv1x1 takes 1x1, stride-1, unpadded, undilated, ungrouped nn.Conv2d layers")
+        lin = nn.Linear(conv.in_channels, conv.out_channels, bias=conv.bias is not None, device=conv.weight.device,
+                        dtype=conv.weight.dtype)
+        lin.bias = conv.bias
+        super().__init__(lin, weights_quantizer, activation_quantizer)
+        self.weight = conv.weight                         # [O, C, 1, 1]; the codes are taken from it as [O, C]
+
+    @staticmethod
+    def eligible(conv) -> bool:
+        return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+                and conv.padding in ((0, 0), 0, "valid") and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.padding_mode == "zeros")
+
+    @classmethod
+    def from_wrapper(cls, wrapper: PytorchQuantizationWrapper, activation_quantizer) -> "QuantizedConv1x1":
+        quantizers = wrapper.weights_quantizers
+        if list(quantizers) != ["weight"] or not cls.eligible(wrapper.layer):
+            raise TypeError("expected a wrapped pointwise nn.Conv2d with one quantizer on 'weight'")
+        conv = nn.Conv2d(wrapper.layer.in_channels, wrapper.layer.out_channels, 1, bias=wrapper.layer.bias is not None,
+                         device=wrapper.weight.device, dtype=wrapper.weight.dtype)
+        conv.weight = wrapper.weight
+        conv.bias = wrapper.layer.bias
+        return cls(conv, quantizers["weight"], activation_quantizer)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != self.in_features:
+            raise RuntimeError(f"expected [N, {self.in_features}, H, W], got {tuple(x.shape)}")
+        b, _, h, w_ = x.shape
+        if x.dtype in (torch.uint8, torch.int8):
+            codes = x
+        else:
+            codes = ops.fq_codes(x, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
+        rows = codes.permute(0, 2, 3, 1)                   # a view for channels-last storage, else one byte transpose
+        y = super().forward(rows.reshape(b * h * w_, self.in_features) if rows.is_contiguous()
+                            else rows.contiguous().reshape(b * h * w_, self.in_features))
+        return y.reshape(b, h, w_, self.out_features).permute(0, 3, 1, 2)
+
+
+def _consumer_for(wrapper, activation_quantizer):
+    """The integer consumer that can stand in for ``wrapper`` fed by ``activation_quantizer``, or None."""
+    layer = getattr(wrapper, "layer", None)
+    if list(getattr(wrapper, "weights_quantizers", {})) != ["weight"]:
+        return None
+    try:
+        if isinstance(layer, nn.Linear) and layer.in_features % 16 == 0 and layer.in_features <= _MAX_K:
+            return QuantizedLinear.from_wrapper(wrapper, activation_quantizer)
+        if QuantizedConv1x1.eligible(layer) and layer.in_channels % 16 == 0 and layer.in_channels <= _MAX_K:
+            return QuantizedConv1x1.from_wrapper(wrapper, activation_quantizer)
+    except (TypeError, NotImplementedError):
+        return None
+    return None
+
+
 class _FusedAway(nn.Identity):
     """Placeholder left where an activation holder was folded into the QuantizedLinear after it."""
 
@@ -223,13 +286,8 @@ def fuse_linear_consumers(model: nn.Module, chain: bool = False) -> int:
             holder, wrapper = seq[i], seq[i + 1]
             if not _plain_holder(holder) or not isinstance(wrapper, PytorchQuantizationWrapper):
                 continue
-            if not isinstance(getattr(wrapper, "layer", None), nn.Linear) or list(wrapper.weights_quantizers) != ["weight"]:
-                continue
-            if wrapper.layer.in_features % 16 or wrapper.layer.in_features > _MAX_K:
-                continue
-            try:
-                fused = QuantizedLinear.from_wrapper(wrapper, holder.activation_holder_quantizer)
-            except (TypeError, NotImplementedError):
+            fused = _consumer_for(wrapper, holder.activation_holder_quantizer)
+            if fused is None:
                 continue
             seq[i] = _FusedAway()
             seq[i + 1] = fused
@@ -262,19 +320,16 @@ def fuse_linear_consumers_fx(model: nn.Module, chain: bool = False):
         if node.op != "call_module" or node.kwargs or len(node.args) != 1:
             continue
         wrapper = mods.get(node.target)
-        if not isinstance(wrapper, PytorchQuantizationWrapper) or not isinstance(getattr(wrapper, "layer", None), nn.Linear):
+        if not isinstance(wrapper, PytorchQuantizationWrapper):
             continue
         src = node.args[0]
         if not isinstance(src, fx.Node) or src.op != "call_module" or len(src.users) != 1 or len(src.args) != 1 or src.kwargs:
             continue
         holder = mods.get(src.target)
-        if not _plain_holder(holder) or list(wrapper.weights_quantizers) != ["weight"]:
+        if not _plain_holder(holder):
             continue
-        if wrapper.layer.in_features % 16 or wrapper.layer.in_features > _MAX_K:
-            continue
-        try:
-            fused = QuantizedLinear.from_wrapper(wrapper, holder.activation_holder_quantizer)
-        except (TypeError, NotImplementedError):
+        fused = _consumer_for(wrapper, holder.activation_holder_quantizer)
+        if fused is None:
             continue
         name = node.target.replace(".", "_") + "_qlinear"
         gm.add_submodule(name, fused)

@@ -392,3 +392,53 @@ def test_fx_fusion_on_a_branching_model_cpu():
 @pytest.mark.gpu
 def test_fx_fusion_on_a_branching_model_gpu():
     _check_fx_fusion("cuda")
+
+
+def _pointwise_block(c_in=32, c_mid=64, c_out=16, seed=3):
+    """holder -> wrapped 1x1 conv -> holder -> wrapped 1x1 conv (the pointwise pair of an inverted-residual block)."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(seed)
+    mods = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ci, co, aq in ((c_in, c_mid, Q.ActivationUniformInferableQuantizer(8, [-2.0], [2.5])),
+                           (c_mid, c_out, Q.ActivationSymmetricInferableQuantizer(8, [6.0], False))):
+            conv = torch.nn.Conv2d(ci, co, 1)
+            thr = [float(v) for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+            mods += [mq.PytorchActivationQuantizationHolder(aq),
+                     mq.PytorchQuantizationWrapper(conv, {"weight": Q.WeightsSymmetricInferableQuantizer(
+                         num_bits=8, threshold=thr, per_channel=True, channel_axis=0)})]
+    return torch.nn.Sequential(*mods)
+
+
+def _check_pointwise(device):
+    from mct_quantizers_amd import consumers
+    ref_model, model, chained = (_pointwise_block().to(device) for _ in range(3))
+    assert consumers.fuse_linear_consumers(model) == 2 and consumers.fuse_linear_consumers(chained, chain=True) == 2
+    assert isinstance(model[1], consumers.QuantizedConv1x1)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        x = (torch.randn(2, 32, 7, 5) * 1.5).to(device).contiguous(memory_format=fmt)
+        ref, y, yc = ref_model(x), model(x), chained(x)
+        assert y.shape == ref.shape == (2, 16, 7, 5)
+        assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5 * float(ref.detach().abs().max()))
+        assert torch.equal(y, yc)                                    # codes handed from conv to conv: same result
+    # layers the consumer cannot take stay as they are
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        strided = torch.nn.Sequential(
+            mq.PytorchActivationQuantizationHolder(Q.ActivationSymmetricInferableQuantizer(8, [2.0], True)),
+            mq.PytorchQuantizationWrapper(torch.nn.Conv2d(32, 8, 1, stride=2), {"weight": Q.WeightsSymmetricInferableQuantizer(
+                num_bits=8, threshold=[1.0], per_channel=False)}))
+    assert consumers.fuse_linear_consumers(strided) == 0
+
+
+def test_pointwise_convolution_consumer_cpu():
+    _check_pointwise("cpu")
+
+
+@pytest.mark.gpu
+def test_pointwise_convolution_consumer_gpu():
+    _check_pointwise("cuda")
