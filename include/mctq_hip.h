@@ -233,6 +233,16 @@ int mctq_grid_per_channel_f32(const float* x, float* y,
                               void* stream);
 
 /*
+ * Per-tensor codes with a layout change: x [batch][channels][pixels] (NCHW, pixels = H * W) -> codes
+ * [batch][pixels][channels] (NHWC), int8 / uint8, same arithmetic as mctq_fq_codes_per_tensor.  What a pointwise
+ * (1x1) convolution consumer feeds mctq_qlinear_i8 with (rows = pixels, K = channels) when the activation arrives
+ * in PyTorch's default layout.
+ */
+int mctq_fq_codes_nchw_to_nhwc(const void* x, void* codes, int64_t batch, int64_t channels, int64_t pixels, int32_t dtype,
+                               int32_t code_dtype, float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,
+                               void* stream);
+
+/*
  * Integer consumer of the codes (extension; the reference has no counterpart): the product a wrapped
  * torch.nn.Linear computes on fake-quantized operands -- PytorchQuantizationWrapper.forward
  * (pytorch/quantize_wrapper.py:231-257: quantize the weight, then self.layer(x)) fed by an activation holder

@@ -205,8 +205,8 @@ class QuantizedConv1x1(QuantizedLinear):
     """``activation quantizer -> PytorchQuantizationWrapper(nn.Conv2d 1x1)`` on integer codes: a pointwise convolution
     (kernel 1x1, stride 1, no padding / dilation / groups -- most of the multiply-accumulates of MobileNet-style
     networks) is the same product over the channel axis for every pixel, so it runs on the same kernels with
-    M = batch x height x width rows.  Channels-last inputs are consumed in place; NCHW inputs pay one transposition
-    of their 1-byte codes.  The result has the NCHW shape with channels-last strides."""
+    M = batch x height x width rows.  Channels-last inputs are quantized in place; NCHW inputs take one fused
+    quantize-and-transpose pass (``mctq_fq_codes_nchw_to_nhwc``).  The result has the NCHW shape with channels-last strides."""
 
     def __init__(self, conv: nn.Conv2d, weights_quantizer, activation_quantizer):
         if not self.eligible(conv):
@@ -238,13 +238,12 @@ class QuantizedConv1x1(QuantizedLinear):
         if x.dim() != 4 or x.shape[1] != self.in_features:
             raise RuntimeError(f"expected [N, {self.in_features}, H, W], got {tuple(x.shape)}")
         b, _, h, w_ = x.shape
-        if x.dtype in (torch.uint8, torch.int8):
-            codes = x
+        if x.dtype in (torch.uint8, torch.int8):          # codes from the previous layer: NCHW-shaped, NHWC-stored
+            rows = x.permute(0, 2, 3, 1)
+            rows = rows if rows.is_contiguous() else rows.contiguous()
         else:
-            codes = ops.fq_codes(x, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
-        rows = codes.permute(0, 2, 3, 1)                   # a view for channels-last storage, else one byte transpose
-        y = super().forward(rows.reshape(b * h * w_, self.in_features) if rows.is_contiguous()
-                            else rows.contiguous().reshape(b * h * w_, self.in_features))
+            rows = ops.fq_codes_nhwc(x, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
+        y = super().forward(rows.reshape(b * h * w_, self.in_features))
         return y.reshape(b, h, w_, self.out_features).permute(0, 3, 1, 2)
 
 

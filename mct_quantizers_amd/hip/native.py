@@ -81,6 +81,9 @@ SIGNATURES = {
                                          ctypes.c_void_p, _c_f32p, _c_i32p, _c_f32p, ctypes.c_void_p, ctypes.c_int32,
                                          ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "mctq_fq_codes_nchw_to_nhwc": (ctypes.c_int, [_c_f32p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
+                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mctq_lut_table_entries": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float]),
     "mctq_lut_build_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_void_p]),

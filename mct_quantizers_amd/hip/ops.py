@@ -352,6 +352,28 @@ def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float =
     return y
 
 
+def fq_codes_nhwc(x, qmin: int, qmax: int, scale: float, zero_point: int):
+    """Per-tensor codes of a 4-D activation as a contiguous [N, H, W, C] int8 / uint8 tensor, whatever x's memory
+    format.  NCHW-contiguous GPU tensors take one fused quantize-and-transpose pass (mctq_fq_codes_nchw_to_nhwc);
+    channels-last ones are quantized in place (their storage order already is NHWC)."""
+    if x.dim() != 4:
+        raise ValueError("fq_codes_nhwc takes [N, C, H, W] tensors")
+    b, c, h, w = x.shape
+    if x.is_cuda and x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last):
+        tdt, code = _code_dtype(qmin, qmax)
+        dt = _dtype_code(x, "fq_codes_nhwc")
+        lib = native.load()
+        y = torch.empty((b, h, w, c), dtype=tdt, device=x.device)
+        with _maybe_on_device(x):
+            rc = _launch(lib.mctq_fq_codes_nchw_to_nhwc, x.data_ptr(), y.data_ptr(), b, c, h * w, dt, code, float(scale),
+                         int(zero_point), qmin, qmax, _stream(x))
+        if rc:
+            native.check(rc, "mctq_fq_codes_nchw_to_nhwc")
+        return y
+    codes = fq_codes(x, None, None, None, qmin, qmax, scale, zero_point)
+    return codes.permute(0, 2, 3, 1).contiguous()          # a no-op view + check for channels-last storage
+
+
 def make_lut_table(lut_values, mult: float, cmin: float, cmax: float, device):
     """Device copy of the codebook's decision table (see include/mctq_hip.h), or None.
 

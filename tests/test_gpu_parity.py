@@ -896,3 +896,18 @@ def test_packed_4bit_codes_reject_unsupported_layouts_and_domains(lib):
         == native.MCTQ_E_ARG
     assert lib.mctq_fq_codes_per_tensor(x.data_ptr(), y.data_ptr(), 70, native.DT_F32, native.CODE_U4, 0.1, 0, 0, 15, st) \
         == native.MCTQ_E_ARG
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 32, 7, 5), (1, 128, 8, 8), (3, 130, 6, 6), (2, 16, 1, 1), (1, 576, 14, 14), (2, 48, 3, 5)])
+def test_fused_quantize_and_nchw_to_nhwc_codes(lib, dtype, shape):
+    from mct_quantizers_amd.hip import ops
+    x = (torch.randn(*shape) * 2).to(dtype)
+    for (qmin, qmax, scale, zp) in ((0, 255, 0.0219, 114), (-128, 127, 0.031, 0), (0, 15, 0.3, 7)):
+        got = ops.fq_codes_nhwc(x.cuda(), qmin, qmax, scale, zp)
+        want = ops.fq_codes(x.cuda(), None, None, None, qmin, qmax, scale, zp).permute(0, 2, 3, 1).contiguous()
+        assert got.shape == (shape[0], shape[2], shape[3], shape[1]) and got.is_contiguous() and got.dtype == want.dtype
+        assert torch.equal(got, want), (shape, dtype, qmin)
+        cl = x.cuda().contiguous(memory_format=torch.channels_last)
+        assert torch.equal(ops.fq_codes_nhwc(cl, qmin, qmax, scale, zp), want)
+        assert torch.equal(ops.fq_codes_nhwc(x, qmin, qmax, scale, zp), want.cpu())          # CPU route
