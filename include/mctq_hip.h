@@ -46,13 +46,14 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 3
+#define MCTQ_ABI_VERSION 4
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
 #define MCTQ_DT_F32 0
 #define MCTQ_DT_F16 1
 #define MCTQ_DT_BF16 2
+#define MCTQ_DT_F64 3   /* float64 tensors: ATen's double arithmetic, see "float64" below */
 
 /* storage types of the integer-code outputs */
 #define MCTQ_CODE_I8 0
@@ -92,6 +93,52 @@ int mctq_fq_per_channel(const void* x, void* y,
                         const float* scales, const int32_t* zero_points,
                         int32_t quant_min, int32_t quant_max,
                         void* stream);
+
+/*
+ * float64 (dtype = MCTQ_DT_F64, accepted by mctq_fq_per_tensor, mctq_fq_per_channel, mctq_fq_per_tensor_tqp,
+ * mctq_lut_per_tensor, mctq_lut_per_channel and mctq_lut_per_tensor_f64; the reference passes double tensors
+ * straight to ATen at the call sites listed at the top).  ATen's double path is not float32 arithmetic on wider
+ * storage, and the package reproduces it as measured against the reference (tests/golden/cases_f64.*):
+ *   q = clamp(rint(x * (double)(1.0f / scale)) + zp, qmin, qmax)      double product, double rounding
+ *   per tensor (float or tensor qparams):  y = (double)((float)(q - zp) * scale)
+ *   per channel:                           y = (double)(q - zp) * (double)scale
+ *   LUT: the scaled value, the clip and the distances |t - lut[j]| are evaluated in double, the result
+ *        (lut[j] / mult) * thr_mul in float32 -- y is float32.
+ */
+
+/*
+ * Per-tensor fake-quant whose scale and zero point are 1-element DEVICE arrays (read by the kernel through scalar
+ * loads; no device->host copy): the tensor-qparams overload of torch.fake_quantize_per_tensor_affine, called by the
+ * per-tensor weights quantizers (weights_symmetric_inferable_quantizer.py:147-151, weights_uniform...py:161-165)
+ * and recorded as such by an fx trace of a wrapper (saved-model flow, pytorch/load_model.py:23-34).
+ */
+int mctq_fq_per_tensor_tqp(const void* x, void* y, int64_t n, int32_t dtype,
+                           const float* scale, const int32_t* zero_point, int32_t quant_min, int32_t quant_max,
+                           void* stream);
+
+/*
+ * A LIST of affine fake-quantizations in one call -- one launch per group of up to 32 tensors of one storage
+ * type.  PytorchQuantizationWrapper.forward re-quantizes each wrapped layer's weights on every forward
+ * (pytorch/quantize_wrapper.py:228-240); a model has tens of such layers, and each separate launch pays its own
+ * host cost and ~2 us of ramp/drain on the GPU.  `items` is a HOST array (it is consumed before the call returns:
+ * the descriptors travel in the kernel arguments, so the call is legal under hipGraph capture); every pointer
+ * inside an item is a DEVICE pointer with the meaning it has in mctq_fq_per_channel.  Per-tensor quantization is
+ * outer = channels = 1, inner = n with 1-element device scales / zero_points.  Tensors the batched kernel cannot
+ * take (x or y not 16-byte aligned, >= 2^31 elements, float64) are launched one by one on the same stream.
+ * All items are validated before anything is launched.
+ */
+typedef struct mctq_fq_item {
+  const void* x;
+  void* y;
+  int64_t outer, channels, inner;
+  const float* scales;           /* device float32[channels] */
+  const int32_t* zero_points;    /* device int32[channels], or NULL = all zero */
+  int32_t quant_min, quant_max;
+  int32_t dtype;                 /* MCTQ_DT_*: storage type of x and y */
+  int32_t reserved;              /* set to 0 */
+} mctq_fq_item;
+
+int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream);
 
 /*
  * Integer-code output of the affine quantizers: codes[i] = clamp(rint(x[i] * (1/scale)) + zero_point, quant_min,
@@ -141,8 +188,8 @@ int mctq_lut_per_channel_f32(const float* x, float* y,
  * step_round (per-tensor only): 0, or MCTQ_DT_F16 / MCTQ_DT_BF16 to round the quotient x/thr_div and the
  * scaled value to that type, which is what the reference's chain does to a half-precision activation
  * divided by a Python-float threshold (activation_lut_pot_inferable_quantizer.py:86-91); thr_div must then
- * already be rounded to that type by the caller.  The literal-scan entry points (mctq_lut_*) accept
- * MCTQ_DT_F32 only; the decision-table ones (mctq_lutt_*) accept all three.
+ * already be rounded to that type by the caller.  The literal-scan entry points (mctq_lut_*) accept all four
+ * storage types (MCTQ_DT_F64: see "float64"); the decision-table ones (mctq_lutt_*) float32 / float16 / bfloat16.
  */
 int mctq_lut_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32_t step_round,
                         float thr_div, float thr_mul,
@@ -156,6 +203,14 @@ int mctq_lut_per_channel(const void* x, float* y,
                          const float* lut, int32_t n_lut,
                          float mult, float clip_min, float clip_max,
                          void* stream);
+
+/* float64 input with a DOUBLE divisor: the activation LUT quantizer divides a double tensor by the Python float
+ * threshold + eps (activation_lut_pot_inferable_quantizer.py:86-91), which stays a double; thr_mul = float32(threshold). */
+int mctq_lut_per_tensor_f64(const double* x, float* y, int64_t n,
+                            double thr_div, float thr_mul,
+                            const float* lut, int32_t n_lut,
+                            float mult, float clip_min, float clip_max,
+                            void* stream);
 
 /*
  * Decision-table form of the LUT quantizer (integer codebooks, clip range of at most 1023.5 units).

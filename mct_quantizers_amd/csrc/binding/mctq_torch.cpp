@@ -1,0 +1,401 @@
+// mctq_torch.cpp -- compiled Python binding of the hot entry points of libmctq_hip.so (C ABI: include/mctq_hip.h).
+//
+// Why: small activations are launch-bound -- per call the host cost IS the cost (BASELINE config 3).
+// Through ctypes a call costs ~4.4 us before any tensor bookkeeping; this module does tensor checks, output
+// allocation (torch's caching allocator), the stream lookup and the C-ABI call in one CPython FASTCALL.
+// It adds no arithmetic and no kernels: every function ends in the same extern "C" entry point the ctypes
+// binding (hip/native.py) calls, so the two bindings are interchangeable and the tests run both.
+//
+// Contract of every function: returns a new tensor, or Py_NotImplemented when the argument is not a plain,
+// dense, supported-dtype HIP tensor in eager mode (CPU tensor, tensor subclass / FakeTensor, fx Proxy, an active
+// torch.jit trace, gaps in the storage, float64 ...).  The Python caller (hip/ops.py) then takes the general route,
+// which knows what the reference does in each of those cases.  A failing launch raises RuntimeError with
+// mctq_last_error().
+//
+// Replaces, on the Python side of the boundary, the call sites
+//   torch.fake_quantize_per_tensor_affine   activation_uniform_inferable_quantizer.py:124, activation_symmetric...py:113,
+//                                           weights_symmetric_inferable_quantizer.py:147, weights_uniform...py:161
+//   torch.fake_quantize_per_channel_affine  weights_symmetric_inferable_quantizer.py:139, weights_uniform...py:153
+//   lut_quantizer                           pytorch/quantizer_utils.py:95-139
+// (paths under /root/reference/mct_quantizers/pytorch/quantizers/).
+//
+// Host-only C++ (no device code); written against the HIP names of PyTorch-ROCm (c10::hip, at::detail::empty_*_cuda
+// as exported by libtorch_hip).
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <ATen/core/Tensor.h>
+#include <ATen/hip/EmptyTensor.h>
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/python_variable.h>
+#include <torch/csrc/jit/frontend/tracer.h>
+#include <torch/csrc/utils/python_arg_parser.h>
+
+#include <vector>
+
+#include "mctq_hip.h"
+
+namespace {
+
+inline int dtype_code(c10::ScalarType t) {
+  switch (t) {
+    case c10::ScalarType::Float: return MCTQ_DT_F32;
+    case c10::ScalarType::Half: return MCTQ_DT_F16;
+    case c10::ScalarType::BFloat16: return MCTQ_DT_BF16;
+    case c10::ScalarType::Double: return MCTQ_DT_F64;
+    default: return -1;
+  }
+}
+
+// A plain eager HIP tensor the kernels can take as it is?  (Parameter is allowed: weights arrive as one.)
+inline const at::Tensor* eligible(PyObject* obj, int* dt) {
+  if (!THPVariable_Check(obj)) return nullptr;
+  PyTypeObject* tp = Py_TYPE(obj);
+  if (tp != (PyTypeObject*)THPVariableClass && tp != (PyTypeObject*)ParameterClass) return nullptr;
+  const at::Tensor& x = THPVariable_Unpack(obj);
+  if (!x.is_cuda() || x.layout() != c10::kStrided) return nullptr;
+  *dt = dtype_code(x.scalar_type());
+  if (*dt < 0) return nullptr;
+  if (!x.unsafeGetTensorImpl()->is_non_overlapping_and_dense()) return nullptr;
+  if (torch::jit::tracer::isTracing()) return nullptr;
+  return &x;
+}
+
+// Output with the input's sizes AND strides: what ATen's empty_like (preserve format) gives for a non-overlapping
+// dense tensor -- including the arbitrary strides of size-1 dimensions, which the reference's outputs keep.
+inline at::Tensor like(const at::Tensor& x, c10::ScalarType dtype) {
+  return at::Tensor(at::detail::empty_strided_cuda(x.sizes(), x.strides(), dtype, x.device()));
+}
+
+struct DeviceScope {          // make x's device current for the launch only when it is not already
+  c10::DeviceIndex prev = -1;
+  explicit DeviceScope(c10::DeviceIndex idx) {
+    const c10::DeviceIndex cur = c10::hip::current_device();
+    if (cur != idx) { prev = cur; c10::hip::set_device(idx); }
+  }
+  ~DeviceScope() { if (prev >= 0) c10::hip::set_device(prev); }
+};
+
+inline PyObject* raise_rc(int rc, const char* what) {
+  PyErr_Format(PyExc_RuntimeError, "%s failed (rc=%d): %s", what, rc, mctq_last_error());
+  return nullptr;
+}
+
+inline PyObject* not_implemented() { Py_RETURN_NOTIMPLEMENTED; }
+
+// (outer, channels, inner) of a dense tensor in storage order for logical dimension `axis` (hip/ops.py:_channel_view)
+inline void channel_view(const at::Tensor& x, int64_t axis, int64_t* outer, int64_t* c, int64_t* inner) {
+  const int64_t n = x.numel();
+  *c = x.size(axis);
+  if (x.is_contiguous()) {
+    int64_t in = 1;
+    for (int64_t d = axis + 1; d < x.dim(); ++d) in *= x.size(d);
+    *inner = in;
+  } else {
+    *inner = *c > 1 ? x.stride(axis) : 1;
+  }
+  const int64_t per = *c * *inner;
+  *outer = per != 0 ? n / per : 0;
+}
+
+// A parameter vector usable as it is: float32 / int32, contiguous, on x's device, `want` elements.
+inline const at::Tensor* param_tensor(PyObject* obj, const at::Tensor& x, c10::ScalarType dtype, int64_t want) {
+  if (!THPVariable_Check(obj)) return nullptr;
+  const at::Tensor& t = THPVariable_Unpack(obj);
+  if (t.scalar_type() != dtype || !t.is_contiguous() || t.device() != x.device() || (want >= 0 && t.numel() != want))
+    return nullptr;
+  return &t;
+}
+
+inline bool as_double(PyObject* o, double* v) {
+  *v = PyFloat_AsDouble(o);
+  return !(*v == -1.0 && PyErr_Occurred());
+}
+inline bool as_i64(PyObject* o, int64_t* v) {
+  *v = PyLong_AsLongLong(o);
+  return !(*v == -1 && PyErr_Occurred());
+}
+
+// ---- per-tensor affine ---------------------------------------------------------------------------------
+PyObject* launch_fq_per_tensor(PyObject* xo, float scale, int32_t zp, int32_t qmin, int32_t qmax) {
+  int dt;
+  const at::Tensor* xp = eligible(xo, &dt);
+  if (!xp) return not_implemented();
+  const at::Tensor& x = *xp;
+  at::Tensor y = like(x, x.scalar_type());
+  const c10::DeviceIndex idx = x.device().index();
+  DeviceScope scope(idx);
+  const int rc = mctq_fq_per_tensor(x.const_data_ptr(), y.mutable_data_ptr(), x.numel(), dt, scale, zp, qmin, qmax,
+                                    (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  if (rc) return raise_rc(rc, "mctq_fq_per_tensor");
+  return THPVariable_Wrap(std::move(y));
+}
+
+// fq_per_tensor(x, scale, zero_point, quant_min, quant_max)
+PyObject* py_fq_per_tensor(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 5) { PyErr_SetString(PyExc_TypeError, "fq_per_tensor(x, scale, zero_point, quant_min, quant_max)"); return nullptr; }
+  double scale; int64_t zp, qmin, qmax;
+  if (!as_double(args[1], &scale) || !as_i64(args[2], &zp) || !as_i64(args[3], &qmin) || !as_i64(args[4], &qmax)) return nullptr;
+  return launch_fq_per_tensor(args[0], (float)scale, (int32_t)zp, (int32_t)qmin, (int32_t)qmax);
+}
+
+// ---- per-channel affine --------------------------------------------------------------------------------
+PyObject* launch_fq_per_channel(PyObject* xo, PyObject* scales_o, PyObject* zps_o, int64_t axis, int32_t qmin, int32_t qmax) {
+  int dt;
+  const at::Tensor* xp = eligible(xo, &dt);
+  if (!xp) return not_implemented();
+  const at::Tensor& x = *xp;
+  if (axis < 0 || axis >= x.dim()) return not_implemented();            // the general route raises ATen's message
+  const at::Tensor* sp = param_tensor(scales_o, x, c10::ScalarType::Float, x.size(axis));
+  if (!sp) return not_implemented();
+  const at::Tensor* zp = nullptr;
+  if (zps_o != Py_None) {
+    zp = param_tensor(zps_o, x, c10::ScalarType::Int, x.size(axis));
+    if (!zp) return not_implemented();
+  }
+  at::Tensor y = like(x, x.scalar_type());
+  int64_t outer, c, inner;
+  channel_view(x, axis, &outer, &c, &inner);
+  const c10::DeviceIndex idx = x.device().index();
+  DeviceScope scope(idx);
+  const int rc = mctq_fq_per_channel(x.const_data_ptr(), y.mutable_data_ptr(), outer, c, inner, dt, sp->const_data_ptr<float>(),
+                                     zp ? zp->const_data_ptr<int32_t>() : nullptr, qmin, qmax,
+                                     (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  if (rc) return raise_rc(rc, "mctq_fq_per_channel");
+  return THPVariable_Wrap(std::move(y));
+}
+
+// fq_per_channel(x, scales, zero_points | None, axis, quant_min, quant_max)
+PyObject* py_fq_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 6) { PyErr_SetString(PyExc_TypeError, "fq_per_channel(x, scales, zero_points, axis, quant_min, quant_max)"); return nullptr; }
+  int64_t axis, qmin, qmax;
+  if (!as_i64(args[3], &axis) || !as_i64(args[4], &qmin) || !as_i64(args[5], &qmax)) return nullptr;
+  return launch_fq_per_channel(args[0], args[1], args[2], axis, (int32_t)qmin, (int32_t)qmax);
+}
+
+// ---- per-tensor affine, parameters read on the device ---------------------------------------------------
+// fq_per_tensor_tqp(x, scale_tensor, zero_point_tensor, quant_min, quant_max): the tensor-qparams overload
+// (weights_symmetric_inferable_quantizer.py:147-151 passes 1-element tensors); no device->host read.
+PyObject* py_fq_per_tensor_tqp(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 5) { PyErr_SetString(PyExc_TypeError, "fq_per_tensor_tqp(x, scale, zero_point, quant_min, quant_max)"); return nullptr; }
+  int64_t qmin, qmax;
+  if (!as_i64(args[3], &qmin) || !as_i64(args[4], &qmax)) return nullptr;
+  int dt;
+  const at::Tensor* xp = eligible(args[0], &dt);
+  if (!xp) return not_implemented();
+  const at::Tensor& x = *xp;
+  const at::Tensor* sp = param_tensor(args[1], x, c10::ScalarType::Float, 1);
+  const at::Tensor* zp = param_tensor(args[2], x, c10::ScalarType::Int, 1);
+  if (!sp || !zp) return not_implemented();
+  at::Tensor y = like(x, x.scalar_type());
+  const c10::DeviceIndex idx = x.device().index();
+  DeviceScope scope(idx);
+  const int rc = mctq_fq_per_tensor_tqp(x.const_data_ptr(), y.mutable_data_ptr(), x.numel(), dt, sp->const_data_ptr<float>(),
+                                        zp->const_data_ptr<int32_t>(), (int32_t)qmin, (int32_t)qmax,
+                                        (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  if (rc) return raise_rc(rc, "mctq_fq_per_tensor_tqp");
+  return THPVariable_Wrap(std::move(y));
+}
+
+// ---- LUT, decision table ---------------------------------------------------------------------------------
+// lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, clip_min, clip_max) -> float32 tensor
+PyObject* py_lutt_per_tensor(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 8) { PyErr_SetString(PyExc_TypeError, "lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, clip_min, clip_max)"); return nullptr; }
+  int64_t step_round; double thr_div, thr_mul, mult, cmin, cmax;
+  if (!as_i64(args[2], &step_round) || !as_double(args[3], &thr_div) || !as_double(args[4], &thr_mul) ||
+      !as_double(args[5], &mult) || !as_double(args[6], &cmin) || !as_double(args[7], &cmax)) return nullptr;
+  int dt;
+  const at::Tensor* xp = eligible(args[0], &dt);
+  if (!xp || dt == MCTQ_DT_F64) return not_implemented();
+  const at::Tensor& x = *xp;
+  const at::Tensor* tp = param_tensor(args[1], x, c10::ScalarType::Float, -1);
+  if (!tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();
+  at::Tensor y = like(x, c10::ScalarType::Float);
+  const c10::DeviceIndex idx = x.device().index();
+  DeviceScope scope(idx);
+  const int rc = mctq_lutt_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, (int32_t)step_round,
+                                      (float)thr_div, (float)thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->size(0) - 1,
+                                      (float)mult, (float)cmin, (float)cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  if (rc) return raise_rc(rc, "mctq_lutt_per_tensor");
+  return THPVariable_Wrap(std::move(y));
+}
+
+// lutt_per_channel(x, thresholds, eps, table, axis, mult, clip_min, clip_max) -> float32 tensor
+PyObject* py_lutt_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 8) { PyErr_SetString(PyExc_TypeError, "lutt_per_channel(x, thresholds, eps, table, axis, mult, clip_min, clip_max)"); return nullptr; }
+  int64_t axis; double eps, mult, cmin, cmax;
+  if (!as_double(args[2], &eps) || !as_i64(args[4], &axis) || !as_double(args[5], &mult) || !as_double(args[6], &cmin) ||
+      !as_double(args[7], &cmax)) return nullptr;
+  int dt;
+  const at::Tensor* xp = eligible(args[0], &dt);
+  if (!xp || dt == MCTQ_DT_F64) return not_implemented();
+  const at::Tensor& x = *xp;
+  if (axis < 0 || axis >= x.dim()) return not_implemented();
+  const at::Tensor* thr = param_tensor(args[1], x, c10::ScalarType::Float, x.size(axis));
+  const at::Tensor* tp = param_tensor(args[3], x, c10::ScalarType::Float, -1);
+  if (!thr || !tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();
+  at::Tensor y = like(x, c10::ScalarType::Float);
+  int64_t outer, c, inner;
+  channel_view(x, axis, &outer, &c, &inner);
+  const c10::DeviceIndex idx = x.device().index();
+  DeviceScope scope(idx);
+  const int rc = mctq_lutt_per_channel(x.const_data_ptr(), y.mutable_data_ptr<float>(), outer, c, inner, dt,
+                                       thr->const_data_ptr<float>(), (float)eps, tp->const_data_ptr<float>(),
+                                       (int32_t)tp->size(0) - 1, (float)mult, (float)cmin, (float)cmax,
+                                       (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  if (rc) return raise_rc(rc, "mctq_lutt_per_channel");
+  return THPVariable_Wrap(std::move(y));
+}
+
+// ---- a list of weights in ONE launch ------------------------------------------------------------------
+// fq_batched(items) with items = sequence of (x, scales, zero_points | None, axis | None, quant_min, quant_max);
+// axis None = per tensor (scales / zero_points are 1-element device tensors).  Returns a list of new tensors,
+// or NotImplemented if any item is not eligible (the caller then quantizes them one by one).
+PyObject* py_fq_batched(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 1) { PyErr_SetString(PyExc_TypeError, "fq_batched(items)"); return nullptr; }
+  PyObject* seq = PySequence_Fast(args[0], "fq_batched expects a sequence of tuples");
+  if (!seq) return nullptr;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+  std::vector<mctq_fq_item> items((size_t)n);
+  std::vector<at::Tensor> outs;
+  outs.reserve((size_t)n);
+  c10::DeviceIndex idx = -1;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject* it = PySequence_Fast_GET_ITEM(seq, i);
+    if (!PyTuple_Check(it) || PyTuple_GET_SIZE(it) != 6) {
+      Py_DECREF(seq);
+      PyErr_SetString(PyExc_TypeError, "fq_batched item: (x, scales, zero_points, axis, quant_min, quant_max)");
+      return nullptr;
+    }
+    int dt;
+    const at::Tensor* xp = eligible(PyTuple_GET_ITEM(it, 0), &dt);
+    int64_t qmin, qmax, axis = -1;
+    PyObject* axis_o = PyTuple_GET_ITEM(it, 3);
+    if (!as_i64(PyTuple_GET_ITEM(it, 4), &qmin) || !as_i64(PyTuple_GET_ITEM(it, 5), &qmax) ||
+        (axis_o != Py_None && !as_i64(axis_o, &axis))) { Py_DECREF(seq); return nullptr; }
+    bool ok = xp != nullptr && (axis_o == Py_None || (axis >= 0 && axis < xp->dim()));
+    const at::Tensor *sp = nullptr, *zp = nullptr;
+    if (ok) {
+      if (idx < 0) idx = xp->device().index();
+      ok = xp->device().index() == idx;
+      const int64_t want = axis_o == Py_None ? 1 : xp->size(axis);
+      sp = param_tensor(PyTuple_GET_ITEM(it, 1), *xp, c10::ScalarType::Float, want);
+      ok = ok && sp != nullptr;
+      if (PyTuple_GET_ITEM(it, 2) != Py_None) {
+        zp = param_tensor(PyTuple_GET_ITEM(it, 2), *xp, c10::ScalarType::Int, want);
+        ok = ok && zp != nullptr;
+      }
+    }
+    if (!ok) { Py_DECREF(seq); return not_implemented(); }
+    outs.push_back(like(*xp, xp->scalar_type()));
+    mctq_fq_item& d = items[(size_t)i];
+    d.x = xp->const_data_ptr(); d.y = outs.back().mutable_data_ptr();
+    if (axis_o == Py_None) { d.outer = 1; d.channels = 1; d.inner = xp->numel(); }
+    else channel_view(*xp, axis, &d.outer, &d.channels, &d.inner);
+    d.scales = sp->const_data_ptr<float>();
+    d.zero_points = zp ? zp->const_data_ptr<int32_t>() : nullptr;
+    d.quant_min = (int32_t)qmin; d.quant_max = (int32_t)qmax; d.dtype = dt;
+  }
+  Py_DECREF(seq);
+  if (n > 0) {
+    DeviceScope scope(idx);
+    const int rc = mctq_fq_batched(items.data(), (int32_t)n, (void*)c10::hip::getCurrentHIPStream(idx).stream());
+    if (rc) return raise_rc(rc, "mctq_fq_batched");
+  }
+  PyObject* list = PyList_New(n);
+  if (!list) return nullptr;
+  for (Py_ssize_t i = 0; i < n; ++i) PyList_SET_ITEM(list, i, THPVariable_Wrap(std::move(outs[(size_t)i])));
+  return list;
+}
+
+// ---- pre-packed launch arguments: plan = AffinePlan(scale, zp, qmin, qmax) / AffinePlan(scales, zps|None, axis, qmin, qmax);
+//      plan(x) -> tensor | NotImplemented -------------------------------------------------------------------
+struct AffinePlan {
+  PyObject_HEAD
+  vectorcallfunc vectorcall;
+  PyObject* scales;       // NULL: per tensor
+  PyObject* zps;          // Py_None or tensor (per channel)
+  int64_t axis;
+  float scale;
+  int32_t zp, qmin, qmax;
+};
+
+PyObject* plan_vectorcall(PyObject* self, PyObject* const* args, size_t nargsf, PyObject* kwnames) {
+  AffinePlan* p = (AffinePlan*)self;
+  if (PyVectorcall_NARGS(nargsf) != 1 || (kwnames && PyTuple_GET_SIZE(kwnames))) {
+    PyErr_SetString(PyExc_TypeError, "AffinePlan.__call__(x)");
+    return nullptr;
+  }
+  if (!p->scales) return launch_fq_per_tensor(args[0], p->scale, p->zp, p->qmin, p->qmax);
+  return launch_fq_per_channel(args[0], p->scales, p->zps, p->axis, p->qmin, p->qmax);
+}
+
+PyObject* plan_new(PyTypeObject* type, PyObject* args, PyObject*) {
+  const Py_ssize_t n = PyTuple_GET_SIZE(args);
+  AffinePlan* p = (AffinePlan*)type->tp_alloc(type, 0);
+  if (!p) return nullptr;
+  p->vectorcall = plan_vectorcall;
+  p->scales = nullptr; p->zps = nullptr; p->axis = 0;
+  int64_t zp = 0, qmin, qmax;
+  if (n == 4) {
+    double scale;
+    if (!as_double(PyTuple_GET_ITEM(args, 0), &scale) || !as_i64(PyTuple_GET_ITEM(args, 1), &zp) ||
+        !as_i64(PyTuple_GET_ITEM(args, 2), &qmin) || !as_i64(PyTuple_GET_ITEM(args, 3), &qmax)) { Py_DECREF(p); return nullptr; }
+    p->scale = (float)scale;
+  } else if (n == 5) {
+    if (!as_i64(PyTuple_GET_ITEM(args, 2), &p->axis) || !as_i64(PyTuple_GET_ITEM(args, 3), &qmin) ||
+        !as_i64(PyTuple_GET_ITEM(args, 4), &qmax)) { Py_DECREF(p); return nullptr; }
+    p->scales = PyTuple_GET_ITEM(args, 0); Py_INCREF(p->scales);
+    p->zps = PyTuple_GET_ITEM(args, 1); Py_INCREF(p->zps);
+  } else {
+    Py_DECREF(p);
+    PyErr_SetString(PyExc_TypeError, "AffinePlan(scale, zero_point, qmin, qmax) or AffinePlan(scales, zero_points, axis, qmin, qmax)");
+    return nullptr;
+  }
+  p->zp = (int32_t)zp; p->qmin = (int32_t)qmin; p->qmax = (int32_t)qmax;
+  return (PyObject*)p;
+}
+
+void plan_dealloc(PyObject* self) {
+  AffinePlan* p = (AffinePlan*)self;
+  Py_XDECREF(p->scales);
+  Py_XDECREF(p->zps);
+  Py_TYPE(self)->tp_free(self);
+}
+
+PyTypeObject AffinePlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
+PyObject* py_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(mctq_abi_version()); }
+
+PyMethodDef methods[] = {
+    {"fq_per_tensor", (PyCFunction)(void (*)(void))py_fq_per_tensor, METH_FASTCALL, nullptr},
+    {"fq_per_channel", (PyCFunction)(void (*)(void))py_fq_per_channel, METH_FASTCALL, nullptr},
+    {"fq_per_tensor_tqp", (PyCFunction)(void (*)(void))py_fq_per_tensor_tqp, METH_FASTCALL, nullptr},
+    {"lutt_per_tensor", (PyCFunction)(void (*)(void))py_lutt_per_tensor, METH_FASTCALL, nullptr},
+    {"lutt_per_channel", (PyCFunction)(void (*)(void))py_lutt_per_channel, METH_FASTCALL, nullptr},
+    {"fq_batched", (PyCFunction)(void (*)(void))py_fq_batched, METH_FASTCALL, nullptr},
+    {"abi_version", py_abi_version, METH_NOARGS, nullptr},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_mctq_torch",
+                         "compiled binding of libmctq_hip.so's hot entry points (see mctq_torch.cpp)", -1, methods};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__mctq_torch(void) {
+  AffinePlanType.tp_name = "_mctq_torch.AffinePlan";
+  AffinePlanType.tp_basicsize = sizeof(AffinePlan);
+  AffinePlanType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL;
+  AffinePlanType.tp_new = plan_new;
+  AffinePlanType.tp_dealloc = plan_dealloc;
+  AffinePlanType.tp_call = PyVectorcall_Call;
+  AffinePlanType.tp_vectorcall_offset = offsetof(AffinePlan, vectorcall);
+  if (PyType_Ready(&AffinePlanType) < 0) return nullptr;
+  PyObject* m = PyModule_Create(&moduledef);
+  if (!m) return nullptr;
+  Py_INCREF(&AffinePlanType);
+  if (PyModule_AddObject(m, "AffinePlan", (PyObject*)&AffinePlanType) < 0) { Py_DECREF(m); return nullptr; }
+  return m;
+}

@@ -3,6 +3,12 @@
 
 using namespace mctq;
 
+namespace mctq {        // mctq_f64.hip
+int fq64_per_tensor(const void* x, void* y, int64_t n, float scale, int32_t zp, int32_t qmin, int32_t qmax, hipStream_t st);
+int fq64_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
+                     const int32_t* zps, int32_t qmin, int32_t qmax, bool wide, hipStream_t st);
+}
+
 extern "C" {
 
 // ---- affine ---------------------------------------------------------------------------------------
@@ -12,6 +18,7 @@ int mctq_fq_per_tensor(const void* x, void* y, int64_t n, int32_t dtype, float s
   if (n < 0) return fail_arg("n < 0");
   if (n > 0 && (!x || !y)) return fail_arg("x or y is NULL");
   if (quant_min > quant_max) return fail_arg("quant_min > quant_max");
+  if (dtype == MCTQ_DT_F64) return fq64_per_tensor(x, y, n, scale, zero_point, quant_min, quant_max, (hipStream_t)stream);
   AffineOp op;
   op.scales = nullptr; op.zps = nullptr;
   op.lo = (float)quant_min; op.hi = (float)quant_max;
@@ -28,12 +35,30 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
   if (quant_min > quant_max) return fail_arg("quant_min > quant_max");
   const int64_t n = outer * channels * inner;
   if (n > 0 && (!x || !y || !scales)) return fail_arg("NULL pointer");
+  if (dtype == MCTQ_DT_F64)
+    return fq64_per_channel(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, true, (hipStream_t)stream);
   AffineOp op;
   op.scales = scales; op.zps = zero_points;
   op.lo = (float)quant_min; op.hi = (float)quant_max;
   return with_affine_types(dtype, [&](auto ti, auto to) {
     return launch_channels<decltype(ti), decltype(to)>(op, x, y, outer, channels, inner, 0, (hipStream_t)stream);
   });
+}
+
+// Per-tensor fake-quant with the scale and zero point READ ON THE DEVICE (1-element tensors): the
+// tensor-qparams overload of torch.fake_quantize_per_tensor_affine, which is what the per-tensor weights
+// quantizers call (weights_symmetric_inferable_quantizer.py:147-151) and what an fx trace of a wrapper records.
+// One row of one channel: the parameters arrive through scalar loads, no device->host read anywhere.
+int mctq_fq_per_tensor_tqp(const void* x, void* y, int64_t n, int32_t dtype, const float* scale,
+                           const int32_t* zero_point, int32_t quant_min, int32_t quant_max, void* stream) {
+  if (n < 0) return fail_arg("n < 0");
+  if (n > 0 && (!scale || !zero_point)) return fail_arg("scale or zero_point is NULL");
+  if (dtype == MCTQ_DT_F64) {          // per-tensor flavour of the float64 arithmetic (float32 product, widened)
+    if (n > 0 && (!x || !y)) return fail_arg("x or y is NULL");
+    if (quant_min > quant_max) return fail_arg("quant_min > quant_max");
+    return fq64_per_channel(x, y, n > 0 ? 1 : 0, 1, n, scale, zero_point, quant_min, quant_max, false, (hipStream_t)stream);
+  }
+  return mctq_fq_per_channel(x, y, n > 0 ? 1 : 0, 1, n, dtype, scale, zero_point, quant_min, quant_max, stream);
 }
 
 int mctq_fq_per_tensor_f32(const float* x, float* y, int64_t n, float scale, int32_t zero_point, int32_t quant_min,

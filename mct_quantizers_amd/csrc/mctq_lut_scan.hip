@@ -3,6 +3,11 @@
 
 using namespace mctq;
 
+namespace mctq {        // mctq_f64.hip
+int lut64_per_channel(const void* x, float* y, int64_t outer, int64_t channels, int64_t inner, const float* thr, float eps,
+                      const float* lut, int32_t n_lut, float mult, float cmin, float cmax, hipStream_t st);
+}
+
 extern "C" {
 
 // ---- LUT, literal scan ----------------------------------------------------------------------------
@@ -16,10 +21,12 @@ int mctq_lut_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32
   if (step_round != 0 && step_round != MCTQ_DT_F16 && step_round != MCTQ_DT_BF16) return fail_arg("bad step_round");
   hipStream_t st = (hipStream_t)stream;
   const LutCommon::Param p = LutCommon::make(thr_div, thr_mul, mult);
-  if (dtype != MCTQ_DT_F32) return fail_arg("the literal-scan LUT kernels take float32 input (widen first)");
-  {
-    typedef float TI;
-    typedef float TO;
+  if (dtype == MCTQ_DT_F64)        // float64 tensor, float32 divisor widened (weights quantizers, per_channel=False)
+    return mctq_lut_per_tensor_f64(static_cast<const double*>(x), y, n, (double)thr_div, thr_mul, lut, n_lut, mult,
+                                   clip_min, clip_max, stream);
+  return with_lut_types(dtype, [&](auto ti, auto to) {
+    typedef decltype(ti) TI;
+    typedef decltype(to) TO;
     switch (lut_class(n_lut)) {
       case 4: return launch_flat<TI, TO>(make_lut_op<4>(nullptr, 0.f, lut, n_lut, mult, clip_min, clip_max, step_round),
                                          p, x, y, n, 0, st);
@@ -30,7 +37,7 @@ int mctq_lut_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32
       default: return launch_flat<TI, TO>(make_lut_op<0>(nullptr, 0.f, lut, n_lut, mult, clip_min, clip_max, step_round),
                                           p, x, y, n, (size_t)((n_lut + 3) & ~3) * sizeof(float), st);
     }
-  }
+  });
 }
 
 int mctq_lut_per_channel(const void* x, float* y, int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
@@ -41,10 +48,11 @@ int mctq_lut_per_channel(const void* x, float* y, int64_t outer, int64_t channel
   if (n > 0 && (!x || !y || !thresholds)) return fail_arg("NULL pointer");
   if (int rc = check_lut_args(lut, n_lut, mult)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype != MCTQ_DT_F32) return fail_arg("the literal-scan LUT kernels take float32 input (widen first)");
-  {
-    typedef float TI;
-    typedef float TO;
+  if (dtype == MCTQ_DT_F64)
+    return lut64_per_channel(x, y, outer, channels, inner, thresholds, eps, lut, n_lut, mult, clip_min, clip_max, st);
+  return with_lut_types(dtype, [&](auto ti, auto to) {
+    typedef decltype(ti) TI;
+    typedef decltype(to) TO;
     switch (lut_class(n_lut)) {
       case 4: return launch_channels<TI, TO>(make_lut_op<4>(thresholds, eps, lut, n_lut, mult, clip_min, clip_max, 0),
                                              x, y, outer, channels, inner, 0, st);
@@ -55,7 +63,7 @@ int mctq_lut_per_channel(const void* x, float* y, int64_t outer, int64_t channel
       default: return launch_channels<TI, TO>(make_lut_op<0>(thresholds, eps, lut, n_lut, mult, clip_min, clip_max, 0),
                                               x, y, outer, channels, inner, (size_t)((n_lut + 3) & ~3) * sizeof(float), st);
     }
-  }
+  });
 }
 
 int mctq_lut_per_tensor_f32(const float* x, float* y, int64_t n, float thr_div, float thr_mul, const float* lut,

@@ -16,10 +16,12 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 SOURCES = [os.path.join(CSRC, f) for f in ("mctq_misc.hip", "mctq_affine.hip", "mctq_codes.hip", "mctq_lut_scan.hip",
-                                             "mctq_lut_table.hip", "mctq_grid.hip", "mctq_qlinear.hip", "mctq_codes4.hip", "mctq_codes_nhwc.hip")]
+                                             "mctq_lut_table.hip", "mctq_grid.hip", "mctq_qlinear.hip", "mctq_codes4.hip", "mctq_codes_nhwc.hip", "mctq_batched.hip", "mctq_f64.hip")]
 HEADERS = [os.path.join(REPO, "include", "mctq_hip.h"), os.path.join(CSRC, "mctq_kernels.hpp"),
            os.path.join(CSRC, "mctq_table_builder.h")]
 OUT = os.path.join(PKG, "lib", "libmctq_hip.so")
+BINDING_SRC = os.path.join(CSRC, "binding", "mctq_torch.cpp")
+BINDING_OUT = os.path.join(PKG, "lib", "_mctq_torch.so")
 
 # -ffp-contract=off / no fast-math: the kernels must reproduce IEEE float32 results bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -65,6 +67,45 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+def binding_needs_build() -> bool:
+    if not os.path.exists(BINDING_OUT):
+        return True
+    t = os.path.getmtime(BINDING_OUT)
+    return any(os.path.getmtime(p) > t for p in (BINDING_SRC, HEADERS[0], OUT, os.path.abspath(__file__)))
+
+
+def build_binding(force: bool = False, verbose: bool = True) -> str:
+    """Compile the CPython binding of the hot entry points (host-only C++: g++, no device code).
+
+    It links libtorch (tensor type, caching allocator, current stream) and libmctq_hip.so; both are found at run
+    time through rpaths ($ORIGIN for the kernels' library, torch's own lib directory)."""
+    if not force and not binding_needs_build():
+        return BINDING_OUT
+    import sysconfig
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found; cannot build the compiled binding")
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    tmp = BINDING_OUT + ".tmp"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
+           "-I", os.path.join(REPO, "include"), "-I", os.path.join(tdir, "include"),
+           "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
+           "-I", sysconfig.get_paths()["include"], BINDING_SRC, "-o", tmp,
+           "-L", os.path.join(tdir, "lib"), "-L", os.path.dirname(OUT),
+           "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python", "-lmctq_hip",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, BINDING_OUT)
+    return BINDING_OUT
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(OUT)
+    build_binding(force="--force" in sys.argv)
+    print(BINDING_OUT)

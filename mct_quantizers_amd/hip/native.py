@@ -14,18 +14,29 @@ import ctypes
 import os
 import threading
 
-ABI_VERSION = 3
-DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+ABI_VERSION = 4
+DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
 CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
 LIB_NAME = "libmctq_hip.so"
 LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
 MCTQ_E_ARG = -10001
 
-_lock = threading.Lock()
+_lock = threading.RLock()
 _lib = None
+TRACE = os.environ.get("MCTQ_ROCTX", "0") not in ("", "0")     # one roctx range per launch (see the end of the file)
 
 _c_f32p = ctypes.c_void_p     # device pointers travel as integers
 _c_i32p = ctypes.c_void_p
+
+
+class FqItem(ctypes.Structure):
+    """mctq_fq_item of include/mctq_hip.h (one tensor of a batched launch)."""
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("outer", ctypes.c_int64), ("channels", ctypes.c_int64), ("inner", ctypes.c_int64),
+                ("scales", ctypes.c_void_p), ("zero_points", ctypes.c_void_p),
+                ("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
 
 # name -> (restype, argtypes); must list every symbol of include/mctq_hip.h
 SIGNATURES = {
@@ -48,6 +59,12 @@ SIGNATURES = {
     "mctq_fq_per_channel": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_int32, _c_f32p, _c_i32p, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_void_p]),
+    "mctq_fq_per_tensor_tqp": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int32, _c_f32p, _c_i32p,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "mctq_fq_batched": (ctypes.c_int, [ctypes.POINTER(FqItem), ctypes.c_int32, ctypes.c_void_p]),
+    "mctq_lut_per_tensor_f64": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_float,
+                                               _c_f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_float, ctypes.c_void_p]),
     "mctq_fq_codes_per_tensor": (ctypes.c_int, [_c_f32p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_void_p]),
@@ -139,6 +156,60 @@ def load():
     return _lib
 
 
+# ------------------------------------------------------------------------------------------
+# compiled binding of the hot entry points (csrc/binding/mctq_torch.cpp -> lib/_mctq_torch.so)
+# ------------------------------------------------------------------------------------------
+FAST_NAME = "_mctq_torch"
+_fast = None
+_fast_tried = False
+
+
+def fast_path() -> str:
+    return os.path.join(LIB_DIR, FAST_NAME + ".so")
+
+
+def fast():
+    """The compiled CPython binding over the same C ABI, or None.
+
+    MCTQ_BINDING = "auto" (default): use it when it loads, otherwise the ctypes binding (both end in the same
+    extern "C" entry points of libmctq_hip.so -- neither is a fallback away from the HIP kernels);
+    "compiled": raise if it cannot be loaded; "ctypes": never use it.  With MCTQ_ROCTX=1 the ctypes binding is
+    used so that every launch gets its roctx range."""
+    global _fast, _fast_tried
+    if _fast_tried:
+        return _fast
+    with _lock:
+        if _fast_tried:
+            return _fast
+        mode = os.environ.get("MCTQ_BINDING", "auto")
+        if mode == "ctypes" or TRACE:
+            _fast_tried = True
+            return None
+        try:
+            load()                                   # libmctq_hip.so first: the binding links against it
+            import importlib.util
+            import torch  # noqa: F401  (the module links libtorch_python; torch must be imported first)
+            path = fast_path()
+            spec = importlib.util.spec_from_file_location(FAST_NAME, path)
+            if spec is None or not os.path.exists(path):
+                raise ImportError(f"{path} not found")
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != ABI_VERSION:
+                raise ImportError(f"{path} was built against ABI {mod.abi_version()}, expected {ABI_VERSION}")
+            _fast = mod
+        except Exception as e:  # noqa: BLE001
+            if mode == "compiled":
+                raise NativeLibraryError(f"compiled binding unavailable: {e}") from e
+            import warnings
+            warnings.warn(f"mct_quantizers_amd: compiled binding not loaded ({e}); using the ctypes binding of "
+                          f"libmctq_hip.so (same kernels, ~2 us more host time per call). "
+                          f"Build it with `python -m mct_quantizers_amd.hip.build`.")
+            _fast = None
+        _fast_tried = True
+    return _fast
+
+
 def is_available() -> bool:
     try:
         load()
@@ -177,7 +248,6 @@ def build_lut_table(lut_values, mult: float, clip_min: float, clip_max: float):
 # ------------------------------------------------------------------------------------------
 # optional roctx ranges (MCTQ_ROCTX=1): one named range per launch, visible in rocprofv3 --marker-trace
 # ------------------------------------------------------------------------------------------
-TRACE = os.environ.get("MCTQ_ROCTX", "0") not in ("", "0")
 _roctx = None
 
 

@@ -8,10 +8,15 @@ Each function stands where the reference calls the tensor runtime:
 * ``lut_per_tensor`` / ``lut_per_channel`` ~ ``lut_quantizer`` (pytorch/quantizer_utils.py:95-139)
 
 Routing:
-  * GPU (HIP) float32 tensor  -> the gfx950 kernels through the C ABI, on torch's current stream.
-    No fallback: a missing library raises.
+  * GPU (HIP) float32 / float16 / bfloat16 / float64 tensor -> the gfx950 kernels through the C ABI, on torch's
+    current stream.  No fallback: a missing library raises.  Two interchangeable bindings of the SAME extern "C"
+    entry points: the compiled one (csrc/binding/mctq_torch.cpp: checks, allocation, stream lookup and launch in
+    one CPython call -- small activations are launch-bound) and ctypes (hip/native.py).
   * CPU tensor                -> the very ATen ops the reference runs on a CPU tensor
     (BASELINE config 1, "torch-cpu plumbing"); not a substitute for the GPU path.
+  * torch.jit tracing (TorchScript / ONNX export without enable_custom_impl) -> the ATen operators / torch op
+    chain the reference itself records there (a raw kernel launch is invisible to the tracer: the graph would
+    contain an uninitialised aten::empty_like).
   * fx Proxy / FakeTensor     -> ``torch.ops.mctq_amd.*`` so tracing records one call_function node.
 """
 from __future__ import annotations
@@ -114,15 +119,40 @@ def _maybe_on_device(x):
     return _NOOP if idx == _current_device() else _on_device(idx)
 
 
-_DTYPES = {torch.float32: native.DT_F32, torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}
+_DTYPES = {torch.float32: native.DT_F32, torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16,
+           torch.float64: native.DT_F64}
 
 
 def _dtype_code(x: torch.Tensor, what: str) -> int:
     code = _DTYPES.get(x.dtype)
     if code is None:
-        raise NotImplementedError(f"{what}: the gfx950 kernels take float32, float16 or bfloat16 tensors, "
+        raise NotImplementedError(f"{what}: the gfx950 kernels take float32, float16, bfloat16 or float64 tensors, "
                                   f"got {x.dtype}")
     return code
+
+
+def _param_on(x: torch.Tensor, t: torch.Tensor, name: str, dtype) -> torch.Tensor:
+    """A parameter vector as the kernels need it: right dtype, contiguous, ON x's DEVICE (the kernel would otherwise
+    dereference another GPU's pointer; ATen raises a device-mismatch error here as well)."""
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.device != x.device:
+        raise RuntimeError(f"Expected all tensors to be on the same device, but {name} is on {t.device} and the "
+                           f"input on {x.device}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# compiled binding (None: ctypes only).  Resolved at the first GPU call.
+_FAST = None
+_FAST_READY = False
+
+
+def _fast_mod():
+    global _FAST, _FAST_READY
+    if not _FAST_READY:
+        _FAST = native.fast() if torch.cuda.is_available() else None
+        _FAST_READY = True
+    return _FAST
 
 
 # ------------------------------------------------------------------------------------------
@@ -165,17 +195,13 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int,
         _dtype_code(x, "fq_per_channel")
     if not 0 <= axis < x.dim() or scales.numel() != x.shape[axis]:
         _check_axis(x, scales.numel(), axis)
-    if scales.dtype != torch.float32 or zero_points.dtype != torch.int32:
-        raise RuntimeError("scales must be float32 and zero_points int32")
+    scales = _param_on(x, scales, "scales", torch.float32)
+    zero_points = _param_on(x, zero_points, "zero_points", torch.int32)
     lib = native.load()
     if not x.is_contiguous():
         x = _dense_input(x)
     y = torch.empty_like(x)
     outer, c, inner = _channel_view(x, axis)
-    if not scales.is_contiguous():
-        scales = scales.contiguous()
-    if not zero_points.is_contiguous():
-        zero_points = zero_points.contiguous()
     idx = x.get_device()
     with (_NOOP if idx == _current_device() else _on_device(idx)):
         rc = _launch(lib.mctq_fq_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, scales.data_ptr(),
@@ -185,24 +211,98 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int,
     return y
 
 
+def _hip_fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
+    """Tensor-qparams overload: ``scale`` float32[1] and ``zero_point`` int32[1] stay on the device (no .item())."""
+    dt = _dtype_code(x, "fq_per_tensor_tqp")
+    if scale.numel() != 1 or zero_point.numel() != 1:
+        raise RuntimeError("fq_per_tensor_tqp: scale and zero_point must have exactly one element")
+    scale = _param_on(x, scale, "scale", torch.float32)
+    zero_point = _param_on(x, zero_point, "zero_point", torch.int32)
+    lib = native.load()
+    if not x.is_contiguous():
+        x = _dense_input(x)
+    y = torch.empty_like(x)
+    with _maybe_on_device(x):
+        rc = _launch(lib.mctq_fq_per_tensor_tqp, x.data_ptr(), y.data_ptr(), x.numel(), dt, scale.data_ptr(),
+                     zero_point.data_ptr(), qmin, qmax, _stream(x))
+    if rc:
+        native.check(rc, "mctq_fq_per_tensor_tqp")
+    return y
+
+
+def _hip_fq_batched(items):
+    """ctypes route of fq_batched (see below): items = [(x, scales, zero_points | None, axis | None, qmin, qmax)]."""
+    lib = native.load()
+    n = len(items)
+    arr = (native.FqItem * n)()
+    outs, keep = [], []
+    dev = None
+    for k, (x, scales, zps, axis, qmin, qmax) in enumerate(items):
+        dt = _dtype_code(x, "fq_batched")
+        if dev is None:
+            dev = x.device
+        elif x.device != dev:
+            raise RuntimeError("fq_batched: all tensors of one call must be on the same device")
+        if not x.is_contiguous():
+            x = _dense_input(x)
+        scales = _param_on(x, scales, "scales", torch.float32)
+        if zps is not None:
+            zps = _param_on(x, zps, "zero_points", torch.int32)
+        if axis is None:
+            outer, c, inner = (1, 1, x.numel()) if x.numel() else (0, 1, 0)
+            if scales.numel() != 1:
+                raise RuntimeError("fq_batched: a per-tensor item takes 1-element scales / zero_points")
+        else:
+            _check_axis(x, scales.numel(), axis)
+            outer, c, inner = _channel_view(x, axis)
+        y = torch.empty_like(x)
+        it = arr[k]
+        it.x, it.y = x.data_ptr(), y.data_ptr()
+        it.outer, it.channels, it.inner = outer, c, inner
+        it.scales = scales.data_ptr()
+        it.zero_points = zps.data_ptr() if zps is not None else None
+        it.quant_min, it.quant_max, it.dtype, it.reserved = qmin, qmax, dt, 0
+        outs.append(y)
+        keep.append((x, scales, zps))
+    if n:
+        with _maybe_on_device(outs[0]):
+            rc = _launch(lib.mctq_fq_batched, arr, n, _stream(outs[0]))
+        if rc:
+            native.check(rc, "mctq_fq_batched")
+    return outs
+
+
 def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
-                        step_round: int = 0):
-    """LUT quantizer, one threshold.  Output is float32 whatever x's type (the reference's chain promotes)."""
+                        step_round: int = 0, thr_div64: float = None):
+    """LUT quantizer, one threshold.  Output is float32 whatever x's type (the reference's chain promotes).
+    ``thr_div64``: for float64 tensors whose divisor is a Python float (the activation quantizer) the divisor
+    stays a double."""
     dt = _dtype_code(x, "lut_per_tensor")
+    if dt != native.DT_F64 and table is not None and native.TRACE is False:
+        f = _FAST if _FAST_READY else _fast_mod()
+        if f is not None:
+            y = f.lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, cmin, cmax)
+            if y is not NotImplemented:
+                return y
     lib = native.load()
     x = _dense_input(x)
     y = torch.empty_like(x, dtype=torch.float32)
+    lut = _param_on(x, lut, "lut_values", torch.float32)
     with _maybe_on_device(x):
-        if table is not None:
+        if dt == native.DT_F64:
+            if thr_div64 is not None:
+                rc = _launch(lib.mctq_lut_per_tensor_f64, x.data_ptr(), y.data_ptr(), x.numel(), thr_div64, thr_mul,
+                             lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
+            else:
+                rc = _launch(lib.mctq_lut_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, 0, thr_div, thr_mul,
+                             lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
+        elif table is not None:
+            table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
                                           table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
         else:
-            lut = lut.contiguous()
-            if dt != native.DT_F32:                       # literal-scan fallback is float32-only: widen (exact)
-                if step_round:
-                    raise NotImplementedError("half-precision activation LUT needs a decision table "
-                                              "(integer codebook, lut_values_bitwidth <= 10)")
-                x, dt = x.float(), native.DT_F32
+            # literal first-minimum scan (non-integer codebooks, wide bit widths): every storage type, incl. the
+            # per-step half-precision roundings of a half activation (step_round)
             rc = _launch(lib.mctq_lut_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
                                          lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
@@ -214,19 +314,24 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
                          table=None):
     dt = _dtype_code(x, "lut_per_channel")
     _check_axis(x, thresholds.numel(), axis)
+    if dt != native.DT_F64 and table is not None and native.TRACE is False:
+        f = _FAST if _FAST_READY else _fast_mod()
+        if f is not None:
+            y = f.lutt_per_channel(x, thresholds, eps, table, axis, mult, cmin, cmax)
+            if y is not NotImplemented:
+                return y
     lib = native.load()
     x = _dense_input(x)
     y = torch.empty_like(x, dtype=torch.float32)
     outer, c, inner = _channel_view(x, axis)
-    thresholds = thresholds.contiguous()
+    thresholds = _param_on(x, thresholds, "thresholds", torch.float32)
+    lut = _param_on(x, lut, "lut_values", torch.float32)
     with _maybe_on_device(x):
-        if table is not None:
+        if table is not None and dt != native.DT_F64:
+            table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                            eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
         else:
-            lut = lut.contiguous()
-            if dt != native.DT_F32:
-                x, dt = x.float(), native.DT_F32
             rc = _launch(lib.mctq_lut_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                           eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
@@ -329,6 +434,8 @@ def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float =
             return pack4(flat).reshape(_packed_shape(x))
         return q.to(tdt)
     dt = _dtype_code(x, "fq_codes")
+    if dt == native.DT_F64:
+        raise NotImplementedError("fq_codes: integer codes are produced from float32 / float16 / bfloat16 tensors")
     lib = native.load()
     if not x.is_contiguous():
         x = _dense_input(x)
@@ -344,6 +451,8 @@ def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float =
                                               _raw_stream(idx))
         else:
             _check_axis(x, scales.numel(), axis)
+            scales = _param_on(x, scales, "scales", torch.float32)
+            zero_points = _param_on(x, zero_points, "zero_points", torch.int32)
             outer, c, inner = _channel_view(x, axis)
             rc = _launch(lib.mctq_fq_codes_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, code,
                                                scales.data_ptr(), zero_points.data_ptr(), qmin, qmax, _raw_stream(idx))
@@ -362,6 +471,8 @@ def fq_codes_nhwc(x, qmin: int, qmax: int, scale: float, zero_point: int):
     if x.is_cuda and x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last):
         tdt, code = _code_dtype(qmin, qmax)
         dt = _dtype_code(x, "fq_codes_nhwc")
+        if dt == native.DT_F64:
+            raise NotImplementedError("fq_codes_nhwc: float32 / float16 / bfloat16 tensors only")
         lib = native.load()
         y = torch.empty((b, h, w, c), dtype=tdt, device=x.device)
         with _maybe_on_device(x):
@@ -410,7 +521,8 @@ def _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round: 
     # step_round == 0: the threshold is a float32 TENSOR in the reference (weights), so a half-precision
     # input is promoted to float32 by the first division; otherwise (activation, Python-float threshold)
     # the chain stays in the input's type until the float32 codebook enters.
-    if step_round == 0 and x.dtype != torch.float32:
+    # (a float64 tensor stays float64 either way: the double quotient, clip and distances of ATen's promotion.)
+    if step_round == 0 and x.dtype in (torch.float16, torch.bfloat16):
         x = x.float()
     return _cpu_lut(x, lut, thr_div, thr_mul, mult, cmin, cmax)
 
@@ -438,20 +550,52 @@ def _cpu_grid(x, lo, hi, step, shifted: bool):
 
 _lib_def = torch.library.Library(_LIBNAME, "DEF")
 _lib_def.define("fq_per_tensor(Tensor x, float scale, int zero_point, int quant_min, int quant_max) -> Tensor")
+_lib_def.define("fq_per_tensor_tqp(Tensor x, Tensor scale, Tensor zero_point, int quant_min, int quant_max) -> Tensor")
 _lib_def.define("fq_per_channel(Tensor x, Tensor scales, Tensor zero_points, int axis, int quant_min, "
                 "int quant_max) -> Tensor")
 _lib_def.define("lut_per_tensor(Tensor x, Tensor lut, float thr_div, float thr_mul, float mult, float clip_min, "
-                "float clip_max) -> Tensor")
+                "float clip_max, int step_round=0) -> Tensor")
 _lib_def.define("lut_per_channel(Tensor x, Tensor lut, Tensor thresholds, float eps, int axis, float mult, "
                 "float clip_min, float clip_max) -> Tensor")
 
+# decision tables for codebooks that reach the ops without their quantizer (fx graphs): built once per codebook
+_op_tables = {}
+
+
+def _op_table(lut, mult, cmin, cmax):
+    key = (lut.data_ptr(), lut._version, lut.numel(), str(lut.device), mult, cmin, cmax)
+    if key not in _op_tables:
+        if len(_op_tables) > 256:
+            _op_tables.clear()
+        _op_tables[key] = make_lut_table(lut.detach().cpu().numpy(), mult, cmin, cmax, lut.device)
+    return _op_tables[key]
+
+
+def _op_hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round=0):
+    return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax,
+                               None if x.dtype == torch.float64 else _op_table(lut, mult, cmin, cmax), step_round)
+
+
+def _op_hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax):
+    return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax,
+                                None if x.dtype == torch.float64 else _op_table(lut, mult, cmin, cmax))
+
+
+def _cpu_fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax):
+    return torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)
+
+
 for _name, _gpu, _cpu in (("fq_per_tensor", _hip_fq_per_tensor, _cpu_fq_per_tensor),
+                          ("fq_per_tensor_tqp", _hip_fq_per_tensor_tqp, _cpu_fq_per_tensor_tqp),
                           ("fq_per_channel", _hip_fq_per_channel, _cpu_fq_per_channel),
-                          ("lut_per_tensor", _hip_lut_per_tensor, _cpu_lut_per_tensor),
-                          ("lut_per_channel", _hip_lut_per_channel, _cpu_lut_per_channel)):
+                          ("lut_per_tensor", _op_hip_lut_per_tensor, _cpu_lut_per_tensor),
+                          ("lut_per_channel", _op_hip_lut_per_channel, _cpu_lut_per_channel)):
     _lib_def.impl(_name, _gpu, "CUDA")
     _lib_def.impl(_name, _cpu, "CPU")
+for _name in ("fq_per_tensor", "fq_per_tensor_tqp", "fq_per_channel"):
     _lib_def.impl(_name, (lambda x, *a: torch.empty_like(x)), "Meta")
+for _name in ("lut_per_tensor", "lut_per_channel"):          # the LUT chain's result is float32 for every input type
+    _lib_def.impl(_name, (lambda x, *a: torch.empty_like(x, dtype=torch.float32)), "Meta")
 
 
 def _is_real(x) -> bool:
@@ -465,8 +609,20 @@ def _cpu_route_allowed():
         raise RuntimeError("MCTQ_REQUIRE_HIP is set: refusing to quantize a CPU tensor outside the HIP kernels")
 
 
+def _tracing() -> bool:
+    """torch.jit.trace / torch.onnx.export in progress: emit what the reference emits (ATen nodes), never a raw launch."""
+    return torch._C._get_tracing_state() is not None
+
+
 def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
+    f = _FAST if _FAST_READY else _fast_mod()
+    if f is not None:
+        y = f.fq_per_tensor(x, scale, zero_point, qmin, qmax)
+        if y is not NotImplemented:
+            return y
     if _is_real(x):
+        if _tracing():
+            return torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)
         if x.is_cuda:
             return _hip_fq_per_tensor(x, scale, zero_point, qmin, qmax)
         if x.device.type == "cpu":
@@ -475,8 +631,34 @@ def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
     return torch.ops.mctq_amd.fq_per_tensor(x, scale, zero_point, qmin, qmax)
 
 
-def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero_zps: bool = False):
+def fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
+    """``torch.fake_quantize_per_tensor_affine(x, scale_tensor, zero_point_tensor, qmin, qmax)``: the parameters are
+    1-element tensors (float32 / int32) that the kernel reads on the device."""
+    f = _FAST if _FAST_READY else _fast_mod()
+    if f is not None:
+        y = f.fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
+        if y is not NotImplemented:
+            return y
     if _is_real(x):
+        if _tracing():
+            return torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)
+        if x.is_cuda:
+            return _hip_fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
+        if x.device.type == "cpu":
+            _cpu_route_allowed()
+            return _cpu_fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
+    return torch.ops.mctq_amd.fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
+
+
+def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero_zps: bool = False):
+    f = _FAST if _FAST_READY else _fast_mod()
+    if f is not None:
+        y = f.fq_per_channel(x, scales, None if zero_zps else zero_points, axis, qmin, qmax)
+        if y is not NotImplemented:
+            return y
+    if _is_real(x):
+        if _tracing():
+            return torch.fake_quantize_per_channel_affine(x, scales, zero_points, axis, qmin, qmax)
         if x.is_cuda:
             return _hip_fq_per_channel(x, scales, zero_points, axis, qmin, qmax, zero_zps)
         if x.device.type == "cpu":
@@ -485,19 +667,51 @@ def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero
     return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
 
 
+def fq_batched(items):
+    """Affine fake-quantization of a LIST of tensors in one launch (per group of 32 tensors of one storage type).
+
+    ``items``: sequence of ``(x, scales, zero_points | None, axis | None, quant_min, quant_max)``; ``axis`` None =
+    per tensor with 1-element device ``scales`` / ``zero_points``.  All tensors dense GPU tensors on one device.
+    Returns the list of outputs, each bit-identical to the corresponding single call.  Replaces the per-layer
+    quantizer calls of PytorchQuantizationWrapper.forward (pytorch/quantize_wrapper.py:228-240) when a whole
+    model's weights are re-quantized together (see pytorch/batching.py)."""
+    items = list(items)
+    f = _FAST if _FAST_READY else _fast_mod()
+    if f is not None:
+        ys = f.fq_batched(items)
+        if ys is not NotImplemented:
+            return ys
+    if all(_is_real(it[0]) and it[0].is_cuda for it in items) and not _tracing():
+        return _hip_fq_batched(items)
+    out = []
+    for x, scales, zps, axis, qmin, qmax in items:            # CPU tensors, traced graphs ...: one by one
+        if zps is None:
+            zps = torch.zeros(scales.numel(), dtype=torch.int32, device=scales.device)
+        if axis is None:
+            out.append(fq_per_tensor_tqp(x, scales, zps, qmin, qmax))
+        else:
+            out.append(fq_per_channel(x, scales, zps, axis, qmin, qmax))
+    return out
+
+
 def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
-                   step_round: int = 0):
+                   step_round: int = 0, thr_div64: float = None):
     if _is_real(x):
+        if _tracing():                                        # the reference's own op chain is what gets recorded
+            return _cpu_lut_per_tensor(x, lut, thr_div if thr_div64 is None else thr_div64, thr_mul, mult, cmin, cmax,
+                                       step_round)
         if x.is_cuda:
-            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round)
+            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round, thr_div64)
         if x.device.type == "cpu":
             _cpu_route_allowed()
             return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round)
-    return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax)
+    return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, max(step_round, 0))
 
 
 def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float, table=None):
     if _is_real(x):
+        if _tracing():
+            return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
         if x.is_cuda:
             return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, table)
         if x.device.type == "cpu":

@@ -69,7 +69,9 @@ def lut_quantizer(tensor_data: torch.Tensor, lut_values: torch.Tensor, signed: b
     """
     mult, cmin, cmax = lut_domain(lut_values_bitwidth, signed)
     if per_channel:
-        return ops.lut_per_channel(tensor_data, lut_values, threshold.reshape(-1), float(eps), channel_axis,
+        rank = tensor_data.dim() if hasattr(tensor_data, "dim") else input_rank
+        axis = channel_axis % rank if rank else channel_axis      # the reference's reshape accepts negative axes
+        return ops.lut_per_channel(tensor_data, lut_values, threshold.reshape(-1), float(eps), axis,
                                    mult, cmin, cmax)
     if isinstance(threshold, torch.Tensor):
         thr = np.float32(threshold.reshape(-1)[0].item())
@@ -77,6 +79,9 @@ def lut_quantizer(tensor_data: torch.Tensor, lut_values: torch.Tensor, signed: b
     else:
         thr = np.float32(threshold)
         thr_div = float(np.float32(float(threshold) + eps))   # double add, then float32
+        if getattr(tensor_data, "dtype", None) is torch.float64:
+            return ops.lut_per_tensor(tensor_data, lut_values, thr_div, float(thr), mult, cmin, cmax, None, 0,
+                                      float(threshold) + eps)
     return ops.lut_per_tensor(tensor_data, lut_values, thr_div, float(thr), mult, cmin, cmax)
 
 

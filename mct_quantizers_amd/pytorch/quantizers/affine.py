@@ -25,6 +25,41 @@ from mct_quantizers_amd.hip import ops
 from mct_quantizers_amd.pytorch.quantizer_utils import fix_range_to_include_zero, get_working_device, to_torch_tensor
 
 
+_is_compiling = torch.compiler.is_compiling
+
+
+class _PerTensorPlanMixin:
+    """Pre-packed launch arguments of the per-tensor activation quantizers (compiled binding's AffinePlan).
+
+    The plan is a function of a few public attributes (``_plan_attrs``); assigning to any of them drops it, so
+    ``q.scale = 0.5`` takes effect on the next call exactly as in the reference, which reads the attributes on
+    every call (activation_uniform_inferable_quantizer.py:124-128)."""
+    _plan_attrs = frozenset()
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name in self._plan_attrs:
+            self.__dict__["_plan"] = None
+
+    def _plan_args(self):
+        raise NotImplementedError
+
+    def _make_plan(self):
+        """AffinePlan, or False when the compiled binding is not in use (CPU-only process, MCTQ_BINDING=ctypes)."""
+        fast = ops._fast_mod()
+        plan = False
+        if fast is not None:
+            try:
+                plan = fast.AffinePlan(*self._plan_args())
+            except (AttributeError, TypeError, ValueError):   # half-constructed object / non-numeric attribute
+                plan = False
+        self.__dict__["_plan"] = plan
+        return plan
+
+
+_MAX_BITS = 24      # the clamp bounds travel as float32: exact for |q| < 2^24
+
+
 class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
     """Base of all PyTorch inference-time quantizers: behaviour flags and the output-reuse cache."""
 
@@ -66,8 +101,16 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
 
     # -- pickles: objects saved by the reference (or by an older build) carry only the public attributes;
     #    the private launch state (host copies of scalars, decision tables) is rebuilt on load.
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in ("_plan", "_plan_key"):            # handles of the compiled binding: rebuilt on first use
+            state.pop(k, None)
+        return state
+
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.pop("_plan", None)
+        self.__dict__.pop("_plan_key", None)
         self._rebuild_launch_state()
 
     def _rebuild_launch_state(self):
@@ -112,6 +155,8 @@ class BaseSymmetricInferableQuantizer(BasePyTorchInferableQuantizer):
     def __init__(self, num_bits: int, threshold: List[float], signed: bool):
         super().__init__()
         assert isinstance(threshold, list), f'Threshold is expected to be a list, but is of type {type(threshold)}'
+        if not 1 <= num_bits <= _MAX_BITS:
+            raise ValueError(f"num_bits must be in [1, {_MAX_BITS}] (the clamp domain is held in float32), got {num_bits}")
         self.signed = signed
         self.threshold_np = np.asarray(threshold)
         self.num_bits = num_bits
@@ -132,6 +177,8 @@ class BaseUniformInferableQuantizer(BasePyTorchInferableQuantizer):
         assert isinstance(max_range, list), f'max_range is expected to be a list, but is of type {type(max_range)}'
         for _min, _max in zip(min_range, max_range):
             assert _min < _max, f"Max range must be greater than min value but min is {_min} and max is {_max}"
+        if not 1 <= num_bits <= _MAX_BITS:
+            raise ValueError(f"num_bits must be in [1, {_MAX_BITS}] (the clamp domain is held in float32), got {num_bits}")
 
         # Parameter math runs in float32 on the HOST and only the results move to the working device:
         # ATen's GPU kernels evaluate tensor / python_scalar as tensor * (1 / scalar), which can differ
@@ -151,48 +198,89 @@ class _WeightsAffineMixin:
     """Per-tensor / per-channel dispatch shared by the symmetric and the uniform weights quantizers.
 
     Expects: self.scales (float32 device tensor [C]), self.zero_points (int32 device tensor [C]),
-    self.per_channel, self.channel_axis, the clamp domain, and host copies _scale0 / _zp0 of the
-    first entry (so the per-tensor launch needs no device->host read).
+    self.per_channel, self.channel_axis, the clamp domain.  The launch state derived from them -- flattened
+    parameter views, host copies of the single scale / zero point for the per-tensor launch (no device->host read
+    per call), the "all zero points are zero" flag and the compiled binding's pre-packed AffinePlan -- is keyed on
+    the identity AND the version counter of the two public tensors, so replacing them or editing them in place
+    (``q.zero_points[0] = 5``) takes effect on the next call, as it does in the reference, which reads the
+    attributes on every call (weights_symmetric_inferable_quantizer.py:139-151).
     """
 
     def _rebuild_launch_state(self):
         self.scales = self._to_working_device(self.scales)
         self.zero_points = self._to_working_device(self.zero_points)
-        if "_scale0" not in self.__dict__ or "_zp0" not in self.__dict__:
-            self._scale0 = float(self.scales.reshape(-1)[0].item())
-            self._zp0 = int(self.zero_points.reshape(-1)[0].item())
-        self._flat_params()
+        self.__dict__.pop("_plan_key", None)
 
-    def _flat_params(self):
-        # flattened, contiguous views made once (the reference flattens on every call); refreshed if the
-        # public attributes are replaced
-        self._flat_src = (self.scales, self.zero_points)
-        self._scales_flat = self.scales.flatten().contiguous()
-        self._zps_flat = self.zero_points.flatten().contiguous()
-        self._zps_all_zero = not bool(torch.any(self._zps_flat != 0).item())     # symmetric: skip the table
+    def _launch_key(self):
+        s, z = self.scales, self.zero_points
+        return (s, z, s._version, z._version, self.per_channel, self.channel_axis, self.min_quantized_domain,
+                self.max_quantized_domain)
+
+    def _refresh(self):
+        """(Re)derive the launch state from the public attributes.  Reads two scalars back from the device: happens
+        at the first call and after a change of the public attributes only."""
+        d = self.__dict__
+        s, z = self.scales, self.zero_points
+        d["_scales_flat"] = s.flatten().contiguous()
+        d["_zps_flat"] = z.flatten().contiguous()
+        d["_zps_all_zero"] = not bool(torch.any(d["_zps_flat"] != 0).item())     # symmetric: skip the table
+        d["_scale0"] = float(d["_scales_flat"][0].item()) if d["_scales_flat"].numel() else 1.0
+        d["_zp0"] = int(d["_zps_flat"][0].item()) if d["_zps_flat"].numel() else 0
+        plan = None
+        fast = ops._fast_mod() if d["_scales_flat"].is_cuda else None
+        if fast is not None:
+            if self.per_channel:
+                plan = fast.AffinePlan(d["_scales_flat"], None if d["_zps_all_zero"] else d["_zps_flat"],
+                                       int(self.channel_axis), self.min_quantized_domain, self.max_quantized_domain)
+            else:
+                plan = fast.AffinePlan(d["_scale0"], d["_zp0"], self.min_quantized_domain, self.max_quantized_domain)
+        d["_plan"] = plan
+        d["_plan_key"] = self._launch_key()
+
+    def _current(self):
+        key = self.__dict__.get("_plan_key")
+        if key is None:
+            self._refresh()
+            return
+        s, z = self.scales, self.zero_points
+        if (key[0] is not s or key[1] is not z or key[2] != s._version or key[3] != z._version
+                or key[4] != self.per_channel or key[5] != self.channel_axis
+                or key[6] != self.min_quantized_domain or key[7] != self.max_quantized_domain):
+            self._refresh()
 
     def quantize_to_codes(self, inputs: torch.Tensor, packed4: bool = False):
         """Extension (not in the reference): the integer clamp indices as int8/uint8 plus the parameters that
         dequantize them, ``(codes - zero_points) * scales`` == ``self(inputs)`` bit for bit.
         ``packed4`` (num_bits <= 4): two codes per byte (``ops.unpack4`` undoes it).
         Returns (codes, scales float32 [C or 1], zero_points int32 [C or 1])."""
-        src = self.__dict__.get("_flat_src")
-        if src is None or src[0] is not self.scales or src[1] is not self.zero_points:
-            self._flat_params()
+        self._current()
         axis = self.channel_axis if self.per_channel else None
         codes = ops.fq_codes(inputs, self._scales_flat, self._zps_flat, axis, self.min_quantized_domain,
                              self.max_quantized_domain, self._scale0, self._zp0, packed4)
         return codes, self._scales_flat, self._zps_flat
 
+    def batch_item(self, inputs: torch.Tensor):
+        """(x, scales, zero_points | None, axis | None, qmin, qmax) for ``ops.fq_batched``: this quantizer's call on
+        ``inputs`` as one entry of a batched launch."""
+        self._current()
+        d = self.__dict__
+        return (inputs, d["_scales_flat"], None if d["_zps_all_zero"] else d["_zps_flat"],
+                int(self.channel_axis) if self.per_channel else None, self.min_quantized_domain,
+                self.max_quantized_domain)
+
     def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
         inputs.requires_grad = False            # the reference flips this on the caller's tensor
+        self._current()
+        d = self.__dict__
+        plan = d["_plan"]
+        if plan is not None and not _is_compiling():
+            y = plan(inputs)                    # compiled binding: checks + allocation + launch in one call
+            if y is not NotImplemented:
+                return y
         if self.per_channel:
-            src = self.__dict__.get("_flat_src")
-            if src is None or src[0] is not self.scales or src[1] is not self.zero_points:
-                self._flat_params()
-            return ops.fq_per_channel(inputs, self._scales_flat, self._zps_flat, self.channel_axis,
-                                      self.min_quantized_domain, self.max_quantized_domain, self._zps_all_zero)
-        return ops.fq_per_tensor(inputs, self._scale0, self._zp0,
+            return ops.fq_per_channel(inputs, d["_scales_flat"], d["_zps_flat"], self.channel_axis,
+                                      self.min_quantized_domain, self.max_quantized_domain, d["_zps_all_zero"])
+        return ops.fq_per_tensor(inputs, d["_scale0"], d["_zp0"],
                                  self.min_quantized_domain, self.max_quantized_domain)
 
 
@@ -214,9 +302,6 @@ class WeightsSymmetricInferableQuantizer(_WeightsAffineMixin, BaseSymmetricInfer
         self.per_channel = per_channel
         self.channel_axis = channel_axis
 
-        scales_f32 = self.scales.astype(np.float32)
-        self._scale0 = float(scales_f32.reshape(-1)[0])
-        self._zp0 = 0
         dev = get_working_device()
         self.scales = to_torch_tensor(self.scales).to(dev)
         self.zero_points = torch.zeros(len(threshold), dtype=torch.int32).to(dev)
@@ -276,8 +361,6 @@ class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferable
         # step of the grid, and the (positive) zero point: TRUNCATION of min/scale, negated (host float32)
         scales = (hi - lo) / (2 ** num_bits - 1)
         zero_points = -(lo / scales).int()
-        self._scale0 = float(scales.reshape(-1)[0].item())
-        self._zp0 = int(zero_points.reshape(-1)[0].item())
         dev = get_working_device()
         self.scales = scales.to(dev)
         self.zero_points = zero_points.to(dev)
@@ -296,8 +379,15 @@ class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferable
 @mark_quantizer(quantization_target=QuantizationTarget.Activation,
                 quantization_method=[QuantizationMethod.SYMMETRIC],
                 identifier=QuantizerID.INFERABLE)
-class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
+class ActivationSymmetricInferableQuantizer(_PerTensorPlanMixin, BaseSymmetricInferableQuantizer):
     """Symmetric activation quantizer (per tensor only), signed or unsigned."""
+    _plan_attrs = frozenset(("scales", "zero_points", "min_quantized_domain", "max_quantized_domain"))
+
+    def _plan_args(self):
+        return float(self.scales), int(self.zero_points), self.min_quantized_domain, self.max_quantized_domain
+
+    def _rebuild_launch_state(self):
+        self.__dict__["_plan"] = None
 
     def __init__(self, num_bits: int, threshold: List[float], signed: bool):
         super().__init__(num_bits=num_bits, threshold=threshold, signed=signed)
@@ -309,6 +399,7 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
                                        f'should be of length 1 but is {len(threshold)}')
         self.scales = float(self.scales[0])      # stays a Python double; narrowed to float32 at launch
         self.zero_points = 0
+        self._make_plan()
 
     def quantize_to_codes(self, inputs: torch.Tensor, packed4: bool = False):
         """Extension: (codes int8/uint8, scale float, zero_point int) with (codes - zero_point) * float32(scale)
@@ -320,14 +411,21 @@ class ActivationSymmetricInferableQuantizer(BaseSymmetricInferableQuantizer):
     _export_function = "ActivationSymF"
 
     def __call__(self, inputs: torch.Tensor):
+        # Small activations are launch-bound: a plain eager GPU tensor goes from here to the kernel launch in ONE
+        # call of the compiled binding (it returns NotImplemented for everything else: CPU tensors, fx proxies,
+        # tensor subclasses, an active torch.jit trace -- those take the general route below).  The launch records
+        # nothing for autograd, so the reference's no_grad context is only needed on the general route.
+        plan = self.__dict__.get("_plan")
+        if plan is None:
+            plan = self._make_plan()
+        if plan is not False and not _is_compiling():     # torch.compile must see torch.ops.mctq_amd.* instead
+            y = plan(inputs)
+            if y is not NotImplemented:
+                return y
         if self._use_custom_impl and torch.jit.is_tracing():
             from mct_quantizers_amd.pytorch.quantizers import onnx_export
             return getattr(onnx_export, self._export_function).apply(inputs, self.threshold_np, self.signed,
                                                                      self.num_bits)
-        if type(inputs) is torch.Tensor and inputs.is_cuda:
-            # the HIP launch records nothing for autograd: no need for the no_grad context on this path
-            return ops._hip_fq_per_tensor(inputs, self.scales, self.zero_points,
-                                          self.min_quantized_domain, self.max_quantized_domain)
         with torch.no_grad():
             return ops.fq_per_tensor(inputs, self.scales, self.zero_points,
                                      self.min_quantized_domain, self.max_quantized_domain)
@@ -348,8 +446,15 @@ class ActivationPOTInferableQuantizer(ActivationSymmetricInferableQuantizer):
 @mark_quantizer(quantization_target=QuantizationTarget.Activation,
                 quantization_method=[QuantizationMethod.UNIFORM],
                 identifier=QuantizerID.INFERABLE)
-class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
+class ActivationUniformInferableQuantizer(_PerTensorPlanMixin, BaseUniformInferableQuantizer):
     """Unsigned uniform activation quantizer (per tensor only)."""
+    _plan_attrs = frozenset(("scale", "zero_point", "min_quantized_domain", "max_quantized_domain"))
+
+    def _plan_args(self):
+        return float(self.scale), int(self.zero_point), self.min_quantized_domain, self.max_quantized_domain
+
+    def _rebuild_launch_state(self):
+        self.__dict__["_plan"] = None
 
     def __init__(self, num_bits: int, min_range: List[float], max_range: List[float]):
         super().__init__(num_bits=num_bits, min_range=min_range, max_range=max_range)
@@ -361,6 +466,7 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
         self.max_range = self._max_range_host[0].item()
         self.scale = float((self.max_range - self.min_range) / ((2 ** num_bits) - 1))
         self.zero_point = int(-np.round(self.min_range / self.scale))   # round half even, in double
+        self._make_plan()
 
     def quantize_to_codes(self, inputs: torch.Tensor, packed4: bool = False):
         """Extension: (codes uint8, scale float, zero_point int) with (codes - zero_point) * float32(scale)
@@ -370,12 +476,16 @@ class ActivationUniformInferableQuantizer(BaseUniformInferableQuantizer):
         return codes, self.scale, self.zero_point
 
     def __call__(self, inputs: torch.Tensor):
+        plan = self.__dict__.get("_plan")           # see ActivationSymmetricInferableQuantizer.__call__
+        if plan is None:
+            plan = self._make_plan()
+        if plan is not False and not _is_compiling():
+            y = plan(inputs)
+            if y is not NotImplemented:
+                return y
         if self._use_custom_impl and torch.jit.is_tracing():
             from mct_quantizers_amd.pytorch.quantizers.onnx_export import ActivationUniformF
             return ActivationUniformF.apply(inputs, self.min_range, self.max_range, self.num_bits)
-        if type(inputs) is torch.Tensor and inputs.is_cuda:
-            return ops._hip_fq_per_tensor(inputs, self.scale, self.zero_point,
-                                          self.min_quantized_domain, self.max_quantized_domain)
         with torch.no_grad():
             return ops.fq_per_tensor(inputs, self.scale, self.zero_point,
                                      self.min_quantized_domain, self.max_quantized_domain)

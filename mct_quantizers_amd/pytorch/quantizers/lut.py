@@ -174,5 +174,7 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
             return ops.lut_per_tensor(inputs, self.lut_values, float(self.threshold) + self.eps, self._thr_mul0,
                                       mult, cmin, cmax, None, step or -1)
         thr_div = self._thr_div_by_dtype.get(dt, self._thr_div_by_dtype[torch.float32])
+        # a float64 tensor divided by the Python-float threshold + eps: the divisor stays a double
+        div64 = float(self.threshold) + self.eps if dt is torch.float64 else None
         return ops.lut_per_tensor(inputs, self.lut_values, thr_div, self._thr_mul0, mult, cmin, cmax,
-                                  self._lut_table_torch, step)
+                                  self._lut_table_torch, step, div64)

@@ -13,6 +13,29 @@ from . import mctq_oracle as O
 def oracle_call(cls_name: str, kwargs: dict, x: np.ndarray, return_index: bool = False, in_dtype: str = "float32"):
     """``x`` holds the tensor's values widened to float32; ``in_dtype`` is the tensor's storage type.
     Affine quantizers return values of that type (widened), LUT quantizers return float32."""
+    if in_dtype == "float64":
+        assert not return_index
+        kw = dict(kwargs)
+        nb = kw["num_bits"]
+        axis = kw.get("channel_axis") if kw.get("per_channel") else None
+        if cls_name in ("WeightsSymmetricInferableQuantizer", "WeightsPOTInferableQuantizer"):
+            s, z, qmin, qmax = O.weights_symmetric_params(nb, kw["threshold"])
+        elif cls_name == "WeightsUniformInferableQuantizer":
+            s, z, qmin, qmax, _, _ = O.weights_uniform_params(nb, kw["min_range"], kw["max_range"])
+        elif cls_name in ("ActivationSymmetricInferableQuantizer", "ActivationPOTInferableQuantizer"):
+            s, z, qmin, qmax = O.activation_symmetric_params(nb, kw["threshold"], kw["signed"])
+        elif cls_name == "ActivationUniformInferableQuantizer":
+            s, z, qmin, qmax, _, _ = O.activation_uniform_params(nb, kw["min_range"], kw["max_range"])
+        elif cls_name in ("WeightsLUTSymmetricInferableQuantizer", "WeightsLUTPOTInferableQuantizer"):
+            return O.lut_quantize_f64(x, kw["lut_values"], np.asarray(kw["threshold"], dtype=np.float64).astype(np.float32),
+                                      True, kw.get("lut_values_bitwidth", O.LUT_VALUES_BITWIDTH), kw.get("eps", O.EPS),
+                                      per_channel=kw["per_channel"], channel_axis=kw.get("channel_axis"))
+        elif cls_name == "ActivationLutPOTInferableQuantizer":
+            return O.lut_quantize_f64(x, kw["lut_values"], float(kw["threshold"][0]), kw["signed"],
+                                      kw.get("lut_values_bitwidth", O.LUT_VALUES_BITWIDTH), kw.get("eps", O.EPS))
+        else:
+            raise KeyError(cls_name)
+        return O.fake_quant_affine_f64(x, s, z, qmin, qmax, axis=axis)
     if in_dtype != "float32":
         assert not return_index
         if "LUT" in cls_name or "Lut" in cls_name:

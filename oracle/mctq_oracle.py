@@ -274,6 +274,77 @@ def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
 
 
 # --------------------------------------------------------------------------
+# float64 tensors (the reference passes them to ATen unchanged; same call sites)
+# --------------------------------------------------------------------------
+
+def fake_quant_affine_f64(x: np.ndarray, scale, zero_point, qmin: int, qmax: int, axis=None):
+    """ATen's CPU fake-quant kernels instantiated for double (same call sites as fake_quant_affine).
+
+    The clamp index uses a DOUBLE product with the float32 reciprocal widened:
+        q = clamp(nearbyint(x * (double)(1.0f / s)) + z, qmin, qmax)
+    The dequantized value differs by overload (pinned by tests/golden/cases_f64.*):
+        per tensor (float or 1-element-tensor qparams):  y = (double)((float)(q - z) * s)
+        per channel:                                     y = (double)(q - z) * (double)s
+    """
+    x = np.asarray(x, dtype=np.float64)
+    s = np.asarray(scale, dtype=F32).reshape(-1)
+    z = np.asarray(zero_point).reshape(-1).astype(np.float64)
+    if axis is not None:
+        shape = _channel_shape(x.ndim, axis)
+        s = s.reshape(shape)
+        z = z.reshape(shape)
+    else:
+        assert s.size == 1 and z.size == 1
+        s = s[0]
+        z = z[0]
+    with np.errstate(all="ignore"):
+        inv = (F32(1.0) / s).astype(np.float64)
+        q = np.rint(x * inv) + z
+        q = np.minimum(np.maximum(q, float(qmin)), float(qmax))
+        if axis is not None:
+            return (q - z) * s.astype(np.float64)
+        return ((q - z).astype(F32) * s).astype(np.float64)
+
+
+def lut_quantize_f64(x: np.ndarray, lut_values, threshold, signed: bool,
+                     lut_values_bitwidth: int = LUT_VALUES_BITWIDTH, eps: float = EPS,
+                     per_channel: bool = False, channel_axis=None, chunk_elems: int = 1 << 19):
+    """pytorch/quantizer_utils.py:95-139 on a float64 tensor: type promotion makes the quotient, the clip and the
+    distances double, while (lut[idx] / 2^k) * threshold stays float32 -- the OUTPUT is float32.
+    ``threshold`` float32 vector (weights: divisor = fl32(thr + fl32(eps)) widened) or Python float (activation:
+    divisor = thr + eps, a double)."""
+    x = np.asarray(x, dtype=np.float64)
+    lut = np.asarray(lut_values, dtype=F32).reshape(-1)
+    k = lut_values_bitwidth - int(signed)
+    m = float(2 ** k)
+    if signed:
+        cmin, cmax = float(-2 ** (lut_values_bitwidth - 1)), float(2 ** (lut_values_bitwidth - 1) - 1)
+    else:
+        cmin, cmax = 0.0, float(2 ** lut_values_bitwidth - 1)
+    if isinstance(threshold, (float, int)):
+        thr_mul = np.broadcast_to(F32(threshold), x.shape)
+        thr_div = np.broadcast_to(np.float64(float(threshold) + eps), x.shape)
+    else:
+        thr = np.asarray(threshold, dtype=F32).reshape(-1)
+        if per_channel:
+            thr = thr.reshape(_channel_shape(x.ndim, channel_axis))
+        thr_mul = np.broadcast_to(thr, x.shape)
+        thr_div = np.broadcast_to((thr + F32(eps)).astype(F32).astype(np.float64), x.shape)
+    xf, tm, td = x.reshape(-1), thr_mul.reshape(-1), thr_div.reshape(-1)
+    y = np.empty(xf.shape, dtype=F32)
+    lut64 = lut.astype(np.float64)
+    with np.errstate(all="ignore"):
+        for lo in range(0, xf.size, chunk_elems):
+            hi = min(lo + chunk_elems, xf.size)
+            t = (xf[lo:hi] / td[lo:hi]) * m
+            t = np.where(np.isnan(t), t, np.minimum(np.maximum(t, cmin), cmax))
+            d = np.abs(t[:, None] - lut64[None, :])
+            idx = np.where(np.isnan(t), 0, np.argmin(d, axis=1))
+            y[lo:hi] = (lut[idx] / F32(m)) * tm[lo:hi]
+    return y.reshape(x.shape)
+
+
+# --------------------------------------------------------------------------
 # export-time arithmetic (`_use_custom_impl and torch.jit.is_tracing()`)
 # --------------------------------------------------------------------------
 

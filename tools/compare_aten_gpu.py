@@ -7,15 +7,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mct_quantizers_amd as mq
 from mct_quantizers_amd import workloads
 
-def timeit(f, xs, steps):
-    n = len(xs); outs = [None] * n
-    for i in range(min(steps, 10)): outs[i % n] = f(xs[i % n])
+def timeit(f, xs, steps, outs):
+    """One timed pass of `steps` calls over the buffer ring.  `outs` is the caller's output ring: it is already
+    full (allocator warm: every call below recycles a cached block -- in round 1 the first candidate paid the
+    hipMallocs of a cold caching allocator and the second did not, which is where the 0.51x at N=1 came from)."""
+    n = len(xs)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
     e0.record()
     for i in range(steps): outs[i % n] = f(xs[i % n])
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / steps, outs[(steps - 1) % n]
+    e1.record()
+    host = (time.perf_counter() - t0) * 1e6 / steps
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / steps, host, outs[(steps - 1) % n]
 
 def lut_chain_gpu(x, lut, thr, eps, axis, B=8):
     shape = [1] * x.dim(); shape[axis] = -1
@@ -28,12 +33,19 @@ rows = []
 def case(name, q, x, aten, steps=100, bytes_per_elem=8):
     ring = max(2, -(-(512 << 20) // (x.numel() * bytes_per_elem)) + 1)
     xs = [x] + [x.clone() for _ in range(ring - 1)]
-    t_ours, y = timeit(q, xs, steps)
-    t_aten, ya = timeit(aten, xs, max(3, steps // 4))
-    same = bool(torch.equal(y, ya))
+    # warm the caching allocator for BOTH candidates: fill one output ring each, keep both alive while timing
+    outs_q = [q(t) for t in xs]
+    slow = "LUT" in name
+    outs_a = [aten(t) for t in (xs[:3] if slow else xs)] + ([None] * (ring - 3) if slow else [])
+    t_o, t_a, h_o, h_a = [], [], [], []
+    for _ in range(3):                                   # alternate the candidates, report the median round
+        a, h, y = timeit(q, xs, steps, outs_q); t_o.append(a); h_o.append(h)
+        a, h, ya = timeit(aten, xs, max(3, steps // 4) if slow else steps, outs_a); t_a.append(a); h_a.append(h)
+    t_ours, t_aten = sorted(t_o)[1], sorted(t_a)[1]
+    same = bool(torch.equal(q(xs[0]), aten(xs[0])))
     gbs = x.numel() * bytes_per_elem / t_ours / 1e3
     rows.append((name, tuple(x.shape), t_ours, t_aten, t_aten / t_ours, gbs, same))
-    print(f"{name:44s} {str(tuple(x.shape)):22s} ours {t_ours:9.2f} us  ATen/ref-chain {t_aten:10.2f} us  x{t_aten/t_ours:6.2f}  {gbs:6.0f} GB/s  equal={same}", flush=True)
+    print(f"{name:44s} {str(tuple(x.shape)):22s} ours {t_ours:8.2f} us (host {sorted(h_o)[1]:6.2f})  ATen/ref-chain {t_aten:9.2f} us (host {sorted(h_a)[1]:6.2f})  x{t_aten/t_ours:6.2f}  {gbs:6.0f} GB/s  equal={same}", flush=True)
 
 Q = mq.pytorch_quantizers
 for cfg, shape in (("cfg2", None), ("cfg5", None)):
@@ -43,7 +55,7 @@ for cfg, shape in (("cfg2", None), ("cfg5", None)):
 for n in (1, 8, 64, 256):
     x_np = workloads.make_input("cfg3", batch=n); wl = workloads.make_workload("cfg3", x_np)
     q = getattr(Q, wl.quantizer)(**wl.kwargs); x = torch.from_numpy(x_np).cuda()
-    case(f"cfg3 ActivationUniform N={n}", q, x, lambda t, q=q: torch.fake_quantize_per_tensor_affine(t, q.scale, q.zero_point, 0, 255), steps=300)
+    case(f"cfg3 ActivationUniform N={n}", q, x, lambda t, q=q: torch.fake_quantize_per_tensor_affine(t, q.scale, q.zero_point, 0, 255), steps=500)
 # LUT config 4: the reference chain materialises N x 16 temporaries (2 x 2.9 GB here)
 x_np = workloads.make_input("cfg4"); wl = workloads.make_workload("cfg4", x_np)
 q = getattr(Q, wl.quantizer)(**wl.kwargs); x = torch.from_numpy(x_np).cuda()

@@ -489,6 +489,219 @@ def gen_half_cases():
     print(len(hc), "half-precision cases")
 
 
+def gen_f64_cases():
+    """float64 inputs (the reference hands them to ATen unchanged).  ATen's double path is its own arithmetic
+    (double product x * (double)(1.0f / s), per-channel results as double products, per-tensor ones as widened
+    float32 products; LUT distances in double with a float32 result) -- these fixtures pin it.
+    Inputs are float64 values that are NOT float32-representable, plus exact double ties."""
+    dc, da = [], {}
+
+    def widen(x32, scales, axis):
+        x = x32.astype(np.float64)
+        noise = rng.standard_normal(x.shape) * 2.0 ** -30
+        x = x * (1.0 + noise)
+        # exact ties of the DOUBLE product: x = (k + 0.5) / (double)(1.0f / s), nudged one double ulp either way
+        s = np.asarray(scales, dtype=np.float32).reshape(-1)
+        inv = (np.float32(1.0) / s).astype(np.float64)
+        if axis is None:
+            invb = np.broadcast_to(inv[0], x.shape)
+        else:
+            bs = [1] * x.ndim
+            bs[axis] = -1
+            invb = np.broadcast_to(inv.reshape(bs), x.shape)
+        flat, invf = x.reshape(-1), invb.reshape(-1)
+        pos = rng.choice(flat.size, size=max(3, flat.size // 6), replace=False)
+        k = rng.integers(-140, 141, size=pos.size).astype(np.float64) + 0.5
+        t = k / invf[pos]
+        kind = rng.integers(0, 3, size=pos.size)
+        t = np.where(kind == 1, np.nextafter(t, np.inf), t)
+        t = np.where(kind == 2, np.nextafter(t, -np.inf), t)
+        flat[pos] = t
+        return flat.reshape(x.shape)
+
+    def add(cls_name, kwargs, x64, memory_format=None):
+        xt = torch.from_numpy(np.ascontiguousarray(x64))
+        if memory_format == "channels_last":
+            xt = xt.contiguous(memory_format=torch.channels_last)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(refq, cls_name)(**kwargs)
+        y = q(xt.clone())
+        cid = f"d{len(dc):03d}"
+        da[cid + "_x"] = x64
+        da[cid + "_y"] = y.detach().numpy().copy()
+        dc.append(dict(id=cid, cls=cls_name, kwargs=kwargs, shape=list(x64.shape), in_dtype="float64",
+                       out_dtype=str(y.dtype).replace("torch.", ""), memory_format=memory_format))
+
+    for bits in (3, 8):
+        qmin, qmax = -2 ** (bits - 1), 2 ** (bits - 1) - 1
+        thr = [float(rng.uniform(0.3, 5.0))]
+        sc = np.asarray(thr) / 2 ** (bits - 1)
+        add("WeightsSymmetricInferableQuantizer", dict(num_bits=bits, threshold=thr, per_channel=False),
+            widen(adversarial((7, 33, 5), sc, None, qmin, qmax), sc, None))
+        for shape, axis, mf in (((6, 37), 0, None), ((5, 7, 11), 1, None), ((1, 10, 10, 3), 3, None), ((3, 2048), 0, None),
+                                ((2, 6, 5, 4), 1, "channels_last")):
+            C = shape[axis]
+            thr = [float(v) for v in rng.uniform(0.05, 7.0, size=C)]
+            sc = np.asarray(thr) / 2 ** (bits - 1)
+            add("WeightsSymmetricInferableQuantizer",
+                dict(num_bits=bits, threshold=thr, per_channel=True, channel_axis=axis),
+                widen(adversarial(shape, sc, axis, qmin, qmax), sc, axis), mf)
+        thr = [float(2.0 ** e) for e in rng.integers(-3, 3, size=6)]
+        sc = np.asarray(thr) / 2 ** (bits - 1)
+        add("WeightsPOTInferableQuantizer", dict(num_bits=bits, threshold=thr, per_channel=True, channel_axis=0),
+            widen(adversarial((6, 48), sc, 0, qmin, qmax), sc, 0))
+        lo = [float(v) for v in rng.uniform(-4.0, 0.5, size=5)]
+        hi = [float(a + d) for a, d in zip(lo, rng.uniform(0.2, 6.0, size=5))]
+        kw = dict(num_bits=bits, min_range=lo, max_range=hi, per_channel=True, channel_axis=1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = refq.WeightsUniformInferableQuantizer(**kw)
+        sc = q.scales.numpy().reshape(-1)
+        add("WeightsUniformInferableQuantizer", kw,
+            widen(adversarial((3, 5, 24), sc, 1, 0, 2 ** bits - 1, q.zero_points.numpy().reshape(-1)), sc, 1))
+        kw = dict(num_bits=bits, min_range=[-1.3], max_range=[2.2], per_channel=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = refq.WeightsUniformInferableQuantizer(**kw)
+        sc = q.scales.numpy().reshape(-1)
+        add("WeightsUniformInferableQuantizer", kw,
+            widen(adversarial((11, 23), sc, None, 0, 2 ** bits - 1, q.zero_points.numpy().reshape(-1)), sc, None))
+        for signed in (True, False):
+            thr = [float(rng.uniform(0.5, 6.0))]
+            sc = np.asarray(thr) / (2 ** (bits - 1) if signed else 2 ** bits)
+            dom = (qmin, qmax) if signed else (0, 2 ** bits - 1)
+            add("ActivationSymmetricInferableQuantizer", dict(num_bits=bits, threshold=thr, signed=signed),
+                widen(adversarial((2, 3, 17, 9), sc, None, *dom), sc, None))
+        sc = np.asarray([4.0]) / 2 ** (bits - 1)
+        add("ActivationPOTInferableQuantizer", dict(num_bits=bits, threshold=[4.0], signed=True),
+            widen(adversarial((3, 50), sc, None, qmin, qmax), sc, None))
+        kw = dict(num_bits=bits, min_range=[-2.5], max_range=[3.1])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = refq.ActivationUniformInferableQuantizer(**kw)
+        add("ActivationUniformInferableQuantizer", kw,
+            widen(adversarial((2, 3, 12, 12), [q.scale], None, 0, 2 ** bits - 1, [q.zero_point]), [q.scale], None))
+
+    def lut64(shape, thr, axis):
+        x = lut_input(shape, thr, axis).astype(np.float64)
+        return x * (1.0 + rng.standard_normal(x.shape) * 2.0 ** -30)
+
+    lut16 = list(workloads.CFG4_LUT)
+    lut8 = [22.0, -53.0, 62.0, 0.0, -66.0, -21.0, 44.0, -40.0]
+    for lut, bits in ((lut16, 4), (lut8, 3)):
+        thr = [float(rng.uniform(0.5, 3.0))]
+        add("WeightsLUTSymmetricInferableQuantizer",
+            dict(num_bits=bits, lut_values=lut, threshold=thr, per_channel=False), lut64((9, 31), thr, None))
+        for shape, axis in (((6, 37), 0), ((5, 7, 12), 1), ((3, 2048), 0)):
+            C = shape[axis]
+            thr = [float(v) for v in rng.uniform(0.05, 4.0, size=C)]
+            add("WeightsLUTSymmetricInferableQuantizer",
+                dict(num_bits=bits, lut_values=lut, threshold=thr, per_channel=True, channel_axis=axis,
+                     input_rank=len(shape)), lut64(shape, thr, axis))
+        add("WeightsLUTPOTInferableQuantizer",
+            dict(num_bits=bits, lut_values=lut, threshold=[2.0, 0.5, 1.0, 4.0], per_channel=True, channel_axis=0, input_rank=2),
+            lut64((4, 300), [2.0, 0.5, 1.0, 4.0], 0))
+        add("ActivationLutPOTInferableQuantizer", dict(num_bits=bits, lut_values=lut, threshold=[2.0], signed=True),
+            lut64((2, 3, 8, 8), [2.0], None))
+        add("ActivationLutPOTInferableQuantizer", dict(num_bits=bits, lut_values=lut, threshold=[0.5], signed=True, eps=1e-3),
+            lut64((3, 700), [0.5], None))
+    add("ActivationLutPOTInferableQuantizer",
+        dict(num_bits=3, lut_values=[0.0, 13.0, 50.0, 90.0, 128.0, 200.0, 255.0, 256.0], threshold=[4.0], signed=False),
+        np.abs(lut64((3, 64), [4.0], None)) * 1.3)
+    np.savez_compressed(os.path.join(OUT, "cases_f64.npz"), **da)
+    with open(os.path.join(OUT, "cases_f64.json"), "w") as f:
+        json.dump(dict(meta=dict(generator="tools/gen_golden.py --f64-only", torch=torch.__version__,
+                                 reference="sony/mct_quantizers v%s" % ref.__version__), cases=dc), f, indent=1)
+    print(len(dc), "float64 cases")
+
+
+def gen_extra_sha():
+    """Digests of the reference outputs for the other batch sizes SURVEY §8(d) names for config 3 (N = 1, 64, 256);
+    merged into full_sha.json next to the N = 8 entry."""
+    path = os.path.join(OUT, "full_sha.json")
+    with open(path) as f:
+        doc = json.load(f)
+    torch.set_num_threads(os.cpu_count() or 1)
+    for n in (1, 64, 256):
+        x = workloads.make_input("cfg3", batch=n)
+        wl = workloads.make_workload("cfg3", x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(refq, wl.quantizer)(**wl.kwargs)
+        y = q(torch.from_numpy(x)).numpy()
+        doc["configs"][f"cfg3_n{n}"] = dict(shape=list(x.shape), quantizer=wl.quantizer, batch=n,
+                                            x_sha256=hashlib.sha256(x.tobytes()).hexdigest(),
+                                            y_sha256=hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest(),
+                                            y_sum_f64=float(np.sum(y, dtype=np.float64)))
+        print(f"cfg3 N={n}", doc["configs"][f"cfg3_n{n}"]["y_sha256"], flush=True)
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+
+
+def gen_traced_wrapper_pickle():
+    """An fx-traced REFERENCE wrapper whose weights quantizer is per-tensor: its graph holds
+    torch.fake_quantize_per_tensor_affine with TENSOR scale / zero point (graph values), the saved-model form of
+    weights_symmetric_inferable_quantizer.py:147-151; plus a per-channel one.  Data only (class paths + tensors +
+    fx's generated forward)."""
+    import torch.nn as nn
+    torch.manual_seed(11)
+
+    class Leafy(torch.fx.Tracer):
+        def is_leaf_module(self, m, qualname):
+            return isinstance(m, (nn.Linear, nn.Conv2d)) or super().is_leaf_module(m, qualname)
+
+    lin = nn.Linear(12, 5)
+    lin2 = nn.Linear(5, 4)
+    thr2 = [float(v) for v in lin2.weight.detach().abs().amax(dim=1)]
+    net = nn.Sequential()
+    net.add_module("l1", ref.PytorchQuantizationWrapper(
+        lin, {"weight": refq.WeightsSymmetricInferableQuantizer(8, [float(lin.weight.detach().abs().max())], False),
+              "bias": refq.WeightsUniformInferableQuantizer(8, [-0.6], [0.7], False)}))
+    net.add_module("a1", ref.PytorchActivationQuantizationHolder(refq.ActivationSymmetricInferableQuantizer(8, [2.0], True)))
+    net.add_module("l2", ref.PytorchQuantizationWrapper(
+        lin2, {"weight": refq.WeightsSymmetricInferableQuantizer(4, thr2, True, 0)}))
+    x = torch.randn(6, 12)
+    y = net(x)
+    graph = Leafy().trace(net)
+    traced = torch.fx.GraphModule(net, graph)
+    yt = traced(x)
+    assert torch.equal(y, yt)
+    kinds = [(n.op, str(n.target)) for n in traced.graph.nodes]
+    # what the quantizers inside produce on the reference, for bit-exact per-quantizer checks
+    w1 = net.l1.weights_quantizers["weight"](lin.weight.detach().clone())
+    b1 = net.l1.weights_quantizers["bias"](lin.bias.detach().clone())
+    w2 = net.l2.weights_quantizers["weight"](lin2.weight.detach().clone())
+    torch.save(traced, os.path.join(OUT, "ref_traced_wrapper.pth"))
+    np.savez_compressed(os.path.join(OUT, "ref_traced_wrapper_io.npz"), x=x.numpy(), y=y.detach().numpy(),
+                        w1=w1.detach().numpy(), b1=b1.detach().numpy(), w2=w2.detach().numpy())
+    with open(os.path.join(OUT, "ref_traced_wrapper_nodes.json"), "w") as f:
+        json.dump(kinds, f, indent=1)
+    print("traced reference wrapper:", [k for k in kinds if "fake_quantize" in k[1]])
+
+    # The reference's weights quantizers traced with the WEIGHT as a graph input: symbolic_trace records
+    # torch.fake_quantize_per_tensor_affine(w, <tensor scale>, <tensor zero point>, ...) -- the tensor-qparams
+    # overload, its qparams lifted to _tensor_constant* attributes -- and fake_quantize_per_channel_affine.
+    class WQ(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q1 = refq.WeightsSymmetricInferableQuantizer(8, [1.7], False)
+            self.q2 = refq.WeightsSymmetricInferableQuantizer(4, [1.0, 2.0, 0.7], True, 0)
+            self.q3 = refq.WeightsUniformInferableQuantizer(8, [-0.6], [0.7], False)
+
+        def forward(self, w, v):
+            return self.q1(w), self.q3(w), self.q2(v)
+
+    tq = torch.fx.symbolic_trace(WQ())
+    w = torch.randn(9, 33) * 1.2
+    v = torch.randn(3, 257)
+    o1, o3, o2 = tq(w, v)
+    torch.save(tq, os.path.join(OUT, "ref_traced_weight_quantizers.pth"))
+    np.savez_compressed(os.path.join(OUT, "ref_traced_weight_quantizers_io.npz"), w=w.numpy(), v=v.numpy(),
+                        o1=o1.numpy(), o3=o3.numpy(), o2=o2.numpy())
+    print("traced reference weights quantizers:", [str(n.target) for n in tq.graph.nodes if n.op == "call_function"])
+
+
 def gen_pickled_reference_models():
     """Pickles of REFERENCE objects (class paths + state only, no source) for the unpickle-compat tests:
     a small module tree built from the reference's wrapper/holders/quantizers, and an fx-traced holder."""
@@ -681,8 +894,17 @@ if __name__ == "__main__":
         gen_half_cases()
     elif "--export-only" in sys.argv:
         gen_export()
+    elif "--f64-only" in sys.argv:
+        gen_f64_cases()
+    elif "--extra-sha-only" in sys.argv:
+        gen_extra_sha()
+    elif "--traced-wrapper-only" in sys.argv:
+        gen_traced_wrapper_pickle()
     else:
         main()
         gen_half_cases()
         gen_pickled_reference_models()
         gen_export()
+        gen_f64_cases()
+        gen_extra_sha()
+        gen_traced_wrapper_pickle()

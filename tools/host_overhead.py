@@ -17,7 +17,14 @@ def bench(name, f, n=20000):
     print(f"{name:55s} host {1e6*(t1-t)/n:6.2f} us/call   incl. drain {1e6*(t2-t)/n:6.2f} us/call")
 bench("quantizer(x)  ActivationUniform (per-tensor)", lambda: q(x))
 bench("quantizer(x)  WeightsSymmetric per-channel axis1", lambda: qw(x))
-bench("ops._hip_fq_per_tensor", lambda: ops._hip_fq_per_tensor(x, q.scale, q.zero_point, 0, 255))
+fast = native.fast()
+if fast is not None:
+    plan = fast.AffinePlan(q.scale, q.zero_point, 0, 255)
+    bench("compiled binding: AffinePlan(x)", lambda: plan(x))
+    bench("compiled binding: fast.fq_per_tensor(x, ...)", lambda: fast.fq_per_tensor(x, q.scale, q.zero_point, 0, 255))
+holder = mq.PytorchActivationQuantizationHolder(q)
+bench("PytorchActivationQuantizationHolder(q)(x)", lambda: holder(x))
+bench("ops._hip_fq_per_tensor (ctypes binding)", lambda: ops._hip_fq_per_tensor(x, q.scale, q.zero_point, 0, 255))
 bench("raw ctypes mctq_fq_per_tensor (no alloc)", lambda: lib.mctq_fq_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), 0, q.scale, q.zero_point, 0, 255, st))
 bench("torch.empty_like", lambda: torch.empty_like(x))
 bench("ATen torch.fake_quantize_per_tensor_affine (GPU)", lambda: torch.fake_quantize_per_tensor_affine(x, q.scale, q.zero_point, 0, 255))
