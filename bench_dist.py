@@ -1,0 +1,137 @@
+"""Importable pieces of bench.py's multi-process leg (one process per GPU; RCCL = backend "nccl" on ROCm).
+
+They take the device and the backend as arguments so that the very code the driver runs on 2/4/8 GPUs is
+exercised by a world-size-2 ``gloo`` test on CPU (tests/test_bench_dist_gloo.py) and by
+``torchrun --nproc-per-node 1 bench.py --gpus 1 --gather`` on the single GPU of a gpurun box.
+No 8-GPU node is available to the build: the N > 1 numbers themselves come from the driver's SCALE run.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+
+def init_process_group(backend: str, device: torch.device, force_gloo: bool = False):
+    """Returns (dist module, control_plane).  ``backend`` "nccl" is probed with one all-reduce (RCCL creates its
+    communicators lazily: fail here, not mid-run) and replaced by gloo for the CONTROL plane (barrier,
+    max-over-ranks) if that probe fails -- the hot path itself has no collective."""
+    import torch.distributed as dist
+    control = backend
+    if backend == "nccl":
+        try:
+            if force_gloo:
+                raise RuntimeError("forced")
+            dist.init_process_group("nccl", device_id=device)
+            probe = torch.zeros(1, device=device)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] RCCL unavailable ({e!r:.200}); barrier / max-over-ranks go over gloo", file=sys.stderr, flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            dist.init_process_group("gloo")
+            control = "gloo"
+    else:
+        dist.init_process_group(backend)
+    return dist, control
+
+
+def sync(device: torch.device):
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_region(step: Callable[[int], None], steps: int, device: torch.device, dist=None) -> float:
+    """Wall time of exactly ``steps`` calls of ``step``, bracketed by barrier + device synchronize on both sides."""
+    if dist is not None:
+        dist.barrier()
+    sync(device)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync(device)
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(values, dist, control: str, device: torch.device):
+    """Element-wise MAX of a list of floats over all ranks (the slowest rank defines the job's time)."""
+    if dist is None:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if control == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: int = 8192, cols: int = 8192,
+                     reps: int = 60, gather_reps: int = 20) -> Dict:
+    """BASELINE config 5: WeightsPOT 4-bit per-channel on rows x cols, sharded by dim 0 across the ranks
+    (strong scaling: rank r quantizes rows [rows r / N, rows (r+1) / N)), then ONE all-gather (RCCL over xGMI on
+    GPUs).  Returns compute-only and compute + all-gather rates; every rank derives the same thresholds from the
+    same portable input, so no object collective is needed."""
+    from mct_quantizers_amd import workloads
+    from mct_quantizers_amd.sharded import ShardedWeightsQuantizer, row_block
+    start, stop = row_block(rows, world, rank)
+    x_full = workloads.make_input("cfg5", shape=(rows, cols))
+    kw = workloads.make_workload("cfg5", x_full).kwargs
+    x_local = torch.from_numpy(x_full[start:stop].copy()).to(device)
+    del x_full
+    sq = ShardedWeightsQuantizer("WeightsPOTInferableQuantizer", kw, full_rows=rows)
+    xs = [x_local, x_local.clone(), x_local.clone()]
+    y = None
+    for i in range(min(6, reps)):
+        y = sq(xs[i % 3])
+    t_comp = timed_region(lambda i: sq(xs[i % 3]), reps, device, dist) / reps
+    y = sq(xs[0])
+    full = None
+    for _ in range(min(3, gather_reps)):
+        full = sq.all_gather(y)
+    box = {}
+
+    def gather(i):
+        box["full"] = sq.all_gather(y)
+    t_gather = timed_region(gather, gather_reps, device, dist) / gather_reps
+    full = box.get("full", full)
+    recv = (rows - (stop - start)) * cols * 4
+    ok = full is not None and tuple(full.shape) == (rows, cols) and bool(torch.equal(full[start:stop], y))
+    return {
+        "workload": f"cfg5 WeightsPOT per-channel(axis0) 4b {rows}x{cols}, dim-0 shards",
+        "scaling": "strong", "rows_per_rank": stop - start,
+        "compute_ms": t_comp * 1e3, "compute_elems_per_s": rows * cols / t_comp,
+        "allgather_ms": t_gather * 1e3, "allgather_recv_bytes_per_rank": recv,
+        "allgather_recv_gbs_per_rank": recv / t_gather / 1e9 if t_gather > 0 else None,
+        "compute_plus_allgather_elems_per_s": rows * cols / (t_comp + t_gather),
+        "gathered_rows_match_local": ok,
+    }
+
+
+class Watchdog:
+    """A stuck collective must not cost the main result -- but it must not look like success either: prints the
+    line it was given and exits with status 4."""
+
+    def __init__(self, seconds: float, rank: int, line_fn: Callable[[], str]):
+        import threading
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self.rank, self.line_fn = rank, line_fn
+
+    def _fire(self):
+        if self.rank == 0:
+            print(self.line_fn(), flush=True)
+        print("[bench] watchdog: the multi-GPU extras did not finish; exiting with status 4", file=sys.stderr, flush=True)
+        os._exit(4)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._t.cancel()
+        return False

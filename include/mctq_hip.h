@@ -67,6 +67,11 @@ int mctq_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* mctq_last_error(void);
 
+/* Diagnostic: which kernel variant the calling thread's last successful elementwise launch used, e.g.
+ * "rows_kernel<AffineOp,in4B,out4B,U=4,NT=1>" ("" before the first launch).  Benchmarks use it to tie profiler
+ * counters (profiles/pmc_traffic.json) to the variant they were measured on.  Valid until the next call. */
+const char* mctq_last_launch(void);
+
 /* y[i] = (clamp(rint(x[i] * (1/scale)) + zero_point, quant_min, quant_max) - zero_point) * scale, i < n. */
 int mctq_fq_per_tensor_f32(const float* x, float* y, int64_t n,
                            float scale, int32_t zero_point, int32_t quant_min, int32_t quant_max,
@@ -123,7 +128,7 @@ int mctq_fq_per_tensor_tqp(const void* x, void* y, int64_t n, int32_t dtype,
  * host cost and ~2 us of ramp/drain on the GPU.  `items` is a HOST array (it is consumed before the call returns:
  * the descriptors travel in the kernel arguments, so the call is legal under hipGraph capture); every pointer
  * inside an item is a DEVICE pointer with the meaning it has in mctq_fq_per_channel.  Per-tensor quantization is
- * outer = channels = 1, inner = n with 1-element device scales / zero_points.  Tensors the batched kernel cannot
+ * outer = channels = 1, inner = n with 1-element device scales / zero_points and flags = MCTQ_FQ_ITEM_PER_TENSOR.  Tensors the batched kernel cannot
  * take (x or y not 16-byte aligned, >= 2^31 elements, float64) are launched one by one on the same stream.
  * All items are validated before anything is launched.
  */
@@ -135,8 +140,12 @@ typedef struct mctq_fq_item {
   const int32_t* zero_points;    /* device int32[channels], or NULL = all zero */
   int32_t quant_min, quant_max;
   int32_t dtype;                 /* MCTQ_DT_*: storage type of x and y */
-  int32_t reserved;              /* set to 0 */
+  int32_t flags;                 /* MCTQ_FQ_ITEM_PER_TENSOR or 0 */
 } mctq_fq_item;
+
+/* The item is a per-tensor quantization (torch.fake_quantize_per_tensor_affine with tensor qparams), not a
+ * per-channel one that happens to have one channel.  Only float64 tensors can tell the difference (see "float64"). */
+#define MCTQ_FQ_ITEM_PER_TENSOR 1
 
 int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream);
 

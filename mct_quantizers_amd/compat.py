@@ -12,6 +12,9 @@ API-compatible:
   ``torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)`` call_function node with
   constant arguments.  ``route_fx_graph()`` rewrites such nodes to
   ``torch.ops.mctq_amd.fq_per_tensor`` / ``fq_per_channel``, which dispatch per device at run time.
+  A traced per-tensor WEIGHTS quantizer records the tensor-qparams overload instead -- scale and zero point are
+  1-element tensors lifted to ``_tensor_constant*`` attributes (weights_symmetric_inferable_quantizer.py:147-151)
+  -- and becomes ``torch.ops.mctq_amd.fq_per_tensor_tqp``, whose kernel reads them on the device.
 
 ``load_reference_model(path)`` does both.
 """
@@ -103,7 +106,9 @@ def remove_reference_aliases() -> None:
 def route_fx_graph(gm: torch.fx.GraphModule) -> int:
     """Rewrite inlined ATen fake-quant nodes to the ``mctq_amd`` ops; returns the number of nodes rewritten.
 
-    Nodes whose scale is itself a graph value (tensor-qparams overload) are left as they are.
+    Python-number qparams -> ``fq_per_tensor``; qparams that are graph values (the tensor-qparams overload: get_attr
+    constants of a traced weights quantizer, or any other node) -> ``fq_per_tensor_tqp``; per-channel ->
+    ``fq_per_channel``.
     """
     names = ("input", "scale", "zero_point", "quant_min", "quant_max")
     names_pc = ("input", "scale", "zero_point", "axis", "quant_min", "quant_max")
@@ -114,6 +119,12 @@ def route_fx_graph(gm: torch.fx.GraphModule) -> int:
         if node.target is torch.fake_quantize_per_tensor_affine:
             args = list(node.args) + [node.kwargs[k] for k in names[len(node.args):]]
             if isinstance(args[1], torch.fx.Node) or isinstance(args[2], torch.fx.Node):
+                if not (isinstance(args[1], torch.fx.Node) and isinstance(args[2], torch.fx.Node)):
+                    continue                              # mixed tensor / number qparams: not an ATen overload
+                node.target = torch.ops.mctq_amd.fq_per_tensor_tqp
+                node.args = (args[0], args[1], args[2], int(args[3]), int(args[4]))
+                node.kwargs = {}
+                routed += 1
                 continue
             node.target = torch.ops.mctq_amd.fq_per_tensor
             node.args = (args[0], float(args[1]), int(args[2]), int(args[3]), int(args[4]))

@@ -297,6 +297,8 @@ PyObject* py_fq_batched(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     d.scales = sp->const_data_ptr<float>();
     d.zero_points = zp ? zp->const_data_ptr<int32_t>() : nullptr;
     d.quant_min = (int32_t)qmin; d.quant_max = (int32_t)qmax; d.dtype = dt;
+    d.flags = axis_o == Py_None ? MCTQ_FQ_ITEM_PER_TENSOR : 0;
+    if (dt == MCTQ_DT_F64 && axis_o == Py_None && !zp) { Py_DECREF(seq); return not_implemented(); }   // general route supplies zeros
   }
   Py_DECREF(seq);
   if (n > 0) {

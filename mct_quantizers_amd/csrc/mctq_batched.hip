@@ -143,6 +143,7 @@ static int launch_batch(const BatchArgs& a, uint32_t tiles, int64_t out_bytes, h
   constexpr int U = 4;
   MCTQ_WITH_MODE(nt_mode(out_bytes) == 0 ? 1 : nt_mode(out_bytes), false, {
     hipLaunchKernelGGL((batched_kernel<TI, TO, U, NT>), dim3(tiles), dim3(kThreads), 0, st, a);
+    note<AffineOp, TI, TO>("batched_kernel", U, NT);
   });
   return check_launch("batched launch");
 }
@@ -166,6 +167,8 @@ int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream) {
     if (d.outer * d.channels * d.inner > 0 && (!d.x || !d.y || !d.scales)) return fail_arg("NULL pointer");
     if (d.dtype != MCTQ_DT_F32 && d.dtype != MCTQ_DT_F16 && d.dtype != MCTQ_DT_BF16 && d.dtype != MCTQ_DT_F64)
       return fail_arg("unknown dtype");
+    if (d.dtype == MCTQ_DT_F64 && (d.flags & MCTQ_FQ_ITEM_PER_TENSOR) && !d.zero_points)
+      return fail_arg("a float64 per-tensor item needs a zero_points pointer");
   }
   for (int dt = MCTQ_DT_F32; dt <= MCTQ_DT_BF16; ++dt) {
     BatchArgs a;
@@ -212,8 +215,16 @@ int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream) {
   for (int32_t k = 0; k < n_items; ++k) {                   // float64 tensors: one launch each
     const mctq_fq_item& d = items[k];
     if (d.dtype != MCTQ_DT_F64 || d.outer * d.channels * d.inner == 0) continue;
-    if (int rc = mctq_fq_per_channel(d.x, d.y, d.outer, d.channels, d.inner, d.dtype, d.scales, d.zero_points,
-                                     d.quant_min, d.quant_max, stream)) return rc;
+    int rc;
+    if ((d.flags & MCTQ_FQ_ITEM_PER_TENSOR) && d.zero_points)
+      rc = mctq_fq_per_tensor_tqp(d.x, d.y, d.outer * d.channels * d.inner, d.dtype, d.scales, d.zero_points, d.quant_min,
+                                  d.quant_max, stream);
+    else if (d.flags & MCTQ_FQ_ITEM_PER_TENSOR)
+      return fail_arg("a float64 per-tensor item needs a zero_points pointer");
+    else
+      rc = mctq_fq_per_channel(d.x, d.y, d.outer, d.channels, d.inner, d.dtype, d.scales, d.zero_points, d.quant_min,
+                               d.quant_max, stream);
+    if (rc) return rc;
   }
   return 0;
 }

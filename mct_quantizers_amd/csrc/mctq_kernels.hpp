@@ -117,6 +117,7 @@ struct IO {
 struct NoBook {};
 
 struct AffineOp {
+  static constexpr const char* kName = "AffineOp";
   const float* __restrict__ scales;    // [C] (per-channel launches only)
   const int32_t* __restrict__ zps;     // [C], or NULL for all-zero zero points (symmetric quantizers)
   float lo, hi;                        // clamp domain as floats (exact: |q| < 2^24)
@@ -174,6 +175,7 @@ struct AffineOp {
 // Same clamp index, left as an integer code (stored as int8 / uint8): the integer domain of the affine
 // quantizers for consumers that dequantize themselves (1 B written per element instead of 4).
 struct AffineCodesOp : AffineOp {
+  static constexpr const char* kName = "AffineCodesOp";
   template <bool FAST = true>
   __device__ __forceinline__ float apply(float x, const Param& p, const Book&) const {
     const float q = __builtin_rintf(x * p.inv) + p.zf;
@@ -187,6 +189,7 @@ struct AffineCodesOp : AffineOp {
 // activation_symmetric...py:29-54, activation_uniform...py:32-65).  Runs once per export: plain streaming,
 // IEEE division per element.
 struct GridOp {
+  static constexpr const char* kName = "GridOp";
   const float* __restrict__ los;       // [C] lower clip bounds   (per-channel launches only)
   const float* __restrict__ his;       // [C] upper clip bounds
   const float* __restrict__ steps;     // [C] grid steps
@@ -326,6 +329,7 @@ struct LdsBook { const float* c; int n; };
 
 template <int LP>   // LP > 0: codebook broadcast into LP scalar registers; LP == 0: codebook in LDS
 struct LutOp : LutCommon {
+  static constexpr const char* kName = LP > 0 ? "LutOp<registers>" : "LutOp<lds>";
   const float* __restrict__ lut;       // [n_lut] device codebook, caller's order
   int n_lut;
   // Fallback path (non-integer codebooks, bit widths the decision table does not cover): built in one
@@ -401,6 +405,7 @@ struct LutOp : LutCommon {
 struct LutTableBook { const f32x2* tab; float nan_q; };
 
 struct LutTableOp : LutCommon {
+  static constexpr const char* kName = "LutTableOp";
   const float* __restrict__ table;     // device, (entries + 1) x 2 words
   int entries;
   float koff;                          // 0.5 - 2*clip_min
@@ -859,6 +864,14 @@ inline int nt_mode(int64_t out_bytes) {
   return (g_cached_store_max_bytes > 0 && out_bytes <= g_cached_store_max_bytes) ? 2 : 1;
 }
 extern int g_unroll;
+// what the calling thread launched last (mctq_last_launch(): lets a benchmark tie its counters to a kernel variant)
+struct LaunchNote { const char* shape; const char* op; int unroll, nt, in_bytes, out_bytes; };
+extern thread_local LaunchNote g_note;
+template <class Op, class TI, class TO>
+inline void note(const char* shape, int unroll, int nt) {
+  g_note.shape = shape; g_note.op = Op::kName; g_note.unroll = unroll; g_note.nt = nt;
+  g_note.in_bytes = (int)sizeof(TI); g_note.out_bytes = (int)sizeof(TO);
+}
 extern int g_heavy_unroll;   // 0 = automatic
 extern int g_heavy_persistent;
 int fail_arg(const char* msg);
@@ -868,6 +881,30 @@ template <class TI, class TO>
 static bool vec_aligned(const void* x, const void* y) {
   typedef IO<TI, TO> io;
   return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % (io::N * sizeof(TO))) == 0;
+}
+
+// Launch through hipModuleLaunchKernel with the kernel's hipFunction_t resolved once per (kernel, device): skips
+// the host-stub -> device-function lookup every hipLaunchKernel call makes (2.4 vs 2.8 us per launch here,
+// profiles/r02/launch_probe.log).  Used for the launch-bound per-tensor path; semantics (stream order, capture,
+// error reporting through hipGetLastError) are those of hipLaunchKernelGGL.
+// The kernel is a template ARGUMENT (not a function argument): one cache per kernel instantiation -- kernels that
+// differ only in U / NT have the same function TYPE.
+template <auto kernel, class... Args>
+inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args) {
+  constexpr int kMaxDevices = 32;
+  static hipFunction_t fns[kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) {
+    hipFunction_t fn = fns[dev];
+    if (!fn && hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(kernel)) == hipSuccess) fns[dev] = fn;
+    if (fn) {
+      void* params[] = {(void*)&args...};
+      (void)hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)shmem, st, params, nullptr);
+      return;
+    }
+    (void)hipGetLastError();
+  }
+  hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
 }
 
 // Launch-variant dispatch.  NT_ is the runtime cache-policy mode (0, 1, 2: see IO::load/store).  Unroll
@@ -939,6 +976,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
     if (blocks > (int64_t)cu_count() * 32) blocks = (int64_t)cu_count() * 32;
     hipLaunchKernelGGL((flat_scalar_kernel<Op, TI, TO>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
                        op, p, x, y, n);
+    note<Op, TI, TO>("flat_scalar_kernel", 1, 0);
     return check_launch("flat scalar launch");
   }
   const int64_t nv = n / io::N;
@@ -950,6 +988,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
         if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
         hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
                            op, p, x, y, n);
+        note<Op, TI, TO>("flat_kernel", U, NT);
       });
       return check_launch("flat launch");
     }
@@ -960,6 +999,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
       if (blocks == 0) blocks = 1;
       hipLaunchKernelGGL((flat_loop_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
                          op, p, x, y, n);
+      note<Op, TI, TO>("flat_loop_kernel", U, NT);
     });
     return check_launch("flat loop launch");
   } else {
@@ -970,8 +1010,9 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       if (blocks == 0) blocks = 1;
       if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
-      hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                         op, p, x, y, n);
+      launch_resolved<flat_kernel<Op, TI, TO, U, NT>>(dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                                                       op, p, x, y, n);
+      note<Op, TI, TO>("flat_kernel", U, NT);
     });
     return check_launch("flat launch");
   }
@@ -1009,6 +1050,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
+          note<Op, TI, TO>("rows_kernel", U, NT);
         });
         return check_launch("rows launch");
       }
@@ -1018,6 +1060,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
           if (grid > total) grid = total;
           hipLaunchKernelGGL((rows_persist_kernel<Op, TI, TO, U, NT>), dim3((unsigned)grid), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)total, (uint32_t)innerv, (uint32_t)channels);
+          note<Op, TI, TO>("rows_persist_kernel", U, NT);
         });
         return check_launch("rows persistent launch");
       }
@@ -1038,6 +1081,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         MCTQ_DISPATCH_U_NT(best_u, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)(rows * tiles)), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
+          note<Op, TI, TO>("rows_kernel", U, NT);
         });
         return check_launch("rows launch");
       }
@@ -1061,6 +1105,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
         hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
                            op, x, y, (uint64_t)outer, (uint32_t)vc, (uint32_t)k, (uint32_t)bps);
+        note<Op, TI, TO>("lastaxis_kernel", LU, NT);
       });
       return check_launch("lastaxis launch");
     }
@@ -1104,6 +1149,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
     } else {
       MCTQ_WINDOW_WU(false, uint32_t);
     }
+    note<Op, TI, TO>(vec_ok ? "window_kernel<vector>" : "window_kernel<scalar>", wu, NT);
   });
 #undef MCTQ_WINDOW_WU
 #undef MCTQ_WINDOW

@@ -4,6 +4,8 @@
 namespace mctq {
 
 thread_local char g_err[256] = "";
+thread_local LaunchNote g_note = {"", "", 0, 0, 0, 0};
+static thread_local char g_note_text[160] = "";
 int g_nt = 1;
 int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggregate L2 stay cached for their consumer
 int g_unroll = 4;
@@ -68,6 +70,13 @@ extern "C" {
 int mctq_abi_version(void) { return MCTQ_ABI_VERSION; }
 
 const char* mctq_last_error(void) { return g_err; }
+
+const char* mctq_last_launch(void) {
+  if (!g_note.shape[0]) return "";
+  snprintf(g_note_text, sizeof(g_note_text), "%s<%s,in%dB,out%dB,U=%d,NT=%d>", g_note.shape, g_note.op, g_note.in_bytes,
+           g_note.out_bytes, g_note.unroll, g_note.nt);
+  return g_note_text;
+}
 
 int mctq_set_tuning(const char* key, int32_t value) {
   if (!key) return fail_arg("key is NULL");

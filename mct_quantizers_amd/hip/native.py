@@ -17,6 +17,7 @@ import threading
 ABI_VERSION = 4
 DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
 CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
+FQ_ITEM_PER_TENSOR = 1
 LIB_NAME = "libmctq_hip.so"
 LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
 MCTQ_E_ARG = -10001
@@ -35,13 +36,14 @@ class FqItem(ctypes.Structure):
                 ("outer", ctypes.c_int64), ("channels", ctypes.c_int64), ("inner", ctypes.c_int64),
                 ("scales", ctypes.c_void_p), ("zero_points", ctypes.c_void_p),
                 ("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32),
-                ("dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("dtype", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/mctq_hip.h
 SIGNATURES = {
     "mctq_abi_version": (ctypes.c_int, []),
     "mctq_last_error": (ctypes.c_char_p, []),
+    "mctq_last_launch": (ctypes.c_char_p, []),
     "mctq_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
     "mctq_selftest_division": (ctypes.c_int, [_c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mctq_fq_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_int32,
@@ -222,6 +224,11 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().mctq_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def last_launch() -> str:
+    """Kernel variant of this thread's last elementwise launch (see include/mctq_hip.h: mctq_last_launch)."""
+    return load().mctq_last_launch().decode("utf-8", "replace")
 
 
 def set_tuning(key: str, value: int):

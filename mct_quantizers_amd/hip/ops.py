@@ -248,6 +248,8 @@ def _hip_fq_batched(items):
         scales = _param_on(x, scales, "scales", torch.float32)
         if zps is not None:
             zps = _param_on(x, zps, "zero_points", torch.int32)
+        elif axis is None and dt == native.DT_F64:
+            zps = torch.zeros(1, dtype=torch.int32, device=x.device)
         if axis is None:
             outer, c, inner = (1, 1, x.numel()) if x.numel() else (0, 1, 0)
             if scales.numel() != 1:
@@ -261,7 +263,8 @@ def _hip_fq_batched(items):
         it.outer, it.channels, it.inner = outer, c, inner
         it.scales = scales.data_ptr()
         it.zero_points = zps.data_ptr() if zps is not None else None
-        it.quant_min, it.quant_max, it.dtype, it.reserved = qmin, qmax, dt, 0
+        it.quant_min, it.quant_max, it.dtype = qmin, qmax, dt
+        it.flags = native.FQ_ITEM_PER_TENSOR if axis is None else 0
         outs.append(y)
         keep.append((x, scales, zps))
     if n:

@@ -592,9 +592,20 @@ def test_cached_store_threshold_does_not_change_results(lib):
         native.set_tuning("cached_store_max_mb", 64)
         for q, b in zip(qs, base):
             assert torch.equal(q(xc.clone()), b)
-            assert torch.equal(q(xc.clone().bfloat16()).float(), q(xc.clone().bfloat16()).float())
     finally:
         native.set_tuning("cached_store_max_mb", 32)
+    # bfloat16 storage under both store policies, against the oracle (not against itself)
+    from oracle import oracle_call
+    xb = xc.clone().bfloat16()
+    kw = dict(num_bits=8, threshold=[1.0 + 0.01 * i for i in range(300)], per_channel=True, channel_axis=0)
+    want = oracle_call("WeightsSymmetricInferableQuantizer", kw, xb.float().cpu().numpy(), in_dtype="bfloat16")
+    for mb in (64, 0, 32):
+        native.set_tuning("cached_store_max_mb", mb)
+        try:
+            got = Q.WeightsSymmetricInferableQuantizer(**kw)(xb.clone())
+            assert got.dtype == torch.bfloat16 and bits_equal(got.float().cpu().numpy(), want), mb
+        finally:
+            native.set_tuning("cached_store_max_mb", 32)
 
 
 def test_side_stream_and_graph_capture(lib):
@@ -825,18 +836,30 @@ def test_tensors_beyond_2_pow_31_elements(lib):
 
 def test_loud_failures(lib, monkeypatch):
     import mct_quantizers_amd as mq
-    from mct_quantizers_amd.hip import native
+    from mct_quantizers_amd.hip import native, ops
     q = mq.pytorch_quantizers.ActivationSymmetricInferableQuantizer(8, [4.0], True)
     with pytest.raises(NotImplementedError):
-        q(torch.zeros(8, device="cuda", dtype=torch.float64))              # float64 is not a kernel type
+        q(torch.zeros(8, device="cuda", dtype=torch.int32))                # not a kernel type (float64 is, since round 2)
     qc = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0], True, 0)
     with pytest.raises(RuntimeError):
         qc(torch.zeros(3, 4, device="cuda"))                   # 2 scales for 3 channels
-    # a missing library is an error, never a silent fallback
+    # a missing library is an error, never a silent fallback -- whichever binding is in use: the compiled one
+    # links libmctq_hip.so, so without the library it cannot load either (a warning says so) and the ctypes
+    # route then raises
     monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "_fast", None)
+    monkeypatch.setattr(native, "_fast_tried", False)
+    monkeypatch.setattr(ops, "_FAST", None)
+    monkeypatch.setattr(ops, "_FAST_READY", False)
     monkeypatch.setenv("MCTQ_HIP_LIB", "/nonexistent/libmctq_hip.so")
+    with pytest.warns(UserWarning, match="compiled binding not loaded"):
+        q2 = mq.pytorch_quantizers.ActivationSymmetricInferableQuantizer(8, [4.0], True)
     with pytest.raises(native.NativeLibraryError):
-        q(torch.zeros(8, device="cuda"))
+        q2(torch.zeros(8, device="cuda"))
+    monkeypatch.setenv("MCTQ_BINDING", "compiled")
+    monkeypatch.setattr(native, "_fast_tried", False)
+    with pytest.raises(native.NativeLibraryError):
+        native.fast()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -905,12 +928,16 @@ def test_packed_4bit_codes_reject_unsupported_layouts_and_domains(lib):
 @pytest.mark.parametrize("shape", [(2, 32, 7, 5), (1, 128, 8, 8), (3, 130, 6, 6), (2, 16, 1, 1), (1, 576, 14, 14), (2, 48, 3, 5)])
 def test_fused_quantize_and_nchw_to_nhwc_codes(lib, dtype, shape):
     from mct_quantizers_amd.hip import ops
+    from oracle import mctq_oracle as O
     x = (torch.randn(*shape) * 2).to(dtype)
     for (qmin, qmax, scale, zp) in ((0, 255, 0.0219, 114), (-128, 127, 0.031, 0), (0, 15, 0.3, 7)):
         got = ops.fq_codes_nhwc(x.cuda(), qmin, qmax, scale, zp)
-        want = ops.fq_codes(x.cuda(), None, None, None, qmin, qmax, scale, zp).permute(0, 2, 3, 1).contiguous()
-        assert got.shape == (shape[0], shape[2], shape[3], shape[1]) and got.is_contiguous() and got.dtype == want.dtype
-        assert torch.equal(got, want), (shape, dtype, qmin)
+        # the ORACLE's clamp index (numpy, from the reference's arithmetic), moved to NHWC on the host
+        _, idx = O.fake_quant_affine(x.float().numpy(), [scale], [zp], qmin, qmax, return_index=True)
+        want = torch.from_numpy(np.ascontiguousarray(idx.transpose(0, 2, 3, 1))).to(got.dtype)
+        assert got.shape == (shape[0], shape[2], shape[3], shape[1]) and got.is_contiguous()
+        assert torch.equal(got.cpu(), want), (shape, dtype, qmin)
+        want = want.cuda()
         cl = x.cuda().contiguous(memory_format=torch.channels_last)
         assert torch.equal(ops.fq_codes_nhwc(cl, qmin, qmax, scale, zp), want)
         assert torch.equal(ops.fq_codes_nhwc(x, qmin, qmax, scale, zp), want.cpu())          # CPU route

@@ -1,0 +1,450 @@
+"""GPU parity tests of the round-2 additions, all against the oracle / reference fixtures:
+
+float64 tensors, the two bindings of the C ABI (compiled and ctypes), the batched multi-tensor launch, the
+tensor-qparams entry point and its fx routing, torch.jit tracing, the literal LUT scan for half inputs, the
+remaining config-3 batch sizes, launch-plan invalidation, device checks.
+"""
+import hashlib
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bits_equal, first_mismatch, load_json
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mct_quantizers_amd.hip import native
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return native.load()
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def _make(cls, kwargs):
+    import mct_quantizers_amd as mq
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return getattr(mq.pytorch_quantizers, cls)(**kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# float64
+# ---------------------------------------------------------------------------------------------
+
+def test_float64_golden_cases_via_quantizer_classes(lib):
+    """41 (kwargs, float64 input) -> output cases produced by the reference: dtype, strides and every bit."""
+    meta = load_json("cases_f64.json")
+    arrays = np.load(os.path.join(GOLDEN, "cases_f64.npz"))
+    assert len(meta["cases"]) >= 40
+    for c in meta["cases"]:
+        x_np, want = arrays[c["id"] + "_x"], arrays[c["id"] + "_y"]
+        x = _dev(x_np)
+        if c["memory_format"] == "channels_last":
+            x = x.contiguous(memory_format=torch.channels_last)
+        y = _make(c["cls"], c["kwargs"])(x)
+        assert y.is_cuda and y.shape == x.shape and str(y.dtype) == "torch." + c["out_dtype"], c["id"]
+        got = y.cpu().numpy()
+        assert got.dtype == want.dtype and np.array_equal(_bits(got), _bits(want)), \
+            f'{c["id"]} {c["cls"]} {c["shape"]}: {(got != want).sum()} of {got.size} differ'
+
+
+def test_float64_raw_abi_against_oracle_all_layouts(lib):
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for outer, C, inner in ((1, 1, 4099), (3, 5, 7), (2, 6, 64), (1, 4, 2048), (5, 3, 1), (1, 1, 1), (2, 2, 3)):
+        n = outer * C * inner
+        s = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+        z = rng.integers(-4, 5, size=C).astype(np.int32)
+        x = rng.standard_normal(n) * 3.0
+        sd, zd = _dev(s), _dev(z)                                # keep the device tables alive across the launch
+        for offset in (0, 1):                                   # 16-byte aligned and not
+            xb = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+            xb[offset:offset + n] = _dev(x)
+            yb = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+            rc = lib.mctq_fq_per_channel(xb[offset:].data_ptr(), yb[offset:].data_ptr(), outer, C, inner, native.DT_F64,
+                                         sd.data_ptr(), zd.data_ptr(), -8, 7, st)
+            assert rc == 0, native.load().mctq_last_error()
+            want = O.fake_quant_affine_f64(x.reshape(outer, C, inner), s, z, -8, 7, axis=1).reshape(-1)
+            got = yb[offset:offset + n].cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(want)), (outer, C, inner, offset)
+            assert float(yb[offset + n:].abs().sum()) == 0 and float(yb[:offset].abs().sum()) == 0   # no stray writes
+    # per tensor: float qparams and device qparams give the float32-product flavour
+    x = rng.standard_normal(1000) * 3.0
+    xd, yd = _dev(x), torch.empty(1000, dtype=torch.float64, device="cuda")
+    want = O.fake_quant_affine_f64(x, [0.0371], [3], 0, 255)
+    assert lib.mctq_fq_per_tensor(xd.data_ptr(), yd.data_ptr(), 1000, native.DT_F64, 0.0371, 3, 0, 255, st) == 0
+    assert np.array_equal(_bits(yd.cpu().numpy()), _bits(want))
+    sc, zp = _dev(np.float32([0.0371])), _dev(np.int32([3]))
+    yd.zero_()
+    assert lib.mctq_fq_per_tensor_tqp(xd.data_ptr(), yd.data_ptr(), 1000, native.DT_F64, sc.data_ptr(), zp.data_ptr(), 0, 255, st) == 0
+    assert np.array_equal(_bits(yd.cpu().numpy()), _bits(want))
+
+
+# ---------------------------------------------------------------------------------------------
+# the two bindings of the same C ABI
+# ---------------------------------------------------------------------------------------------
+
+def test_compiled_and_ctypes_bindings_agree_with_the_oracle(lib):
+    from mct_quantizers_amd.hip import native, ops
+    from oracle import mctq_oracle as O
+    fast = native.fast()
+    assert fast is not None, "the compiled binding must load on the GPU box (python -m mct_quantizers_amd.hip.build)"
+    rng = np.random.default_rng(11)
+    for shape in ((3, 224, 224), (7,), (5, 1031), (2, 3, 8, 8), (0, 4)):
+        x_np = (rng.standard_normal(shape) * 2).astype(np.float32)
+        x = _dev(x_np)
+        want = O.fake_quant_affine(x_np, [0.0219], [114], 0, 255)
+        a = fast.fq_per_tensor(x, 0.0219, 114, 0, 255)
+        b = ops._hip_fq_per_tensor(x, 0.0219, 114, 0, 255)
+        plan = fast.AffinePlan(0.0219, 114, 0, 255)
+        c = plan(x)
+        for got in (a, b, c):
+            assert got.dtype == x.dtype and got.shape == x.shape and got.stride() == x.stride()
+            assert bits_equal(got.cpu().numpy(), want), first_mismatch(got.cpu().numpy(), want, x_np)
+    # per channel, every axis, dense permuted storage, Parameter input
+    x_np = (rng.standard_normal((6, 5, 40)) * 2).astype(np.float32)
+    for axis in (0, 1, 2):
+        C = x_np.shape[axis]
+        s = rng.uniform(0.01, 0.1, size=C).astype(np.float32)
+        z = rng.integers(-3, 4, size=C).astype(np.int32)
+        want = O.fake_quant_affine(x_np, s, z, -128, 127, axis=axis)
+        sd, zd = _dev(s), _dev(z)
+        for x in (_dev(x_np), torch.nn.Parameter(_dev(x_np)), _dev(x_np).permute(2, 0, 1).contiguous().permute(1, 2, 0)):
+            a = fast.fq_per_channel(x, sd, zd, axis, -128, 127)
+            b = ops._hip_fq_per_channel(x.detach(), sd, zd, axis, -128, 127)
+            c = fast.AffinePlan(sd, zd, axis, -128, 127)(x)
+            for got in (a, b, c):
+                assert got.stride() == x.stride() and not got.requires_grad
+                assert bits_equal(got.cpu().numpy(), want), (axis, first_mismatch(got.cpu().numpy(), want, x_np))
+    # what the compiled binding declines goes to the general route: NotImplemented, never a wrong answer
+    assert fast.fq_per_tensor(torch.randn(4), 0.1, 0, -8, 7) is NotImplemented                      # CPU tensor
+    assert fast.fq_per_tensor(torch.randn(8, 8, device="cuda")[:, ::2], 0.1, 0, -8, 7) is NotImplemented   # gaps
+    assert fast.fq_per_tensor(torch.zeros(4, device="cuda", dtype=torch.int32), 0.1, 0, -8, 7) is NotImplemented
+    assert fast.fq_per_channel(torch.randn(4, 4, device="cuda"), torch.ones(4), None, 0, -8, 7) is NotImplemented  # CPU scales
+    y = ops.fq_per_tensor(torch.randn(8, 8, device="cuda")[:, ::2], 0.1, 0, -8, 7)                # ... and still works
+    assert y.shape == (8, 4)
+
+
+def test_ctypes_binding_alone_runs_the_suite_subset(lib, golden_cases, monkeypatch):
+    """MCTQ_BINDING=ctypes: same results without the compiled module (fresh ops state)."""
+    from mct_quantizers_amd.hip import ops
+    monkeypatch.setattr(ops, "_FAST", None)
+    monkeypatch.setattr(ops, "_FAST_READY", True)
+    cases, arrays = golden_cases
+    for c in cases[:40]:
+        x_np, want = arrays[c["id"] + "_x"], arrays[c["id"] + "_y"]
+        x = _dev(x_np)
+        if c["memory_format"] == "channels_last":
+            x = x.contiguous(memory_format=torch.channels_last)
+        elif c["memory_format"] == "transposed":
+            x = x.transpose(0, -1).contiguous().transpose(0, -1)
+        q = _make(c["cls"], c["kwargs"])
+        assert q.__dict__.get("_plan") in (None, False)
+        got = q(x).cpu().numpy()
+        assert bits_equal(got, want), f'{c["id"]}: {first_mismatch(got, want, x_np)}'
+
+
+# ---------------------------------------------------------------------------------------------
+# one launch for a list of tensors
+# ---------------------------------------------------------------------------------------------
+
+def _batch_cases(rng):
+    from oracle import mctq_oracle as O
+    items, wants = [], []
+    specs = [((64, 4096), 0, torch.float32), ((300, 576), 0, torch.float32), ((7, 33, 5), 1, torch.float32),
+             ((16, 8, 3, 3), 0, torch.float32), ((5, 1031), None, torch.float32), ((4, 4096), 1, torch.float32),
+             ((3, 10, 10, 6), 3, torch.float32), ((2, 2050), 0, torch.float16), ((9, 257), 1, torch.bfloat16),
+             ((128, 1024), 0, torch.bfloat16), ((1,), None, torch.float32), ((6, 37), 0, torch.float64),
+             ((11, 23), None, torch.float64)]
+    for shape, axis, dt in specs:
+        C = 1 if axis is None else shape[axis]
+        s = rng.uniform(0.01, 0.1, size=C).astype(np.float32)
+        z = rng.integers(-3, 4, size=C).astype(np.int32) if rng.random() < 0.6 else None
+        x32 = (rng.standard_normal(shape) * 2).astype(np.float32)
+        if dt == torch.float64:
+            x = torch.from_numpy(x32.astype(np.float64) * (1 + 1e-9))
+            zz = np.zeros(C, np.int32) if z is None else z
+            want = O.fake_quant_affine_f64(x.numpy(), s, zz, -128, 127, axis=axis) if axis is not None else \
+                O.fake_quant_affine_f64(x.numpy(), s, zz, -128, 127)
+        else:
+            x = torch.from_numpy(x32).to(dt)
+            zz = np.zeros(C, np.int32) if z is None else z
+            want = O.narrow(O.fake_quant_affine(x.float().numpy(), s, zz, -128, 127, axis=axis),
+                            str(dt).replace("torch.", ""))
+        items.append((x.cuda(), _dev(s), None if z is None else _dev(z), axis, -128, 127))
+        wants.append(want)
+    return items, wants
+
+
+def test_batched_launch_mixed_shapes_axes_dtypes_against_oracle(lib):
+    from mct_quantizers_amd.hip import native, ops
+    rng = np.random.default_rng(23)
+    items, wants = _batch_cases(rng)
+    for route in ("compiled", "ctypes"):
+        outs = ops.fq_batched(items) if route == "compiled" else ops._hip_fq_batched(items)
+        assert len(outs) == len(items)
+        for (x, *_), y, want in zip(items, outs, wants):
+            assert y.dtype == x.dtype and y.shape == x.shape and y.stride() == x.stride()
+            got = y.cpu().double().numpy() if x.dtype == torch.float64 else y.float().cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(want)), (route, tuple(x.shape), x.dtype)
+    assert "batched_kernel" in native.last_launch() or "fq64" in native.last_launch() or native.last_launch()
+    # more tensors than one launch holds (32), tails, unaligned views (-> single launches inside the call)
+    many = []
+    for k in range(70):
+        n = 1000 + 37 * k
+        base = torch.randn(n + 1, device="cuda")
+        many.append((base[1:] if k % 5 == 0 else base[:n], _dev(np.float32([0.05 + 0.001 * k])), None, None, -8, 7))
+    outs = ops.fq_batched(many)
+    for (x, s, _, _, lo, hi), y in zip(many, outs):
+        assert torch.equal(y, ops.fq_per_tensor(x.contiguous(), float(s.item()), 0, lo, hi)), x.shape
+    assert ops.fq_batched([]) == []
+    # a bad descriptor fails before anything is launched
+    st = torch.cuda.current_stream().cuda_stream
+    arr = (native.FqItem * 2)()
+    x = torch.randn(64, device="cuda"); y = torch.full((64,), 7.0, device="cuda"); s = _dev(np.float32([0.1]))
+    for it, qmin in zip(arr, (-8, 9)):
+        it.x, it.y, it.outer, it.channels, it.inner = x.data_ptr(), y.data_ptr(), 1, 1, 64
+        it.scales, it.zero_points, it.quant_min, it.quant_max, it.dtype = s.data_ptr(), None, qmin, 7, native.DT_F32
+    assert lib.mctq_fq_batched(arr, 2, st) == native.MCTQ_E_ARG
+    torch.cuda.synchronize()
+    assert bool((y == 7.0).all())
+
+
+def test_batched_weight_quantization_of_a_model_is_bit_identical(lib):
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(3)
+    layers = []
+    for i, (fin, fout) in enumerate(((64, 96), (96, 4096), (4096, 40))):
+        lin = torch.nn.Linear(fin, fout)
+        thr = [float(v) + 1e-3 for v in lin.weight.detach().abs().amax(dim=1)]
+        wq = {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0) if i != 1 else
+              Q.WeightsUniformInferableQuantizer(4, [-0.3] * fout, [0.2] * fout, True, 0),
+              "bias": Q.WeightsSymmetricInferableQuantizer(8, [1.0], False)}
+        layers += [mq.PytorchQuantizationWrapper(lin, wq),
+                   mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0]))]
+    lut = mq.PytorchQuantizationWrapper(torch.nn.Linear(40, 8), {"weight": Q.WeightsLUTSymmetricInferableQuantizer(
+        3, [-100.0, -50.0, -10.0, 0.0, 10.0, 50.0, 100.0, 127.0], [1.0], False)})      # stays on its own quantizer
+    model = torch.nn.Sequential(*layers, lut).cuda()
+    x = torch.randn(5, 64, device="cuda")
+    want = model(x)
+    want_w = [m.layer.weight.clone() for m in model if isinstance(m, mq.PytorchQuantizationWrapper)]
+    handle = batch_weight_quantization(model)
+    assert handle.quantize_now() == 6
+    got = model(x)
+    assert torch.equal(got, want)
+    for m, w in zip([m for m in model if isinstance(m, mq.PytorchQuantizationWrapper)], want_w):
+        assert torch.equal(m.layer.weight, w) and "_prequantized" not in m.__dict__
+    with torch.no_grad():
+        model[0].weight.mul_(0.5)                           # weights are re-quantized on EVERY forward
+    after = model(x)
+    handle.remove()
+    assert torch.equal(model(x), after) and not torch.equal(after, want)
+
+
+# ---------------------------------------------------------------------------------------------
+# tensor-qparams entry point, fx routing of traced reference quantizers
+# ---------------------------------------------------------------------------------------------
+
+def test_tensor_qparams_entry_against_oracle(lib):
+    from mct_quantizers_amd.hip import ops
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(31)
+    for n in (1, 3, 1023, 1024, 4096 + 5, 1 << 20):
+        x_np = (rng.standard_normal(n) * 2).astype(np.float32)
+        s, z = np.float32([0.0173]), np.int32([-2])
+        want = O.fake_quant_affine(x_np, s, z, -128, 127)
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            x = torch.from_numpy(x_np).to(dt).cuda()
+            w = O.narrow(O.fake_quant_affine(x.float().cpu().numpy(), s, z, -128, 127), str(dt).replace("torch.", ""))
+            for got in (ops.fq_per_tensor_tqp(x, _dev(s), _dev(z), -128, 127),
+                        ops._hip_fq_per_tensor_tqp(x, _dev(s), _dev(z), -128, 127),
+                        torch.ops.mctq_amd.fq_per_tensor_tqp(x, _dev(s), _dev(z), -128, 127)):
+                assert got.dtype == dt and bits_equal(got.float().cpu().numpy(), w), (n, dt)
+        assert bits_equal(ops.fq_per_tensor_tqp(_dev(x_np), _dev(s), _dev(z), -128, 127).cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        ops.fq_per_tensor_tqp(_dev(np.float32([1, 2])), torch.tensor([0.1]), _dev(np.int32([0])), -8, 7)   # CPU scale
+
+
+def test_traced_reference_weights_quantizers_are_rerouted_and_bit_exact(lib):
+    """tests/golden/ref_traced_weight_quantizers.pth: fx trace of the REFERENCE's per-tensor / per-channel weights
+    quantizers (tensor-qparams nodes).  Every fake_quantize node must end up on the mctq_amd ops and reproduce the
+    reference's outputs."""
+    from mct_quantizers_amd import compat
+    gm = compat.load_reference_model(os.path.join(GOLDEN, "ref_traced_weight_quantizers.pth"), map_location="cuda")
+    targets = [str(n.target) for n in gm.graph.nodes if n.op == "call_function"]
+    assert sum("fq_per_tensor_tqp" in t for t in targets) == 2 and sum("fq_per_channel" in t for t in targets) == 1
+    assert not any("fake_quantize" in t for t in targets), targets
+    io = np.load(os.path.join(GOLDEN, "ref_traced_weight_quantizers_io.npz"))
+    o1, o3, o2 = gm(_dev(io["w"]), _dev(io["v"]))
+    for got, key in ((o1, "o1"), (o3, "o3"), (o2, "o2")):
+        assert got.is_cuda and bits_equal(got.cpu().numpy(), io[key]), key
+    # the traced reference WRAPPER: weights were folded at trace time, the activation node is rerouted
+    gw = compat.load_reference_model(os.path.join(GOLDEN, "ref_traced_wrapper.pth"), map_location="cuda").cuda()
+    assert any("mctq_amd" in str(n.target) for n in gw.graph.nodes if n.op == "call_function")
+    iow = np.load(os.path.join(GOLDEN, "ref_traced_wrapper_io.npz"))
+    assert bits_equal(gw.l1.layer.weight.cpu().numpy(), iow["w1"]) and bits_equal(gw.l2.layer.weight.cpu().numpy(), iow["w2"])
+    y = gw(_dev(iow["x"])).detach().cpu().numpy()
+    assert np.allclose(y, iow["y"], rtol=0, atol=1e-4)              # two float32 GEMMs on another device
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.jit tracing without enable_custom_impl (TorchScript / fakely-quant ONNX export)
+# ---------------------------------------------------------------------------------------------
+
+def test_jit_trace_records_aten_nodes_not_an_uninitialised_buffer(lib):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    x = torch.randn(4, 16, device="cuda")
+    holder = mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1]))
+    lin = torch.nn.Linear(16, 8)
+    wrapper = mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, [0.3] * 8, True, 0),
+                                                  "bias": Q.WeightsSymmetricInferableQuantizer(8, [0.5], False)}).cuda()
+    lutq = Q.ActivationLutPOTInferableQuantizer(2, [-100.0, 0.0, 60.0, 127.0], [4.0], True)
+    wl = Q.WeightsLUTSymmetricInferableQuantizer(3, [-100.0, -50.0, -10.0, 0.0, 10.0, 50.0, 100.0, 127.0], [1.0, 2.0, 0.5, 1.5], True, 0, 2)
+    for mod, inp in ((holder, x), (wrapper, x), (mq.PytorchActivationQuantizationHolder(lutq), x),
+                     (mq.PytorchActivationQuantizationHolder(Q.ActivationPOTInferableQuantizer(4, [2.0], True)), x)):
+        eager = mod(inp)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            traced = torch.jit.trace(mod, inp, check_trace=False)
+        kinds = [n.kind() for n in traced.graph.nodes()]
+        if mod is not wrapper:
+            assert any("fake_quantize" in k or "argmin" in k for k in kinds), kinds
+        assert not any(k == "aten::empty_like" for k in kinds), kinds
+        y1, y2 = traced(inp), traced(inp * 0.5)
+        assert torch.equal(y1, eager) and torch.equal(y2, mod(inp * 0.5))
+    w = torch.randn(4, 33, device="cuda")
+    f = lambda t: wl(t)   # noqa: E731
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = torch.jit.trace(f, w.clone(), check_trace=False)
+    assert torch.equal(tr(w.clone()), wl(w.clone()))
+    assert torch.equal(mq.PytorchActivationQuantizationHolder(lutq)(x), lutq(x))      # eager path untouched afterwards
+
+
+# ---------------------------------------------------------------------------------------------
+# literal LUT scan for half-precision storage (no decision table)
+# ---------------------------------------------------------------------------------------------
+
+def test_literal_scan_takes_half_inputs_and_step_rounding(lib):
+    from mct_quantizers_amd.hip import native, ops
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(41)
+    lut = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+    lut_d = _dev(np.float32(lut))
+    x32 = (rng.standard_normal((5, 700)) * 1.4).astype(np.float32)
+    for dt, name, code in ((torch.float16, "float16", native.DT_F16), (torch.bfloat16, "bfloat16", native.DT_BF16)):
+        x = torch.from_numpy(x32).to(dt)
+        xw = x.float().numpy()
+        # activation flavour: Python-float threshold, per-step roundings in the tensor's type
+        div = float(torch.tensor([2.0 + 1e-8], dtype=torch.float64).to(dt).item())
+        want = O.lut_quantize(xw, lut, 2.0, True, 8, 1e-8, step_dtype=name)
+        got = ops._hip_lut_per_tensor(x.cuda(), lut_d, div, 2.0, 128.0, -128.0, 127.0, None, code)
+        assert got.dtype == torch.float32 and bits_equal(got.cpu().numpy(), want), (name, first_mismatch(got.cpu().numpy(), want, xw))
+        # weights flavour: float32 tensor threshold -> promoted chain, per channel, NO widening pass
+        thr = rng.uniform(0.5, 3.0, size=5).astype(np.float32)
+        want = O.lut_quantize(xw, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=0)
+        got = ops._hip_lut_per_channel(x.cuda(), lut_d, _dev(thr), 1e-8, 0, 128.0, -128.0, 127.0, None)
+        assert bits_equal(got.cpu().numpy(), want), name
+        assert "LutOp" in native.last_launch() and "in2B" in native.last_launch(), native.last_launch()
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3 at the other batch sizes SURVEY §8(d) names
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 64, 256])
+def test_config3_full_size_digests_for_every_batch_size(lib, n):
+    from mct_quantizers_amd import workloads
+    rec = load_json("full_sha.json")["configs"][f"cfg3_n{n}"]
+    x_np = workloads.make_input("cfg3", batch=n)
+    assert hashlib.sha256(x_np.tobytes()).hexdigest() == rec["x_sha256"]
+    wl = workloads.make_workload("cfg3", x_np)
+    y = _make(wl.quantizer, wl.kwargs)(_dev(x_np)).cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest() == rec["y_sha256"]
+
+
+# ---------------------------------------------------------------------------------------------
+# launch state follows the public attributes (the reference reads them on every call)
+# ---------------------------------------------------------------------------------------------
+
+def test_public_attribute_changes_take_effect(lib):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    x = torch.randn(3, 64, device="cuda")
+    q = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    a = q(x)
+    q.scale = q.scale * 2
+    b = q(x)
+    assert torch.equal(b, torch.fake_quantize_per_tensor_affine(x, q.scale, q.zero_point, 0, 255)) and not torch.equal(a, b)
+    q.zero_point = 100
+    assert torch.equal(q(x), torch.fake_quantize_per_tensor_affine(x, q.scale, 100, 0, 255))
+    qs = Q.ActivationSymmetricInferableQuantizer(8, [2.0], True)
+    qs.scales = 0.05
+    assert torch.equal(qs(x), torch.fake_quantize_per_tensor_affine(x, 0.05, 0, -128, 127))
+    w = torch.randn(3, 64, device="cuda")
+    qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0, 3.0], True, 0)
+    base = qw(w.clone())
+    qw.zero_points[0] = 5                                           # in-place edit of the device tensor
+    got = qw(w.clone())
+    want = torch.fake_quantize_per_channel_affine(w, qw.scales, qw.zero_points, 0, -128, 127)
+    assert torch.equal(got, want) and not torch.equal(got, base)
+    qw.scales = qw.scales * 0.5                                     # replaced tensor
+    assert torch.equal(qw(w.clone()), torch.fake_quantize_per_channel_affine(w, qw.scales, qw.zero_points, 0, -128, 127))
+    qt = Q.WeightsUniformInferableQuantizer(8, [-1.0], [1.0], False)
+    qt.scales.mul_(2.0)
+    assert torch.equal(qt(w.clone()), torch.fake_quantize_per_tensor_affine(w, qt.scales, qt.zero_points, 0, 255))
+    import copy
+    import pickle
+    for obj in (q, qs, qw, qt):
+        clone = pickle.loads(pickle.dumps(obj))
+        assert torch.equal(clone(w.clone()), obj(w.clone())) and torch.equal(copy.deepcopy(obj)(w.clone()), obj(w.clone()))
+    with pytest.raises(ValueError):
+        Q.ActivationSymmetricInferableQuantizer(30, [2.0], True)
+
+
+def test_parameters_on_another_device_raise_cleanly(lib):
+    from mct_quantizers_amd.hip import ops
+    x = torch.randn(4, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="same device"):
+        ops.fq_per_channel(x, torch.ones(4), torch.zeros(4, dtype=torch.int32), 0, -8, 7)
+    with pytest.raises(RuntimeError, match="same device"):
+        ops.fq_codes(x, torch.ones(4), torch.zeros(4, dtype=torch.int32), 0, -8, 7)
+    with pytest.raises(RuntimeError, match="same device"):
+        ops.lut_per_channel(x, torch.tensor([0.0, 1.0]), torch.ones(4, device="cuda"), 1e-8, 0, 128.0, -128.0, 127.0)
+
+
+def test_holder_fast_call_keeps_module_semantics(lib):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    h = mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1]))
+    x = torch.randn(2, 8, device="cuda")
+    want = h.forward(x)
+    assert torch.equal(h(x), want)
+    seen = []
+    hook = h.register_forward_hook(lambda m, i, o: seen.append(1))
+    assert torch.equal(h(x), want) and seen == [1]
+    hook.remove()
+    pre = h.register_forward_pre_hook(lambda m, i: (i[0] * 0,))
+    assert float(h(x).abs().sum()) == float(h.forward(x * 0).abs().sum())
+    pre.remove()
+    b = mq.PytorchFLNActivationQuantizationHolder(Q.ActivationPOTInferableQuantizer(8, [2.0], True), quantization_bypass=True)
+    assert b(x) is x

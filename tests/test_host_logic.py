@@ -354,3 +354,93 @@ def test_packed_4bit_codes_on_cpu_tensors_match_the_oracle_packing():
     import pytest
     with pytest.raises(ValueError):
         Q.ActivationSymmetricInferableQuantizer(num_bits=8, threshold=[1.0], signed=True).quantize_to_codes(x, packed4=True)
+
+
+def test_batched_weight_quantization_on_cpu_tensors_matches_per_layer_calls():
+    """pytorch/batching.py on CPU tensors (no batched kernel there: the general route quantizes one by one) --
+    same results, same re-quantize-every-forward semantics, clean removal."""
+    from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+    torch.manual_seed(0)
+    mods = []
+    for fin, fout in ((8, 16), (16, 4)):
+        lin = torch.nn.Linear(fin, fout)
+        mods.append(PytorchQuantizationWrapper(lin, {
+            "weight": Q.WeightsSymmetricInferableQuantizer(8, [0.5] * fout, True, 0),
+            "bias": Q.WeightsUniformInferableQuantizer(8, [-0.4], [0.6], False)}))
+        mods.append(PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])))
+    model = torch.nn.Sequential(*mods)
+    x = torch.randn(3, 8)
+    want = model(x)
+    handle = batch_weight_quantization(model)
+    assert handle.quantize_now() == 4
+    assert torch.equal(model(x), want)
+    with torch.no_grad():
+        model[0].weight.mul_(0.25)
+    changed = model(x)
+    handle.remove()
+    assert torch.equal(model(x), changed) and not torch.equal(changed, want)
+    assert all("_prequantized" not in m.__dict__ for m in model)
+
+
+def test_tensor_qparams_op_and_fx_routing_on_cpu():
+    from mct_quantizers_amd import compat
+    from mct_quantizers_amd.hip import ops
+    x = torch.randn(5, 9)
+    s, z = torch.tensor([0.05]), torch.tensor([3], dtype=torch.int32)
+    want = torch.fake_quantize_per_tensor_affine(x, s, z, 0, 255)
+    assert torch.equal(ops.fq_per_tensor_tqp(x, s, z, 0, 255), want)
+    assert torch.equal(torch.ops.mctq_amd.fq_per_tensor_tqp(x, s, z, 0, 255), want)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("s", s.clone())
+            self.register_buffer("z", z.clone())
+
+        def forward(self, t):
+            return torch.fake_quantize_per_tensor_affine(t, self.s, self.z, 0, 255)
+
+    gm = torch.fx.symbolic_trace(M())
+    assert compat.route_fx_graph(gm) == 1
+    assert "fq_per_tensor_tqp" in gm.code and torch.equal(gm(x), want)
+
+
+def test_launch_attributes_invalidate_the_plan_and_survive_pickling():
+    import copy
+    import pickle
+    q = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    x = torch.randn(4, 7)
+    q.scale = 0.125
+    q.zero_point = 9
+    assert torch.equal(q(x), torch.fake_quantize_per_tensor_affine(x, 0.125, 9, 0, 255))
+    assert q.__dict__["scale"] == 0.125                     # plain instance attributes, as in the reference's pickles
+    for clone in (pickle.loads(pickle.dumps(q)), copy.deepcopy(q)):
+        assert clone.scale == 0.125 and torch.equal(clone(x), q(x))
+    w = Q.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0], True, 0)
+    t = torch.randn(2, 5)
+    w.zero_points[1] = 4
+    assert torch.equal(w(t.clone()), torch.fake_quantize_per_channel_affine(t, w.scales, w.zero_points, 0, -128, 127))
+    assert "_plan" not in pickle.loads(pickle.dumps(w)).__getstate__()
+    with pytest.raises(ValueError):
+        Q.WeightsSymmetricInferableQuantizer(25, [1.0], False)
+
+
+def test_jit_trace_on_cpu_records_the_reference_nodes():
+    h = PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1]))
+    x = torch.randn(3, 5)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = torch.jit.trace(h, x, check_trace=False)
+    assert any("fake_quantize_per_tensor_affine" in n.kind() for n in tr.graph.nodes())
+    assert torch.equal(tr(x * 2), h(x * 2))
+
+
+def test_lut_quantizer_accepts_a_negative_channel_axis():
+    from mct_quantizers_amd.pytorch.quantizer_utils import lut_quantizer
+    x = torch.randn(3, 4, 5)
+    lut = torch.tensor([-100.0, 0.0, 60.0, 127.0])
+    thr = torch.tensor([1.0, 2.0, 0.5, 4.0, 1.5])
+    a = lut_quantizer(x, lut, True, thr, 8, 1e-8, per_channel=True, channel_axis=-1, input_rank=3)
+    b = lut_quantizer(x, lut, True, thr, 8, 1e-8, per_channel=True, channel_axis=2, input_rank=3)
+    assert torch.equal(a, b)

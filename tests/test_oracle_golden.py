@@ -151,3 +151,25 @@ def test_portable_generator_digests():
         wl = workloads.make_workload(cfg, x)
         y = oracle_call(wl.quantizer, wl.kwargs, x)
         assert hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest() == full[cfg]["y_sha256"]
+
+
+def test_oracle_matches_reference_float64_cases():
+    """float64 tensors: the reference hands them to ATen, whose double kernels are their own arithmetic (double
+    product for the index; per-tensor results are widened float32 products, per-channel ones double products; the
+    LUT chain answers in float32).  41 reference-generated cases, bit for bit."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from oracle import oracle_call
+    with open(os.path.join(GOLDEN, "cases_f64.json")) as f:
+        meta = json.load(f)
+    arrays = np.load(os.path.join(GOLDEN, "cases_f64.npz"))
+    kinds = set()
+    for c in meta["cases"]:
+        x, want = arrays[c["id"] + "_x"], arrays[c["id"] + "_y"]
+        assert x.dtype == np.float64 and str(want.dtype) == c["out_dtype"]
+        got = oracle_call(c["cls"], c["kwargs"], x, in_dtype="float64")
+        view = np.uint64 if want.dtype == np.float64 else np.uint32
+        assert got.dtype == want.dtype and np.array_equal(got.view(view), want.view(view)), c["id"]
+        kinds.add((c["cls"], bool(c["kwargs"].get("per_channel"))))
+    assert len(kinds) >= 12        # all nine classes, per-tensor and per-channel where they exist

@@ -46,6 +46,11 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
             for q in mod.weights_quantizers.values():
                 q.enable_versioned_reuse()
     reuse, y3 = timeit(m3, x)
+    # all wrapped weights re-quantized in ONE launch per forward (pytorch/batching.py -> mctq_fq_batched)
+    from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+    m6 = build(layers, d, False)
+    batch_weight_quantization(m6)
+    batched, y6 = timeit(m6, x)
     # integer consumers: every (activation holder, wrapped Linear) pair runs on the codes (mctq_qlinear_i8)
     from mct_quantizers_amd import consumers
     m4 = build(layers, d, False)
@@ -62,7 +67,8 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
     # build()'s order is wrapper, holder, wrapper, ...: every QuantizedLinear but the last feeds the next one
     chained, y5 = timeit(m5, x)
     print(f"{layers} x Linear({d},{d}) batch {batch}: this package {ours:7.3f} ms/forward, ATen fake-quant ops {aten:7.3f} ms/forward "
-          f"(x{aten/ours:.2f}), with versioned weight reuse {reuse:7.3f} ms; outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3)}; "
+          f"(x{aten/ours:.2f}), weights batched into one launch {batched:7.3f} ms, with versioned weight reuse {reuse:7.3f} ms; "
+          f"outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(y1, y6)}; "
           f"{nf} layer pairs on integer codes {fused:7.3f} ms (x{aten/fused:.2f} vs ATen path, max rel diff after the first pair {err:.1e}); "
           f"chained (codes passed between layers) {chained:7.3f} ms (x{aten/chained:.2f}), equal to unchained={torch.equal(y4, y5)}",
           flush=True)

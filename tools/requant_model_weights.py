@@ -1,0 +1,48 @@
+"""Re-quantizing ALL weights of a model, as every forward of an MCT-exported model does
+(reference pytorch/quantize_wrapper.py:228-240): one quantizer call per layer vs ONE batched launch
+(ops.fq_batched -> mctq_fq_batched).  Weight shapes of ResNet-50 (54 tensors, 25.5 M parameters) and of a
+16 x Linear(4096) stack; per-channel symmetric 8 bit along axis 0.  Outputs are compared bit for bit."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mct_quantizers_amd as mq
+from mct_quantizers_amd.hip import ops
+Q = mq.pytorch_quantizers
+
+def resnet50_shapes():
+    shapes = [(64, 3, 7, 7)]
+    cin = 64
+    for width, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            shapes += [(width, cin, 1, 1), (width, width, 3, 3), (width * 4, width, 1, 1)]
+            if b == 0:
+                shapes.append((width * 4, cin, 1, 1))
+            cin = width * 4
+    shapes.append((1000, 2048))
+    return shapes
+
+def run(name, shapes, reps=200):
+    torch.manual_seed(0)
+    ws = [torch.randn(s, device="cuda") * 0.05 for s in shapes]
+    qs = [Q.WeightsSymmetricInferableQuantizer(8, [float(v) + 1e-6 for v in w.reshape(w.shape[0], -1).abs().amax(dim=1)], True, 0) for w in ws]
+    aten = lambda: [torch.fake_quantize_per_channel_affine(w, q.scales, q.zero_points, 0, -128, 127) for w, q in zip(ws, qs)]
+    per_layer = lambda: [q(w) for w, q in zip(ws, qs)]
+    batched = lambda: ops.fq_batched([q.batch_item(w) for w, q in zip(ws, qs)])
+    a, b, c = aten(), per_layer(), batched()
+    same = all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(a, b, c))
+    nbytes = sum(w.numel() for w in ws) * 8
+    res = {}
+    for label, f in (("ATen ops (what the reference runs)", aten), ("this package, one call per layer", per_layer), ("this package, ONE batched launch", batched)):
+        for _ in range(10): f()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps): f()
+        torch.cuda.synchronize()
+        res[label] = (time.perf_counter() - t) / reps * 1e6
+    print(f"{name}: {len(ws)} tensors, {nbytes / 8e6:.1f} M elements, bit-equal={same}")
+    for k, v in res.items():
+        print(f"    {k:42s} {v:9.1f} us per model   {nbytes / v / 1e3:7.0f} GB/s algorithmic")
+
+run("ResNet-50 weights", resnet50_shapes())
+run("MobileNet-like pointwise/depthwise stack", [(c, 1, 3, 3) for c in (32, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024)] +
+    [(co, ci, 1, 1) for ci, co in ((32, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 1024), (1024, 1024))])
+run("16 x Linear(4096,4096)", [(4096, 4096)] * 16, reps=50)
