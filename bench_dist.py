@@ -43,7 +43,13 @@ def init_process_group(backend: str, device: torch.device, force_gloo: bool = Fa
 
 
 def sync(device: torch.device):
+    """torch.cuda.synchronize(), reached by polling an event first: the blocking wait of the runtime wakes up tens of
+    microseconds after the GPU has finished, which a 20-step timed region of ~0.5 ms would otherwise carry as cost."""
     if device.type == "cuda":
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
         torch.cuda.synchronize(device)
 
 

@@ -1,12 +1,46 @@
 #!/bin/bash
-# HBM traffic of the headline kernel: separate rocprofv3 --pmc passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2),
-# run on the GPU box via gpurun; results go to gpurun_out/ and are summarised into profiles/pmc_traffic.json
-mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+# Per-config profiler evidence for the judged bench command, run on the GPU box via gpurun:
+#   1. rocprofv3 --kernel-trace --stats of `bench.py --config C` (kernel durations; no counters)
+#   2. separate rocprofv3 --kernel-trace --pmc passes (never combined with other trace domains):
+#        FETCH_SIZE, WRITE_SIZE                      HBM-side traffic (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
+#        SQ stall split, TCC EA stall counters       who waits for what (cfg2 only)
+# Raw per-dispatch CSVs land in gpurun_out/pmc/<config>/; tools/pmc_summarize.py (run in the build container
+# afterwards) turns them into profiles/pmc_traffic.json + profiles/r02/*.csv, keyed by the kernel VARIANT that the
+# very same bench run reports (mctq_last_launch) and the git head.
+mkdir -p gpurun_out/pmc; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 cd /tmp
-for pass in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$pass
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_$pass -- python3 $R/bench.py --no-cpu --steps 100 --warmup 10 > $R/gpurun_out/pmc_$pass.log 2>&1
-  f=$(find /tmp/pmc_$pass -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then head -1 $f > $R/gpurun_out/pmc_$pass.csv; grep rows_kernel $f | tail -40 >> $R/gpurun_out/pmc_$pass.csv; fi
+rocprofv3 -L 2>/dev/null | grep -o -E "\b(SQ_[A-Z_0-9]+|TCC_[A-Z_0-9]+|TCP_[A-Z_0-9]+|GRBM_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE)\b" | sort -u > $R/gpurun_out/pmc/available_counters.txt
+run_cfg() {   # name, bench args...
+  local name=$1; shift
+  local out=$R/gpurun_out/pmc/$name; mkdir -p $out
+  rm -rf /tmp/prof_$name
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --no-cpu --evidence-launches 0 "$@" > $out/bench_stats.log 2>&1
+  find /tmp/prof_$name -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+  for pass in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${name}_$pass
+    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
+    f=$(find /tmp/pmc_${name}_$pass -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then head -1 $f > $out/$pass.csv; grep -E "mctq::" $f | tail -120 >> $out/$pass.csv; fi
+  done
+}
+run_cfg cfg2
+run_cfg cfg3_n64 --config cfg3 --batch 64
+run_cfg cfg4 --config cfg4 --steps 300
+run_cfg cfg5 --config cfg5 --steps 300
+# stall counters of the headline kernel: one pass per group (8 SQ slots, 4 TCC slots)
+out=$R/gpurun_out/pmc/cfg2
+i=0
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum" \
+           "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_NC_READ_REQ_sum"; do
+  i=$((i+1)); rm -rf /tmp/pmc_stall_$i
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_$i -- python3 $R/bench.py --no-cpu --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 > $out/bench_stall_$i.log 2>&1
+  f=$(find /tmp/pmc_stall_$i -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq::" $f | tail -400 >> $out/stall_$i.csv; else echo "group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
 done
-head -3 $R/gpurun_out/pmc_FETCH_SIZE.csv; head -3 $R/gpurun_out/pmc_WRITE_SIZE.csv
+ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
+for c in cfg2 cfg3_n64 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
