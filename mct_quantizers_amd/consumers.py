@@ -35,6 +35,15 @@ def _activation_code_params(q):
     raise TypeError(f"{type(q).__name__} is not an affine per-tensor activation quantizer")
 
 
+def _check_consumer_operands(a_codes, w_scales, w_rowsum, bias):
+    """The kernels read w_scales / bias as float32 and w_rowsum as int32, all on a_codes' device."""
+    for name, t, dt in (("w_scales", w_scales, torch.float32), ("w_rowsum", w_rowsum, torch.int32), ("bias", bias, torch.float32)):
+        if t is None:
+            continue
+        if t.dtype != dt or t.device != a_codes.device or not t.is_contiguous():
+            raise TypeError(f"{name} must be a contiguous {dt} tensor on {a_codes.device}, got {t.dtype} on {t.device}")
+
+
 def qlinear_i8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes: torch.Tensor,
                w_scales: torch.Tensor, w_rowsum: torch.Tensor, bias: Optional[torch.Tensor],
                out_codes=None) -> torch.Tensor:
@@ -48,6 +57,7 @@ def qlinear_i8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_codes
     if a_codes.is_cuda:
         if K % 16 or K > _MAX_K:
             raise NotImplementedError(f"mctq_qlinear_i8 needs K % 16 == 0 and K <= {_MAX_K}, got K={K}")
+        _check_consumer_operands(a_codes, w_scales, w_rowsum, bias)
         lib = native.load()
         a_codes, w_codes = a_codes.contiguous(), w_codes.contiguous()
         code = native.CODE_U8 if a_codes.dtype == torch.uint8 else native.CODE_I8
@@ -98,6 +108,7 @@ def qlinear_w4a8(a_codes: torch.Tensor, a_zero_point: int, a_scale: float, w_cod
         raise RuntimeError(f"shape mismatch: activations have K={K}, packed weights K={w_codes4.shape[1] * 2}")
     if K % 16 or K > _MAX_K:
         raise NotImplementedError(f"mctq_qlinear_w4a8 needs K % 16 == 0 and K <= {_MAX_K}, got K={K}")
+    _check_consumer_operands(a_codes, w_scales, w_rowsum, bias)
     lib = native.load()
     a_codes, w_codes4 = a_codes.contiguous(), w_codes4.contiguous()
     code = native.CODE_U8 if a_codes.dtype == torch.uint8 else native.CODE_I8
@@ -138,6 +149,13 @@ class QuantizedLinear(nn.Module):
             raise NotImplementedError("per-channel weight scales must run along the output channels (axis 0)")
         if weights_quantizer.num_bits > 8 or activation_quantizer.num_bits > 8:
             raise NotImplementedError("codes wider than 8 bits")
+        # The kernels read the bias as float32 and return float32: a half-precision layer stays on the fake-quant
+        # path (its wrapper returns the layer's own type), it is never reinterpreted.
+        if linear.weight.dtype != torch.float32 or (linear.bias is not None and linear.bias.dtype != torch.float32):
+            raise TypeError(f"QuantizedLinear takes float32 layers, got weight {linear.weight.dtype}"
+                            + ("" if linear.bias is None else f" / bias {linear.bias.dtype}"))
+        if linear.bias is not None and linear.bias.device != linear.weight.device:
+            raise TypeError("weight and bias live on different devices")
         self.weight = linear.weight
         self.bias = linear.bias
         self.in_features, self.out_features = linear.in_features, linear.out_features
@@ -191,7 +209,12 @@ class QuantizedLinear(nn.Module):
             a_codes = x2
         else:
             a_codes = ops.fq_codes(x2, None, None, None, self._a_qmin, self._a_qmax, self._a_scale, self._a_zp)
-        bias = None if self.bias is None else self.bias.detach()
+        bias = None
+        if self.bias is not None:
+            bias = self.bias.detach()
+            if bias.dtype != torch.float32 or bias.device != a_codes.device or not bias.is_contiguous():
+                # (.to() after construction, e.g. model.half(): convert instead of letting the kernel misread it)
+                bias = bias.to(device=a_codes.device, dtype=torch.float32).contiguous()
         if self._w_codes4 is not None and a_codes.is_cuda and a_codes.shape[0] <= _W4_MAX_ROWS:
             y = qlinear_w4a8(a_codes, self._a_zp, self._a_scale, self._w_codes4, self._w_scales, self._w_rowsum, bias,
                              self.emit_codes_for)
@@ -251,6 +274,12 @@ def _consumer_for(wrapper, activation_quantizer):
     """The integer consumer that can stand in for ``wrapper`` fed by ``activation_quantizer``, or None."""
     layer = getattr(wrapper, "layer", None)
     if list(getattr(wrapper, "weights_quantizers", {})) != ["weight"]:
+        return None
+    weight = getattr(wrapper, "weight", None)
+    bias = getattr(layer, "bias", None)
+    if not isinstance(weight, torch.Tensor) or weight.dtype != torch.float32:
+        return None                     # half-precision layers: the integer consumer would change the output type
+    if isinstance(bias, torch.Tensor) and (bias.dtype != torch.float32 or bias.device != weight.device):
         return None
     try:
         if isinstance(layer, nn.Linear) and layer.in_features % 16 == 0 and layer.in_features <= _MAX_K:

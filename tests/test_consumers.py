@@ -442,3 +442,30 @@ def test_pointwise_convolution_consumer_cpu():
 @pytest.mark.gpu
 def test_pointwise_convolution_consumer_gpu():
     _check_pointwise("cuda")
+
+
+def test_half_precision_layers_are_left_unfused_and_never_misread():
+    """a half-precision wrapped Linear must not reach the integer consumer (it reads the bias as float32
+    and answers in float32)."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd import consumers
+    Q = mq.pytorch_quantizers
+    lin = torch.nn.Linear(32, 8).half()
+    wrapper = mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, [0.5] * 8, True, 0)})
+    holder = mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.0], [2.0]))
+    model = torch.nn.Sequential(holder, wrapper)
+    assert consumers.fuse_linear_consumers(model) == 0 and isinstance(model[1], mq.PytorchQuantizationWrapper)
+    with pytest.raises(TypeError):
+        consumers.QuantizedLinear(torch.nn.Linear(32, 8).half(), Q.WeightsSymmetricInferableQuantizer(8, [0.5] * 8, True, 0),
+                                  Q.ActivationUniformInferableQuantizer(8, [-2.0], [2.0]))
+    with pytest.raises(TypeError):
+        consumers._check_consumer_operands(torch.zeros(2, 16, dtype=torch.int8), torch.ones(8), torch.zeros(8, dtype=torch.int32),
+                                           torch.zeros(8, dtype=torch.float16))
+    # float32 layer whose bias was converted afterwards: converted back for the launch, same result
+    lin32 = torch.nn.Linear(32, 8)
+    ql = consumers.QuantizedLinear(lin32, Q.WeightsSymmetricInferableQuantizer(8, [0.5] * 8, True, 0),
+                                   Q.ActivationUniformInferableQuantizer(8, [-2.0], [2.0]))
+    x = torch.randn(3, 32)
+    want = ql(x)
+    ql.bias = torch.nn.Parameter(lin32.bias.detach().double())
+    assert torch.equal(ql(x), want)                    # float32 -> float64 -> float32 is the identity on the values
