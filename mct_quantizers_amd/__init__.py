@@ -22,4 +22,7 @@ def __getattr__(name):
     if name in ("compat", "sharded", "workloads", "consumers"):
         import importlib
         return importlib.import_module(f"mct_quantizers_amd.{name}")
+    if name == "batch_weight_quantization":          # all wrapped weights of a model in ONE launch per forward
+        from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+        return batch_weight_quantization
     raise AttributeError(f"module 'mct_quantizers_amd' has no attribute {name!r}")

@@ -448,3 +448,65 @@ def test_holder_fast_call_keeps_module_semantics(lib):
     pre.remove()
     b = mq.PytorchFLNActivationQuantizationHolder(Q.ActivationPOTInferableQuantizer(8, [2.0], True), quantization_bypass=True)
     assert b(x) is x
+
+
+def test_fuzz_float64_tensor_qparams_and_batched_against_aten_cpu(lib):
+    """Seeded fuzz over ranks, shapes, axes, permuted storage and ALL FOUR storage types (incl. float64), for the
+    per-channel quantizers, the per-tensor weights quantizers (tensor qparams) and the activation quantizers; every
+    dense case is also pushed through the batched launch and must give the same bits.  Reference: ATen's CPU
+    operators on the same tensor (what the reference package executes)."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "77")))
+    pending = []
+    for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "140"))):
+        rank = int(rng.integers(1, 5))
+        shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 64])) for _ in range(rank)]
+        if rng.random() < 0.3:
+            shape[int(rng.integers(0, rank))] = int(rng.choice([257, 1024, 1030, 4096, 8192]))
+        if int(np.prod(shape, dtype=np.int64)) > (1 << 24):
+            continue
+        axis = int(rng.integers(0, rank))
+        dt = [torch.float32, torch.float64, torch.float64, torch.float16, torch.bfloat16][int(rng.integers(0, 5))]
+        bits = int(rng.choice([2, 4, 8]))
+        x = torch.from_numpy(rng.standard_normal(shape) * 3).to(dt)
+        perm = list(rng.permutation(rank))
+        x = x.permute(perm).contiguous().permute(list(np.argsort(perm)))
+        C = x.shape[axis]
+        kind = int(rng.integers(0, 4))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == 0:
+                q = Q.WeightsSymmetricInferableQuantizer(bits, [float(v) for v in rng.uniform(0.2, 6.0, size=C)], True, axis)
+                ref = lambda t, q=q, axis=axis: torch.fake_quantize_per_channel_affine(   # noqa: E731
+                    t, q.scales.cpu(), q.zero_points.cpu(), axis, q.min_quantized_domain, q.max_quantized_domain)
+            elif kind == 1:
+                lo = [float(v) for v in rng.uniform(-4.0, -0.1, size=C)]
+                hi = [float(v) for v in rng.uniform(0.1, 5.0, size=C)]
+                q = Q.WeightsUniformInferableQuantizer(bits, lo, hi, True, axis)
+                ref = lambda t, q=q, axis=axis, bits=bits: torch.fake_quantize_per_channel_affine(   # noqa: E731
+                    t, q.scales.cpu(), q.zero_points.cpu(), axis, 0, 2 ** bits - 1)
+            elif kind == 2:
+                q = Q.WeightsUniformInferableQuantizer(bits, [float(rng.uniform(-3, -0.1))], [float(rng.uniform(0.1, 4))], False)
+                ref = lambda t, q=q, bits=bits: torch.fake_quantize_per_tensor_affine(   # noqa: E731  (tensor qparams)
+                    t, q.scales.cpu(), q.zero_points.cpu(), 0, 2 ** bits - 1)
+            else:
+                q = Q.ActivationSymmetricInferableQuantizer(bits, [float(rng.uniform(0.5, 5))], bool(rng.integers(0, 2)))
+                ref = lambda t, q=q: torch.fake_quantize_per_tensor_affine(   # noqa: E731
+                    t, q.scales, q.zero_points, q.min_quantized_domain, q.max_quantized_domain)
+        want = ref(x.clone())
+        xg = x.cuda()
+        got = q(xg)
+        info = (case, tuple(x.shape), x.stride(), axis, dt, kind)
+        view = torch.int64 if dt == torch.float64 else torch.int32
+        conv = (lambda t: t) if dt == torch.float64 else (lambda t: t.float())
+        assert got.dtype == want.dtype and got.shape == want.shape and got.stride() == xg.stride(), info
+        assert torch.equal(conv(got.cpu()).contiguous().view(view), conv(want).contiguous().view(view)), info
+        if kind < 3:
+            pending.append((q.batch_item(xg), got, info))
+        if len(pending) >= 9 or (pending and case % 37 == 36):
+            outs = ops.fq_batched([p[0] for p in pending])
+            for y, (_, single, inf) in zip(outs, pending):
+                assert y.dtype == single.dtype and y.stride() == single.stride() and torch.equal(y, single), ("batched", inf)
+            pending = []
