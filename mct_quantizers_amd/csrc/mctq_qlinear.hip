@@ -200,6 +200,170 @@ __global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product with the activation codes staged through per-wave LDS (ql_variant 18x, M <= 64 by default).
+// In the kernel above every block re-reads ALL of A through L2 as MFMA-fragment-shaped loads: each 16-byte-per-lane
+// instruction touches 16 rows x one 64-byte sector, and at M = 64 those 64 MiB of L2 traffic (256 blocks x 256 KiB)
+// cost more than the 16 MiB weight stream from HBM (13.1 us vs 6.4 us without them, profiles/r01).  Here a wave
+// copies its K block of A global -> LDS with global_load_lds_dwordx4: one instruction = 4 rows x 256 contiguous
+// bytes (full lines; the 16-byte chunks of a row are permuted by an XOR swizzle applied on the SOURCE address, so
+// the fragment reads below are bank-conflict free), then reads the fragments with ds_read_b128.  Bytes through L2
+// are the same; the requests are whole lines instead of half-used sectors.  A wave owns its LDS region: no block
+// barrier in the K loop, only vmcnt waits.  MT <= 2: two LDS buffers per wave (copy of block i+1 under the MFMAs of
+// block i); MT = 4: one buffer (8 waves x 16 KiB).  The reduction of the 8 waves' partial sums reuses the region.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void ql_lds_void_;
+typedef const __attribute__((address_space(1))) void ql_glb_void_;
+
+template <int kQlWaves, int MT, bool A_U8, bool W_NT>
+__global__ __launch_bounds__(kQlWaves * 64) void qlinear_i8_lds_kernel(
+    const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa, QlOut oq) {
+  constexpr int kQlThreads = kQlWaves * 64;
+  constexpr int NBUF = kQlWaves * 2 * MT * 4096 <= 128 * 1024 ? 2 : 1;      // double-buffer when it fits 128 KiB
+  constexpr int kSlots = MT * 256;                       // 16-byte slots of one A buffer: MT*16 rows x 16 chunks
+  constexpr int kRedSlots = kQlWaves * MT * 64;          // int4 slots of the reduction
+  constexpr int kLdsSlots = kQlWaves * NBUF * kSlots > kRedSlots ? kQlWaves * NBUF * kSlots : kRedSlots;
+  __shared__ i32x4 lds[kLdsSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int8_t* wrow = w + (int64_t)min(n0 + r, N - 1) * K;
+  const int64_t kblocks = (K + kQlKBlock - 1) / kQlKBlock;
+  const int64_t full_blocks = K / kQlKBlock;
+  const int en = min(n0 + (int)(threadIdx.x & 15), N - 1);
+  const int e_corr = za * w_rowsum[en];
+  const float e_scale = sa * w_scales[en];
+  const float e_bias = bias ? bias[en] : 0.0f;
+  i32x4* abuf = lds + wave * NBUF * kSlots;
+
+  for (int m0 = 0; m0 < M; m0 += 16 * MT) {
+    i32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = i32x4{0, 0, 0, 0};
+    // copy instruction j of a K block covers tile rows 4j .. 4j+3: this lane's source row and swizzled chunk
+    const int8_t* asrc[MT * 4];
+#pragma unroll
+    for (int j = 0; j < MT * 4; ++j) {
+      const int row = 4 * j + (lane >> 4);
+      asrc[j] = a + (int64_t)min(m0 + row, M - 1) * K + 16 * ((lane & 15) ^ (row & 15));
+    }
+    const int64_t rot = full_blocks ? (int64_t)blockIdx.x % full_blocks : 0;
+    auto kbyte = [&](int64_t i) {
+      int64_t kblk = wave + i * kQlWaves + rot;
+      if (kblk >= full_blocks) kblk -= full_blocks;
+      return kblk * kQlKBlock;
+    };
+    auto copy_a = [&](int64_t i, int buf) {
+      const int64_t k = kbyte(i);
+#pragma unroll
+      for (int j = 0; j < MT * 4; ++j)
+        __builtin_amdgcn_global_load_lds((ql_glb_void_*)(asrc[j] + k), (ql_lds_void_*)&abuf[buf * kSlots + j * 64], 16, 0, 0);
+    };
+    auto load_w = [&](int64_t i, i32x4* wf) { ql_load_row<W_NT, true>(wrow, kbyte(i) + 16 * g, K, wf); };
+    auto multiply = [&](const i32x4* wf, int buf) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          i32x4 av = abuf[buf * kSlots + (16 * t + r) * 16 + ((4 * p + g) ^ r)];
+          if constexpr (A_U8) av = av ^ (int)0x80808080;
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wf[p], acc[t], 0, 0, 0);
+        }
+      }
+    };
+    const int64_t n_i = full_blocks > wave ? (full_blocks - wave + kQlWaves - 1) / kQlWaves : 0;
+    i32x4 wf0[4], wf1[4];
+    if constexpr (NBUF == 2) {
+      if (n_i > 0) { copy_a(0, 0); load_w(0, wf0); }
+      for (int64_t i = 0; i < n_i; i += 2) {
+        if (i + 1 < n_i) {
+          copy_a(i + 1, 1); load_w(i + 1, wf1);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 4 + 4) : "memory");    // block i has landed, i+1 in flight
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        multiply(wf0, 0);
+        if (i + 1 < n_i) {
+          if (i + 2 < n_i) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // fragments of buffer 0 are in registers
+            copy_a(i + 2, 0); load_w(i + 2, wf0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 4 + 4) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          multiply(wf1, 1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    } else {
+      if (n_i > 0) load_w(0, wf0);
+      for (int64_t i = 0; i < n_i; ++i) {
+        copy_a(i, 0);
+        if (i + 1 < n_i) load_w(i + 1, (i & 1) ? wf0 : wf1);
+        if (i + 1 < n_i) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // A(i) and W(i) landed; W(i+1) may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        multiply((i & 1) ? wf1 : wf0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // before the next copy overwrites the buffer
+      }
+    }
+    if (full_blocks != kblocks && wave == kQlWaves - 1) {          // ragged end of K: guarded loads straight from global
+      const int64_t k = full_blocks * kQlKBlock + 16 * g;
+      i32x4 af[4];
+      ql_load_row<W_NT, false>(wrow, k, K, wf0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        ql_load_row<false, false>(a + (int64_t)min(m0 + 16 * t + r, M - 1) * K, k, K, af);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          i32x4 av = af[p];
+          if constexpr (A_U8) av = av ^ (int)0x80808080;
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wf0[p], acc[t], 0, 0, 0);
+        }
+      }
+    }
+
+    // partial sums of the waves meet in LDS (the A buffers are dead now)
+    __syncthreads();
+    int* red = reinterpret_cast<int*>(lds);                 // [wave][t][lane][4]
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      lds[(wave * MT + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int e = threadIdx.x; e < MT * 256; e += kQlThreads) {
+      const int t = e >> 8, rem = e & 255;
+      const int mi = rem >> 4, ni = rem & 15;
+      const int src_lane = (mi >> 2) * 16 + ni, src_reg = mi & 3;
+      int v = 0;
+#pragma unroll
+      for (int wv = 0; wv < kQlWaves; ++wv) v += red[((wv * MT + t) * 64 + src_lane) * 4 + src_reg];
+      const int m = m0 + 16 * t + mi, n = n0 + ni;
+      if (m < M && n < N) {
+        float out = (float)(v - e_corr) * e_scale;
+        if (bias) out = out + e_bias;
+        ql_store(y, (int64_t)m * N + n, out, oq);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int WAVES, int MT, bool A_U8>
+static int launch_qlinear_lds(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
+                              const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                              const QlOut& oq, hipStream_t stream) {
+  const dim3 grid((unsigned)((N + 15) / 16));
+  const bool one_pass = M <= 16 * MT;
+  if (one_pass)
+    hipLaunchKernelGGL((qlinear_i8_lds_kernel<WAVES, MT, A_U8, true>), grid, dim3(WAVES * 64), 0, stream,
+                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
+  else
+    hipLaunchKernelGGL((qlinear_i8_lds_kernel<WAVES, MT, A_U8, false>), grid, dim3(WAVES * 64), 0, stream,
+                       (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
+  return check_launch("mctq_qlinear_i8 (LDS-staged activations)");
+}
+
 template <int WAVES, int MT, bool A_U8, bool W4 = false>
 static int launch_qlinear(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
                           const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
@@ -380,6 +544,17 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     case 44: return MCTQ_QL(4, 4);
     default: break;
   }
+#define MCTQ_QLL(W_, MT_)                                                                                          \
+  (u8 ? launch_qlinear_lds<W_, MT_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s) \
+      : launch_qlinear_lds<W_, MT_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  switch (g_ql_variant) {                           // LDS-staged activations: 1<waves><row tiles>
+    case 181: return MCTQ_QLL(8, 1);
+    case 182: return MCTQ_QLL(8, 2);
+    case 184: return MCTQ_QLL(8, 4);
+    case 142: return MCTQ_QLL(4, 2);
+    case 144: return MCTQ_QLL(4, 4);
+    default: break;
+  }
 #define MCTQ_QG(BM_, BN_, BK_)                                                                                    \
   (u8 ? launch_glds<BM_, BN_, BK_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
@@ -393,11 +568,14 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   }
   const int64_t cus = cu_count();
   const auto blocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-  if (M <= 16) return MCTQ_QL(8, 1);
-  if (M <= 32) return MCTQ_QL(8, 2);
-  // up to 128 rows: weight streaming, unless there are enough 64 x 64 tiles to occupy half the chip -- then the
-  // tiled kernel's shared activation tile wins (64 x 11008 x 4096: 19.8 vs 34 us; 128 x 4096 x 4096: 18.1 vs 21.6)
-  if (M <= 128 && blocks(64, 64) * 2 < cus) return MCTQ_QL(8, 4);
+  // Few rows: stream the weights once, activation codes staged through per-wave LDS (full-line copies instead of
+  // fragment-shaped L2 reads; profiles/r02/qlinear_probe.log: 16 x 11008 x 4096 16.3 -> 14.8 us, 32 x 4096^2
+  // 8.8 -> 8.4, 64 x 4096^2 12.5 -> 10.0, 64 x 4096 x 11008 28.5 -> 20.5, 128 x 4096^2 18.2 -> 15.3).
+  if (M <= 16) return MCTQ_QLL(8, 1);
+  if (M <= 32) return MCTQ_QLL(8, 2);
+  // up to 128 rows: weight streaming, unless there are enough 64 x 64 tiles to occupy more than half the chip --
+  // then the tiled kernel's shared activation tile wins (64 x 11008 x 4096: 19.1 vs 25.5 us; 256 x 4096^2: 18.7 vs 26.6)
+  if (M <= 128 && blocks(64, 64) * 2 <= cus) return MCTQ_QLL(8, 4);
   {                                                  // tiled: the largest tile that still gives every CU two blocks
     if (blocks(128, 128) >= 2 * cus) return MCTQ_QG(128, 128, 128);
     if (blocks(64, 128) >= 2 * cus) return MCTQ_QG(64, 128, 128);
@@ -406,6 +584,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   }
 #undef MCTQ_QG
 #undef MCTQ_QL
+#undef MCTQ_QLL
 }
 
 extern "C" {

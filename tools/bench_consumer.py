@@ -10,7 +10,7 @@ from mct_quantizers_amd.hip import native
 
 HBM_PEAK_GBS, I8_PEAK_TOPS = 8000.0, 5000.0
 lib = native.load(); dev = torch.device("cuda"); S = lambda: torch.cuda.current_stream().cuda_stream
-for (M, N, K) in [(16, 4096, 4096), (64, 4096, 4096), (256, 4096, 4096), (2048, 4096, 4096), (4096, 4096, 11008)]:
+for (M, N, K) in [(16, 4096, 4096), (16, 11008, 4096), (32, 4096, 4096), (64, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (256, 4096, 4096), (2048, 4096, 4096), (4096, 4096, 11008)]:
     ring = max(2, int(np.ceil(400e6 / (N * K))))
     ws = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(ring)]
     a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)
@@ -18,7 +18,7 @@ for (M, N, K) in [(16, 4096, 4096), (64, 4096, 4096), (256, 4096, 4096), (2048, 
     y = torch.empty(M, N, device=dev)
     call = lambda i: lib.mctq_qlinear_i8(a.data_ptr(), native.CODE_U8, 114, 0.02, ws[i % ring].data_ptr(), sc.data_ptr(),
                                          rs.data_ptr(), bias.data_ptr(), y.data_ptr(), M, N, K, S())
-    for i in range(10): call(i)
+    for i in range(ring + 10): call(i)
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     steps = 200; e0.record()
     for i in range(steps): call(i)

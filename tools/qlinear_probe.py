@@ -28,7 +28,7 @@ def oracle(a, za, sa, w, ws, bias):
 
 rng = np.random.default_rng(1)
 bad = 0
-for variant in (0, 41, 42, 44, 81, 82, 84, 1212, 612, 66, 662, 12122):
+for variant in (0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 142, 144, 1212, 612, 66, 662, 12122):
     lib.mctq_set_tuning(b"ql_variant", variant)
     for (M, N, K) in [(129, 130, 144), (300, 257, 1040), (1, 16, 16), (5, 100, 256), (16, 33, 272), (33, 64, 4096), (64, 4096, 1024), (100, 48, 11008), (7, 1000, 4112)]:
         for u8 in (False, True):
@@ -50,16 +50,16 @@ print("exactness failures:", bad)
 
 # timings: cold weights (ring larger than the 256 MiB Infinity Cache)
 res = {}
-for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (32, 4096, 4096), (64, 11008, 4096), (128, 4096, 4096), (128, 11008, 4096), (256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (2048, 11008, 4096), (4096, 4096, 11008)]:
+for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (32, 4096, 4096), (16, 11008, 4096), (16, 4096, 11008), (64, 11008, 4096), (64, 4096, 11008), (128, 4096, 4096), (128, 11008, 4096), (256, 4096, 4096)]:
     ring = max(2, int(np.ceil(400e6 / (N * K))))
     ws_ = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(ring)]
     a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)
     sc = torch.rand(N, device=dev) * 0.01
     wsum = ws_[0].sum(1, dtype=torch.int32)
     bias = torch.randn(N, device=dev)
-    for variant in ((0, 81, 82, 84) if M <= 64 else (0, 1212, 612, 66, 662, 12122)):
+    for variant in ((0, 81, 82, 84, 181, 182, 184, 142, 144) if M <= 64 else ((0, 84, 184, 144, 1212, 612, 66, 662, 12122) if M <= 256 else (0, 1212, 612, 66, 662, 12122))):
         lib.mctq_set_tuning(b"ql_variant", variant)
-        for i in range(5):
+        for i in range(ring + 5):
             run(a, True, 114, 0.02, ws_[i % ring], sc, wsum, bias, M, N, K)
         torch.cuda.synchronize()
         iters = 50
