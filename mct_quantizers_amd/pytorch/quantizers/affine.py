@@ -210,22 +210,34 @@ class _WeightsAffineMixin:
         self.scales = self._to_working_device(self.scales)
         self.zero_points = self._to_working_device(self.zero_points)
         self.__dict__.pop("_plan_key", None)
+        if hasattr(self, "per_channel"):
+            self._refresh()                # now, not at the first call: that call may sit inside hipGraph capture
 
     def _launch_key(self):
         s, z = self.scales, self.zero_points
         return (s, z, s._version, z._version, self.per_channel, self.channel_axis, self.min_quantized_domain,
                 self.max_quantized_domain)
 
-    def _refresh(self):
-        """(Re)derive the launch state from the public attributes.  Reads two scalars back from the device: happens
-        at the first call and after a change of the public attributes only."""
+    def _refresh(self, host_scales=None, host_zps=None):
+        """(Re)derive the launch state from the public attributes.  Constructors pass the HOST copies of the
+        parameters they just computed; otherwise (public attributes replaced or edited in place, objects
+        un-pickled) the values are read back from the device -- a synchronising read that is not legal
+        inside hipGraph capture, so change quantizer attributes outside captured regions."""
         d = self.__dict__
         s, z = self.scales, self.zero_points
         d["_scales_flat"] = s.flatten().contiguous()
         d["_zps_flat"] = z.flatten().contiguous()
-        d["_zps_all_zero"] = not bool(torch.any(d["_zps_flat"] != 0).item())     # symmetric: skip the table
-        d["_scale0"] = float(d["_scales_flat"][0].item()) if d["_scales_flat"].numel() else 1.0
-        d["_zp0"] = int(d["_zps_flat"][0].item()) if d["_zps_flat"].numel() else 0
+        if host_scales is None or host_zps is None:
+            host_scales = d["_scales_flat"][:1].cpu()
+            zps_nonzero = bool(torch.any(d["_zps_flat"] != 0).item())
+            host_zp0 = int(d["_zps_flat"][0].item()) if d["_zps_flat"].numel() else 0
+        else:
+            host_scales, host_zps = host_scales.reshape(-1), host_zps.reshape(-1)
+            zps_nonzero = bool(torch.any(host_zps != 0))
+            host_zp0 = int(host_zps[0]) if host_zps.numel() else 0
+        d["_zps_all_zero"] = not zps_nonzero                                     # symmetric: skip the table
+        d["_scale0"] = float(host_scales[0]) if host_scales.numel() else 1.0
+        d["_zp0"] = host_zp0
         plan = None
         fast = ops._fast_mod() if d["_scales_flat"].is_cuda else None
         if fast is not None:
@@ -303,8 +315,11 @@ class WeightsSymmetricInferableQuantizer(_WeightsAffineMixin, BaseSymmetricInfer
         self.channel_axis = channel_axis
 
         dev = get_working_device()
-        self.scales = to_torch_tensor(self.scales).to(dev)
-        self.zero_points = torch.zeros(len(threshold), dtype=torch.int32).to(dev)
+        host_scales = torch.from_numpy(self.scales.astype(np.float32))
+        host_zps = torch.zeros(len(threshold), dtype=torch.int32)
+        self.scales = host_scales.to(dev)
+        self.zero_points = host_zps.to(dev)
+        self._refresh(host_scales, host_zps)
 
     _export_function = "WeightsSymmetricF"
 
@@ -364,6 +379,7 @@ class WeightsUniformInferableQuantizer(_WeightsAffineMixin, BaseUniformInferable
         dev = get_working_device()
         self.scales = scales.to(dev)
         self.zero_points = zero_points.to(dev)
+        self._refresh(scales, zero_points)
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached(inputs):

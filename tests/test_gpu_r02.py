@@ -510,3 +510,39 @@ def test_fuzz_float64_tensor_qparams_and_batched_against_aten_cpu(lib):
             for y, (_, single, inf) in zip(outs, pending):
                 assert y.dtype == single.dtype and y.stride() == single.stride() and torch.equal(y, single), ("batched", inf)
             pending = []
+
+
+def test_first_call_of_a_process_inside_graph_capture(lib, tmp_path):
+    """The per-tensor kernel is launched through hipModuleLaunchKernel with its hipFunction_t resolved on first use
+    (and the compiled binding is imported lazily): both must be legal when the very first quantizer call of a process
+    happens under hipGraph stream capture."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = f"""
+import sys, torch, logging
+sys.path.insert(0, {REPO!r})
+logging.getLogger("mct_quantizers_amd").setLevel(logging.ERROR)
+import mct_quantizers_amd as mq
+Q = mq.pytorch_quantizers
+x = torch.randn(2, 3, 32, 32, device="cuda")
+w = torch.randn(64, 4096, device="cuda")
+qa = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.01 * i for i in range(64)], True, 0)
+scale_t = torch.tensor([0.02], device="cuda")
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    ya = qa(x)
+    yw = qw(w)
+    from mct_quantizers_amd.hip import ops
+    yb = ops.fq_batched([qw.batch_item(w), (x, scale_t, None, None, 0, 255)])
+x.copy_(torch.randn_like(x)); w.copy_(torch.randn_like(w))
+g.replay(); torch.cuda.synchronize()
+assert torch.equal(ya, torch.fake_quantize_per_tensor_affine(x, qa.scale, qa.zero_point, 0, 255))
+assert torch.equal(yw, torch.fake_quantize_per_channel_affine(w, qw.scales, qw.zero_points, 0, -128, 127))
+assert torch.equal(yb[0], yw) and torch.equal(yb[1], torch.fake_quantize_per_tensor_affine(x, 0.02, 0, 0, 255))
+print("capture-ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "capture-ok" in r.stdout, r.stderr[-2000:]
