@@ -369,6 +369,76 @@ void plan_dealloc(PyObject* self) {
 
 PyTypeObject AffinePlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
+// ---- pre-packed arguments of the per-tensor LUT quantizer with a decision table (the activation LUT quantizer):
+//      plan = LutPlan(table, thr_div_f32, thr_div_f16, thr_div_bf16, thr_mul, mult, clip_min, clip_max, half_steps);
+//      plan(x) -> float32 tensor | NotImplemented.  The divisor depends on the tensor's type because the reference
+//      narrows the Python-float `threshold + eps` to it (activation_lut_pot_inferable_quantizer.py:86-91);
+//      half_steps != 0: a half-precision tensor also rounds the quotient and the scaled value to its own type.
+struct LutPlan {
+  PyObject_HEAD
+  vectorcallfunc vectorcall;
+  PyObject* table;
+  float thr_div[3];
+  float thr_mul, mult, cmin, cmax;
+  int half_steps;
+};
+
+PyObject* lutplan_vectorcall(PyObject* self, PyObject* const* args, size_t nargsf, PyObject* kwnames) {
+  LutPlan* p = (LutPlan*)self;
+  if (PyVectorcall_NARGS(nargsf) != 1 || (kwnames && PyTuple_GET_SIZE(kwnames))) {
+    PyErr_SetString(PyExc_TypeError, "LutPlan.__call__(x)");
+    return nullptr;
+  }
+  int dt;
+  const at::Tensor* xp = eligible(args[0], &dt);
+  if (!xp || dt == MCTQ_DT_F64) return not_implemented();
+  const at::Tensor& x = *xp;
+  const at::Tensor* tp = param_tensor(p->table, x, c10::ScalarType::Float, -1);
+  if (!tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();
+  at::Tensor y = like(x, c10::ScalarType::Float);
+  const c10::DeviceIndex idx = x.device().index();
+  DeviceScope scope(idx);
+  const int step = (p->half_steps && dt != MCTQ_DT_F32) ? dt : 0;
+  const int rc = mctq_lutt_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, step, p->thr_div[dt],
+                                      p->thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->size(0) - 1, p->mult, p->cmin,
+                                      p->cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  if (rc) return raise_rc(rc, "mctq_lutt_per_tensor");
+  return THPVariable_Wrap(std::move(y));
+}
+
+PyObject* lutplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
+  if (PyTuple_GET_SIZE(args) != 9) {
+    PyErr_SetString(PyExc_TypeError, "LutPlan(table, thr_div_f32, thr_div_f16, thr_div_bf16, thr_mul, mult, clip_min, clip_max, half_steps)");
+    return nullptr;
+  }
+  LutPlan* p = (LutPlan*)type->tp_alloc(type, 0);
+  if (!p) return nullptr;
+  p->vectorcall = lutplan_vectorcall;
+  p->table = nullptr;
+  double v[7];
+  for (int i = 0; i < 7; ++i)
+    if (!as_double(PyTuple_GET_ITEM(args, 1 + i), &v[i])) { Py_DECREF(p); return nullptr; }
+  int64_t hs;
+  if (!as_i64(PyTuple_GET_ITEM(args, 8), &hs)) { Py_DECREF(p); return nullptr; }
+  if (!THPVariable_Check(PyTuple_GET_ITEM(args, 0))) {
+    Py_DECREF(p);
+    PyErr_SetString(PyExc_TypeError, "LutPlan: table must be a tensor");
+    return nullptr;
+  }
+  p->table = PyTuple_GET_ITEM(args, 0); Py_INCREF(p->table);
+  p->thr_div[MCTQ_DT_F32] = (float)v[0]; p->thr_div[MCTQ_DT_F16] = (float)v[1]; p->thr_div[MCTQ_DT_BF16] = (float)v[2];
+  p->thr_mul = (float)v[3]; p->mult = (float)v[4]; p->cmin = (float)v[5]; p->cmax = (float)v[6];
+  p->half_steps = (int)hs;
+  return (PyObject*)p;
+}
+
+void lutplan_dealloc(PyObject* self) {
+  Py_XDECREF(((LutPlan*)self)->table);
+  Py_TYPE(self)->tp_free(self);
+}
+
+PyTypeObject LutPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
 PyObject* py_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(mctq_abi_version()); }
 
 PyMethodDef methods[] = {
@@ -395,9 +465,19 @@ PyMODINIT_FUNC PyInit__mctq_torch(void) {
   AffinePlanType.tp_call = PyVectorcall_Call;
   AffinePlanType.tp_vectorcall_offset = offsetof(AffinePlan, vectorcall);
   if (PyType_Ready(&AffinePlanType) < 0) return nullptr;
+  LutPlanType.tp_name = "_mctq_torch.LutPlan";
+  LutPlanType.tp_basicsize = sizeof(LutPlan);
+  LutPlanType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL;
+  LutPlanType.tp_new = lutplan_new;
+  LutPlanType.tp_dealloc = lutplan_dealloc;
+  LutPlanType.tp_call = PyVectorcall_Call;
+  LutPlanType.tp_vectorcall_offset = offsetof(LutPlan, vectorcall);
+  if (PyType_Ready(&LutPlanType) < 0) return nullptr;
   PyObject* m = PyModule_Create(&moduledef);
   if (!m) return nullptr;
   Py_INCREF(&AffinePlanType);
   if (PyModule_AddObject(m, "AffinePlan", (PyObject*)&AffinePlanType) < 0) { Py_DECREF(m); return nullptr; }
+  Py_INCREF(&LutPlanType);
+  if (PyModule_AddObject(m, "LutPlan", (PyObject*)&LutPlanType) < 0) { Py_DECREF(m); return nullptr; }
   return m;
 }
