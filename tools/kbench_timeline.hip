@@ -60,6 +60,32 @@ __global__ __launch_bounds__(T) void k_tile(const float* __restrict__ xs, float*
   }
 }
 
+// E: the same tile kernel, but the blocks of the FIRST residency round (blockIdx < first) delay their loads by
+// (blockIdx / per_slot) * delay sleeps of 64 clocks: the launch otherwise starts 2048 blocks in lockstep (all read,
+// then all write), and the timeline shows reads starving for ~2.5 us behind the first write burst.
+template <int T, int U>
+__global__ __launch_bounds__(T) void k_tile_stagger(const float* __restrict__ xs, float* __restrict__ ys,
+                                                    const float* __restrict__ scales, uint32_t tiles_per_row, uint32_t inner4,
+                                                    uint32_t first, uint32_t per_slot, uint32_t delay, uint32_t mod) {
+  if (blockIdx.x < first) {
+    uint32_t k = blockIdx.x / per_slot;
+    if (mod) k %= mod;
+    for (uint32_t i = 0; i < k * delay; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+  const uint32_t row = blockIdx.x / tiles_per_row;
+  const uint32_t tile = blockIdx.x - row * tiles_per_row;
+  const f4* x = reinterpret_cast<const f4*>(xs) + (int64_t)row * inner4;
+  f4* y = reinterpret_cast<f4*>(ys) + (int64_t)row * inner4;
+  const uint32_t col = tile * (T * U) + threadIdx.x;
+  f4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(x + col + u * T);
+  const float s = scales[row];
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int u = 0; u < U; ++u) __builtin_nontemporal_store(fq4(v[u], s, inv), y + col + u * T);
+}
+
 // C: phase separated.  grid = blocks resident at once; lane holds NV float4.  barrier counter is monotonic:
 // launch number `epoch` waits for epoch * gridDim.x arrivals.
 template <int T, int NV>
@@ -161,12 +187,12 @@ int main(int argc, char** argv) {
     for (int k = 0; k < K; ++k) {
       const uint64_t* s = hst.data() + (size_t)k * blocks * 3;
       uint64_t mn = ~0ull, mx = 0, mn_done = ~0ull;
-      std::vector<uint64_t> starts(blocks), ends(blocks);
+      std::vector<uint64_t> starts(blocks), ends(blocks), landed(blocks);
       for (uint32_t b = 0; b < blocks; ++b) {
         mn = std::min(mn, s[3 * b]); mx = std::max(mx, s[3 * b + 2]); mn_done = std::min(mn_done, s[3 * b + 1]);
-        starts[b] = s[3 * b]; ends[b] = s[3 * b + 2];
+        starts[b] = s[3 * b]; ends[b] = s[3 * b + 2]; landed[b] = s[3 * b + 1];
       }
-      std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+      std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end()); std::sort(landed.begin(), landed.end());
       span.push_back((mx - mn) * 0.01);
       first_done.push_back((mn_done - mn) * 0.01);
       if (k) bubble.push_back(((double)mn - (double)prev_end) * 0.01);
@@ -177,7 +203,13 @@ int main(int argc, char** argv) {
           const uint64_t lim = mn + (uint64_t)(t * 100.0);
           size_t a = std::upper_bound(starts.begin(), starts.end(), lim) - starts.begin();
           size_t c = std::upper_bound(ends.begin(), ends.end(), lim) - ends.begin();
-          printf("      t=%5.1f  entered %5zu  finished %5zu  resident %5zu\n", t, a, c, a - c);
+          size_t l = std::upper_bound(landed.begin(), landed.end(), lim) - landed.begin();
+          const uint64_t lim0 = mn + (uint64_t)((t - 0.5) * 100.0);
+          size_t l0 = std::upper_bound(landed.begin(), landed.end(), lim0) - landed.begin();
+          size_t c0 = std::upper_bound(ends.begin(), ends.end(), lim0) - ends.begin();
+          // 16 KiB read per block landed, 16 KiB written per block finished, per 0.5 us bin -> GB/s
+          printf("      t=%5.1f  entered %5zu  loads landed %5zu  finished %5zu  resident %5zu | this bin: read %5.0f GB/s  write(issued) %5.0f GB/s\n",
+                 t, a, l, c, a - c, (l - l0) * 16384.0 / 0.5e-6 / 1e9, (c - c0) * 16384.0 / 0.5e-6 / 1e9);
         }
         // block lifetime distribution
         std::vector<double> life(blocks);
@@ -224,6 +256,24 @@ int main(int argc, char** argv) {
     }
     run(k_tile<512, 2, false>, "T512 U2 (16 KiB in per block)", 512, 1, 0);
     run(k_tile<1024, 1, false>, "T1024 U1 (16 KiB in per block)", 1024, 1, 0);
+  }
+
+  // ---- E. staggered first residency round ----
+  printf("\n[E] first-round stagger: block b < first sleeps ((b / per_slot) %% mod) * delay * 64 clocks before its loads (cold ring)\n");
+  {
+    for (uint32_t first : {2048u, 1024u}) {
+      for (uint32_t per_slot : {256u, 32u, 8u}) {
+        for (uint32_t delay : {0u, 2u, 4u, 8u, 12u, 16u, 24u}) {
+          const uint32_t mod = per_slot == 256 ? 0 : 8;
+          float us = time_events([&](int i) {
+            hipLaunchKernelGGL((k_tile_stagger<256, 4>), dim3(ROWS), dim3(256), 0, st, x[i % RING], y[i % RING], scales, 1u, INNER4, first, per_slot, delay, mod);
+          }, iters);
+          if (!launched_ok("stagger")) return 1;
+          printf("    first %4u per_slot %3u delay %2u x64clk (max %.2f us)  %8.2f us  %6.0f GB/s\n", first, per_slot, delay,
+                 (mod ? 7 : (first / per_slot - 1)) * delay * 64 / 2100.0, us, 2.0 * bytes / us / 1e3);
+        }
+      }
+    }
   }
 
   // ---- C. phase-separated (all load -> grid barrier -> all store) ---------------------------------
