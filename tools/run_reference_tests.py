@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Drop-in check (build container only): run the REFERENCE's own PyTorch test-suite (/root/reference/tests/pytorch_tests,
+unmodified, read in place) with `mct_quantizers` resolving to THIS package (compat.install_reference_aliases).
+Nothing of the reference is copied: its test files are collected from where they lie.  The onnx_export_tests need
+onnxruntime-extensions / the metadata module (out of scope) and are skipped; test_pytorch_load_model's
+metadata cases likewise.  On a GPU box the same suite exercises the HIP kernels (the working device is 'cuda')."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF_TESTS = "/root/reference/tests"
+assert os.path.isdir(REF_TESTS), "the reference checkout is only present in the build container"
+
+import pytest  # noqa: E402
+from mct_quantizers_amd import compat  # noqa: E402
+
+compat.install_reference_aliases(force=False)
+import mct_quantizers  # noqa: E402,F401
+assert mct_quantizers.__name__ == "mct_quantizers_amd", "the real package is importable: refusing to shadow it"
+sys.path.insert(0, os.path.dirname(REF_TESTS))          # so that `tests.pytorch_tests...` imports resolve
+args = [os.path.join(REF_TESTS, "pytorch_tests"), "-q", "-p", "no:cacheprovider", "--rootdir", "/tmp",
+        "--ignore", os.path.join(REF_TESTS, "pytorch_tests", "onnx_export_tests")] + sys.argv[1:]
+sys.exit(pytest.main(args))
