@@ -439,6 +439,113 @@ void lutplan_dealloc(PyObject* self) {
 
 PyTypeObject LutPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
+// ---- a whole list of weights, pre-packed: plan = BatchPlan(items) with items = sequence of
+//      (x, y, scales, zero_points | None, axis | None, quant_min, quant_max); plan() re-quantizes every x into ITS y
+//      (caller-owned, persistent output buffers) with one mctq_fq_batched call and returns None -- no allocation, no
+//      per-tensor Python.  The device pointers are re-read from the tensors on every call (a Parameter whose storage
+//      was swapped is followed); shapes, strides and dtypes are fixed at construction and re-checked.
+struct BatchPlan {
+  PyObject_HEAD
+  vectorcallfunc vectorcall;
+  std::vector<mctq_fq_item>* items;
+  std::vector<PyObject*>* refs;          // 4 per item: x, y, scales, zero_points (or Py_None)
+  std::vector<int64_t>* numel;
+  c10::DeviceIndex device;
+};
+
+PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, PyObject* kwnames) {
+  BatchPlan* p = (BatchPlan*)self;
+  if (PyVectorcall_NARGS(nargsf) != 0 || (kwnames && PyTuple_GET_SIZE(kwnames))) {
+    PyErr_SetString(PyExc_TypeError, "BatchPlan.__call__()");
+    return nullptr;
+  }
+  if (torch::jit::tracer::isTracing()) return not_implemented();
+  const size_t n = p->items->size();
+  for (size_t i = 0; i < n; ++i) {
+    const at::Tensor& x = THPVariable_Unpack((*p->refs)[4 * i]);
+    const at::Tensor& y = THPVariable_Unpack((*p->refs)[4 * i + 1]);
+    if (x.numel() != (*p->numel)[i] || y.numel() != (*p->numel)[i] || !x.is_cuda() || !y.is_cuda() ||
+        x.device().index() != p->device || y.device().index() != p->device ||
+        !x.unsafeGetTensorImpl()->is_non_overlapping_and_dense() || x.strides() != y.strides() ||
+        dtype_code(x.scalar_type()) != (*p->items)[i].dtype || y.scalar_type() != x.scalar_type()) {
+      PyErr_Format(PyExc_RuntimeError, "BatchPlan: tensor %zu changed shape, layout, dtype or device since the plan was built", i);
+      return nullptr;
+    }
+    (*p->items)[i].x = x.const_data_ptr();
+    (*p->items)[i].y = y.mutable_data_ptr();
+  }
+  if (n > 0) {
+    DeviceScope scope(p->device);
+    const int rc = mctq_fq_batched(p->items->data(), (int32_t)n, (void*)c10::hip::getCurrentHIPStream(p->device).stream());
+    if (rc) return raise_rc(rc, "mctq_fq_batched");
+  }
+  Py_RETURN_NONE;
+}
+
+void batchplan_dealloc(PyObject* self) {
+  BatchPlan* p = (BatchPlan*)self;
+  if (p->refs) for (PyObject* o : *p->refs) Py_XDECREF(o);
+  delete p->items; delete p->refs; delete p->numel;
+  Py_TYPE(self)->tp_free(self);
+}
+
+PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
+  if (PyTuple_GET_SIZE(args) != 1) { PyErr_SetString(PyExc_TypeError, "BatchPlan(items)"); return nullptr; }
+  PyObject* seq = PySequence_Fast(PyTuple_GET_ITEM(args, 0), "BatchPlan expects a sequence of tuples");
+  if (!seq) return nullptr;
+  BatchPlan* p = (BatchPlan*)type->tp_alloc(type, 0);
+  if (!p) { Py_DECREF(seq); return nullptr; }
+  p->vectorcall = batchplan_vectorcall;
+  p->items = new std::vector<mctq_fq_item>(); p->refs = new std::vector<PyObject*>(); p->numel = new std::vector<int64_t>();
+  p->device = -1;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+  const char* err = nullptr;
+  for (Py_ssize_t i = 0; i < n && !err; ++i) {
+    PyObject* it = PySequence_Fast_GET_ITEM(seq, i);
+    if (!PyTuple_Check(it) || PyTuple_GET_SIZE(it) != 7) { err = "item: (x, y, scales, zero_points, axis, quant_min, quant_max)"; break; }
+    int dt, dty;
+    const at::Tensor* xp = eligible(PyTuple_GET_ITEM(it, 0), &dt);
+    const at::Tensor* yp = eligible(PyTuple_GET_ITEM(it, 1), &dty);
+    int64_t qmin, qmax, axis = -1;
+    PyObject* axis_o = PyTuple_GET_ITEM(it, 4);
+    if (!as_i64(PyTuple_GET_ITEM(it, 5), &qmin) || !as_i64(PyTuple_GET_ITEM(it, 6), &qmax) || (axis_o != Py_None && !as_i64(axis_o, &axis))) {
+      Py_DECREF(seq); Py_DECREF(p); return nullptr;
+    }
+    if (!xp || !yp) { err = "x and y must be plain dense HIP tensors of a supported dtype"; break; }
+    if (dt != dty || xp->sizes() != yp->sizes() || xp->strides() != yp->strides() || xp->device() != yp->device()) {
+      err = "y must have x's dtype, shape, strides and device"; break;
+    }
+    if (axis_o != Py_None && (axis < 0 || axis >= xp->dim())) { err = "axis out of range"; break; }
+    if (p->device < 0) p->device = xp->device().index();
+    if (xp->device().index() != p->device) { err = "all tensors of one plan must be on the same device"; break; }
+    const int64_t want = axis_o == Py_None ? 1 : xp->size(axis);
+    const at::Tensor* sp = param_tensor(PyTuple_GET_ITEM(it, 2), *xp, c10::ScalarType::Float, want);
+    const at::Tensor* zp = nullptr;
+    if (PyTuple_GET_ITEM(it, 3) != Py_None) {
+      zp = param_tensor(PyTuple_GET_ITEM(it, 3), *xp, c10::ScalarType::Int, want);
+      if (!zp) { err = "zero_points must be a contiguous int32 tensor on x's device with one entry per channel"; break; }
+    }
+    if (!sp) { err = "scales must be a contiguous float32 tensor on x's device with one entry per channel"; break; }
+    if (dt == MCTQ_DT_F64 && axis_o == Py_None && !zp) { err = "a float64 per-tensor item needs zero_points"; break; }
+    mctq_fq_item d;
+    d.x = xp->const_data_ptr(); d.y = yp->mutable_data_ptr();
+    if (axis_o == Py_None) { d.outer = 1; d.channels = 1; d.inner = xp->numel(); }
+    else channel_view(*xp, axis, &d.outer, &d.channels, &d.inner);
+    d.scales = sp->const_data_ptr<float>();
+    d.zero_points = zp ? zp->const_data_ptr<int32_t>() : nullptr;
+    d.quant_min = (int32_t)qmin; d.quant_max = (int32_t)qmax; d.dtype = dt;
+    d.flags = axis_o == Py_None ? MCTQ_FQ_ITEM_PER_TENSOR : 0;
+    p->items->push_back(d);
+    p->numel->push_back(xp->numel());
+    for (int k = 0; k < 4; ++k) { PyObject* o = PyTuple_GET_ITEM(it, k); Py_INCREF(o); p->refs->push_back(o); }
+  }
+  Py_DECREF(seq);
+  if (err) { Py_DECREF(p); PyErr_Format(PyExc_TypeError, "BatchPlan: %s", err); return nullptr; }
+  return (PyObject*)p;
+}
+
+PyTypeObject BatchPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
 PyObject* py_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(mctq_abi_version()); }
 
 PyMethodDef methods[] = {
@@ -473,11 +580,21 @@ PyMODINIT_FUNC PyInit__mctq_torch(void) {
   LutPlanType.tp_call = PyVectorcall_Call;
   LutPlanType.tp_vectorcall_offset = offsetof(LutPlan, vectorcall);
   if (PyType_Ready(&LutPlanType) < 0) return nullptr;
+  BatchPlanType.tp_name = "_mctq_torch.BatchPlan";
+  BatchPlanType.tp_basicsize = sizeof(BatchPlan);
+  BatchPlanType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL;
+  BatchPlanType.tp_new = batchplan_new;
+  BatchPlanType.tp_dealloc = batchplan_dealloc;
+  BatchPlanType.tp_call = PyVectorcall_Call;
+  BatchPlanType.tp_vectorcall_offset = offsetof(BatchPlan, vectorcall);
+  if (PyType_Ready(&BatchPlanType) < 0) return nullptr;
   PyObject* m = PyModule_Create(&moduledef);
   if (!m) return nullptr;
   Py_INCREF(&AffinePlanType);
   if (PyModule_AddObject(m, "AffinePlan", (PyObject*)&AffinePlanType) < 0) { Py_DECREF(m); return nullptr; }
   Py_INCREF(&LutPlanType);
   if (PyModule_AddObject(m, "LutPlan", (PyObject*)&LutPlanType) < 0) { Py_DECREF(m); return nullptr; }
+  Py_INCREF(&BatchPlanType);
+  if (PyModule_AddObject(m, "BatchPlan", (PyObject*)&BatchPlanType) < 0) { Py_DECREF(m); return nullptr; }
   return m;
 }

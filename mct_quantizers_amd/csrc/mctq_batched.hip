@@ -10,6 +10,8 @@
 // Per tile (256 * U lane-vectors of one tensor, never crossing tensors):
 //   - the tile lies inside ONE (outer, channel) row  -> the row's scale / zero point arrive by scalar loads and
 //     sit in SGPRs, exactly as rows_kernel does (Linear / conv weights quantized along axis 0, per-tensor items);
+//   - the tile covers exactly TWO rows (rows longer than a tile that do not divide into tiles): both rows' parameters in
+//     SGPRs, a lane-vector selects by its position relative to the boundary;
 //   - otherwise every lane-vector finds its row with one 32-bit division and reads its parameters from the
 //     (L1/L2-resident) tables; vectors that straddle rows go element by element.
 // Arithmetic: AffineOp (mctq_kernels.hpp), the same expression as every other affine entry point.
@@ -105,20 +107,65 @@ __global__ __launch_bounds__(kThreads) void batched_kernel(const BatchArgs a) {
     return;
   }
 
+  if (row_last == row0 + 1) {
+    // ---- exactly two rows (rows at least a tile long, e.g. 11008-wide Linear weights): both parameter sets in SGPRs,
+    //      a lane-vector picks by its position relative to the row boundary -- no per-lane division or table read ----
+    const uint32_t c0 = channels > 1 ? row0 % channels : 0;
+    const uint32_t c1 = channels > 1 ? (c0 + 1 == channels ? 0 : c0 + 1) : 0;
+    const AffineOp::Param p0 = op.fetch(c0), p1 = op.fetch(c1);
+    const uint32_t bnd = (row0 + 1) * inner - e0;             // elements of the tile that belong to row0 (0 < bnd < count)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t off = (u * kThreads + threadIdx.x) * N;
+      if (off >= count) continue;
+      if (off + N <= count) {
+        float in[N], out[N];
+        io::unpack(v[u], in);
+        if (off + N <= bnd || off >= bnd) {
+          const bool first = off + N <= bnd;
+          AffineOp::Param p;
+          p.s = first ? p0.s : p1.s; p.inv = first ? p0.inv : p1.inv; p.zf = first ? p0.zf : p1.zf;
+#pragma unroll
+          for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
+        } else {                                              // the vector straddles the boundary (inner % N != 0)
+#pragma unroll
+          for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], off + j < bnd ? p0 : p1, book);
+        }
+        io::template store<NT>(y + e0 + off, io::pack(out));
+      } else {
+        for (uint32_t j = 0; j < N && off + j < count; ++j)
+          y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], off + j < bnd ? p0 : p1, book);
+      }
+    }
+    return;
+  }
+
   // ---- several rows in the tile: per lane-vector parameters ----
+  // Pass 1 finds every vector's row and issues its table reads (U independent loads in flight, not U dependent
+  // round trips to L2); pass 2 inverts the scales and applies.
+  uint32_t cc[U], rr[U];
+  float sv[U];
+  int32_t zv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t off = (u * kThreads + threadIdx.x) * N;
+    const uint32_t pos = e0 + (off < count ? off : 0);
+    const uint32_t row = pos / inner;
+    rr[u] = pos - row * inner;
+    cc[u] = channels > 1 ? row % channels : 0;
+    sv[u] = op.scales[cc[u]];
+    zv[u] = op.zps ? op.zps[cc[u]] : 0;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
     if (off >= count) continue;
-    const uint32_t pos = e0 + off;
-    uint32_t row = pos / inner;
-    uint32_t rem = pos - row * inner;
-    uint32_t c = channels > 1 ? row % channels : 0;
+    uint32_t rem = rr[u], c = cc[u];
     if (off + N <= count) {
       float in[N], out[N];
       io::unpack(v[u], in);
       if (rem + N <= inner) {                               // the vector lies in one row
-        const AffineOp::Param p = op.fetch(c);
+        const AffineOp::Param p = AffineOp::make(sv[u], zv[u]);
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
       } else {

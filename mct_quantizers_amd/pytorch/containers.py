@@ -139,7 +139,15 @@ class PytorchQuantizationWrapper(nn.Module):
     def forward(self, *args: List[Any], **kwargs: Dict[str, Any]) -> Union[torch.Tensor, List[torch.Tensor]]:
         if self.is_weights_quantization:
             # tensors a batched launch has already prepared for THIS forward (pytorch/batching.py); used once
-            ready = self.__dict__.pop("_prequantized", None)
+            d = self.__dict__
+            ready = d.pop("_prequantized", None)
+            if ready is None:
+                # reuse_buffers mode: (generation cell, {name: persistent tensor}); valid once per generation, i.e.
+                # only for the forward whose pre-hook has just re-quantized into those tensors
+                plan = d.get("_prequantized_plan")
+                if plan is not None and plan[0][0] != d.get("_prequantized_seen"):
+                    d["_prequantized_seen"] = plan[0][0]
+                    ready = plan[1]
             fresh = {}
             for name, weight, quantizer in self._weights_vars:
                 if ready is not None and name in ready:

@@ -546,3 +546,51 @@ print("capture-ok")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "capture-ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_batched_weight_quantization_with_persistent_buffers(lib):
+    """reuse_buffers=True: pre-packed BatchPlan + persistent outputs.  Same values as per-layer quantization on every
+    forward, in-place weight updates followed, sub-module calls past the hook fall back to the quantizer, refresh()
+    picks up changed quantizer parameters, remove() restores the reference behaviour."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(5)
+
+    def build():
+        torch.manual_seed(5)
+        mods = []
+        for fin, fout in ((64, 96), (96, 4096), (4096, 48)):
+            lin = torch.nn.Linear(fin, fout)
+            thr = [float(v) + 1e-3 for v in lin.weight.detach().abs().amax(dim=1)]
+            mods += [mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0),
+                                                         "bias": Q.WeightsUniformInferableQuantizer(8, [-0.5], [0.5], False)}),
+                     mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0]))]
+        return torch.nn.Sequential(*mods).cuda()
+
+    ref, model = build(), build()
+    x = torch.randn(7, 64, device="cuda")
+    handle = batch_weight_quantization(model, reuse_buffers=True)
+    y1 = model(x)
+    assert handle._plan is not None and torch.equal(y1, ref(x))
+    w_obj = model[0].layer.weight
+    for _ in range(3):
+        with torch.no_grad():
+            for m, r in zip(model, ref):
+                if isinstance(m, mq.PytorchQuantizationWrapper):
+                    m.weight.mul_(0.9); r.weight.mul_(0.9)           # in-place update: pointers unchanged, values new
+        assert torch.equal(model(x), ref(x))
+        assert model[0].layer.weight is w_obj                        # the persistent tensor, rewritten in place
+    # a wrapper called directly (past the model's pre-hook) must not serve the previous generation's tensor
+    with torch.no_grad():
+        model[0].weight.mul_(0.5); ref[0].weight.mul_(0.5)
+    assert torch.equal(model[0](x), ref[0](x))
+    assert torch.equal(model(x), ref(x))
+    # changed quantizer parameters: refresh()
+    q, qr = model[2].weights_quantizers["weight"], ref[2].weights_quantizers["weight"]
+    q.scales = q.scales * 2.0; qr.scales = qr.scales * 2.0
+    handle.refresh()
+    assert torch.equal(model(x), ref(x))
+    handle.remove()
+    assert torch.equal(model(x), ref(x)) and model[0].layer.weight is not w_obj
+    assert all("_prequantized_plan" not in m.__dict__ for m in model)

@@ -51,6 +51,9 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
     m6 = build(layers, d, False)
     batch_weight_quantization(m6)
     batched, y6 = timeit(m6, x)
+    m7 = build(layers, d, False)
+    batch_weight_quantization(m7, reuse_buffers=True)
+    planned, y7 = timeit(m7, x)
     # integer consumers: every (activation holder, wrapped Linear) pair runs on the codes (mctq_qlinear_i8)
     from mct_quantizers_amd import consumers
     m4 = build(layers, d, False)
@@ -67,8 +70,35 @@ for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
     # build()'s order is wrapper, holder, wrapper, ...: every QuantizedLinear but the last feeds the next one
     chained, y5 = timeit(m5, x)
     print(f"{layers} x Linear({d},{d}) batch {batch}: this package {ours:7.3f} ms/forward, ATen fake-quant ops {aten:7.3f} ms/forward "
-          f"(x{aten/ours:.2f}), weights batched into one launch {batched:7.3f} ms, with versioned weight reuse {reuse:7.3f} ms; "
-          f"outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(y1, y6)}; "
+          f"(x{aten/ours:.2f}), weights batched into one launch {batched:7.3f} ms (pre-packed plan + persistent outputs {planned:7.3f} ms), with versioned weight reuse {reuse:7.3f} ms; "
+          f"outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(y1, y6) and torch.equal(y1, y7)}; "
           f"{nf} layer pairs on integer codes {fused:7.3f} ms (x{aten/fused:.2f} vs ATen path, max rel diff after the first pair {err:.1e}); "
           f"chained (codes passed between layers) {chained:7.3f} ms (x{aten/chained:.2f}), equal to unchained={torch.equal(y4, y5)}",
           flush=True)
+
+
+# A convolutional stack (ResNet-ish bottlenecks at 14x14, batch 1): many small weights, so the per-layer quantizer calls are
+# launch-bound -- the case batching is for.
+def conv_stack(aten):
+    torch.manual_seed(1)
+    mods = []
+    cin = 256
+    for i in range(12):
+        for cout, k in ((64, 1), (64, 3), (256, 1)):
+            conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False).cuda()
+            thr = [float(v) + 1e-6 for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+            wq = Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)
+            aq = Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0])
+            mods.append(mq.PytorchQuantizationWrapper(conv, {"weight": AtenWeights(wq) if aten else wq}))
+            mods.append(mq.PytorchActivationQuantizationHolder(AtenAct(aq) if aten else aq))
+            cin = cout
+    return torch.nn.Sequential(*mods)
+
+x = torch.randn(1, 256, 14, 14, device="cuda")
+ours, y1 = timeit(conv_stack(False), x, 50)
+aten, y2 = timeit(conv_stack(True), x, 50)
+mb = conv_stack(False); batch_weight_quantization(mb); batched, y3 = timeit(mb, x, 50)
+mp = conv_stack(False); batch_weight_quantization(mp, reuse_buffers=True); planned, y4 = timeit(mp, x, 50)
+print(f"36 wrapped convolutions (1x1 / 3x3, 64-256 channels) + holders, batch 1 at 14x14: this package {ours:7.3f} ms/forward, "
+      f"ATen fake-quant ops {aten:7.3f} ms (x{aten/ours:.2f}), weights batched {batched:7.3f} ms, pre-packed plan {planned:7.3f} ms "
+      f"(x{aten/planned:.2f}); outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(y1, y4)}", flush=True)
