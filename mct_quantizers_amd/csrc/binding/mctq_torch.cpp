@@ -29,6 +29,7 @@
 #include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/Exceptions.h>
 #include <torch/csrc/autograd/python_variable.h>
 #include <torch/csrc/jit/frontend/tracer.h>
 #include <torch/csrc/utils/python_arg_parser.h>
@@ -120,10 +121,19 @@ inline bool as_i64(PyObject* o, int64_t* v) {
 
 // ---- per-tensor affine ---------------------------------------------------------------------------------
 PyObject* launch_fq_per_tensor(PyObject* xo, float scale, int32_t zp, int32_t qmin, int32_t qmax) {
+  HANDLE_TH_ERRORS
   int dt;
   const at::Tensor* xp = eligible(xo, &dt);
   if (!xp) return not_implemented();
   const at::Tensor& x = *xp;
+  if (qmin > qmax) {                      // ATen's checks and messages (fake_quantize_per_tensor_affine), in its order
+    PyErr_SetString(PyExc_RuntimeError, "`quant_min` should be less than or         equal to `quant_max`.");
+    return nullptr;
+  }
+  if (zp < qmin || zp > qmax) {
+    PyErr_SetString(PyExc_RuntimeError, "`zero_point` must be between `quant_min` and `quant_max`.");
+    return nullptr;
+  }
   at::Tensor y = like(x, x.scalar_type());
   const c10::DeviceIndex idx = x.device().index();
   DeviceScope scope(idx);
@@ -131,6 +141,7 @@ PyObject* launch_fq_per_tensor(PyObject* xo, float scale, int32_t zp, int32_t qm
                                     (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_fq_per_tensor");
   return THPVariable_Wrap(std::move(y));
+  END_HANDLE_TH_ERRORS
 }
 
 // fq_per_tensor(x, scale, zero_point, quant_min, quant_max)
@@ -143,6 +154,7 @@ PyObject* py_fq_per_tensor(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
 
 // ---- per-channel affine --------------------------------------------------------------------------------
 PyObject* launch_fq_per_channel(PyObject* xo, PyObject* scales_o, PyObject* zps_o, int64_t axis, int32_t qmin, int32_t qmax) {
+  HANDLE_TH_ERRORS
   int dt;
   const at::Tensor* xp = eligible(xo, &dt);
   if (!xp) return not_implemented();
@@ -165,6 +177,7 @@ PyObject* launch_fq_per_channel(PyObject* xo, PyObject* scales_o, PyObject* zps_
                                      (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_fq_per_channel");
   return THPVariable_Wrap(std::move(y));
+  END_HANDLE_TH_ERRORS
 }
 
 // fq_per_channel(x, scales, zero_points | None, axis, quant_min, quant_max)
@@ -179,6 +192,7 @@ PyObject* py_fq_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs) 
 // fq_per_tensor_tqp(x, scale_tensor, zero_point_tensor, quant_min, quant_max): the tensor-qparams overload
 // (weights_symmetric_inferable_quantizer.py:147-151 passes 1-element tensors); no device->host read.
 PyObject* py_fq_per_tensor_tqp(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  HANDLE_TH_ERRORS
   if (nargs != 5) { PyErr_SetString(PyExc_TypeError, "fq_per_tensor_tqp(x, scale, zero_point, quant_min, quant_max)"); return nullptr; }
   int64_t qmin, qmax;
   if (!as_i64(args[3], &qmin) || !as_i64(args[4], &qmax)) return nullptr;
@@ -197,11 +211,13 @@ PyObject* py_fq_per_tensor_tqp(PyObject*, PyObject* const* args, Py_ssize_t narg
                                         (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_fq_per_tensor_tqp");
   return THPVariable_Wrap(std::move(y));
+  END_HANDLE_TH_ERRORS
 }
 
 // ---- LUT, decision table ---------------------------------------------------------------------------------
 // lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, clip_min, clip_max) -> float32 tensor
 PyObject* py_lutt_per_tensor(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  HANDLE_TH_ERRORS
   if (nargs != 8) { PyErr_SetString(PyExc_TypeError, "lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, clip_min, clip_max)"); return nullptr; }
   int64_t step_round; double thr_div, thr_mul, mult, cmin, cmax;
   if (!as_i64(args[2], &step_round) || !as_double(args[3], &thr_div) || !as_double(args[4], &thr_mul) ||
@@ -220,10 +236,12 @@ PyObject* py_lutt_per_tensor(PyObject*, PyObject* const* args, Py_ssize_t nargs)
                                       (float)mult, (float)cmin, (float)cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_lutt_per_tensor");
   return THPVariable_Wrap(std::move(y));
+  END_HANDLE_TH_ERRORS
 }
 
 // lutt_per_channel(x, thresholds, eps, table, axis, mult, clip_min, clip_max) -> float32 tensor
 PyObject* py_lutt_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  HANDLE_TH_ERRORS
   if (nargs != 8) { PyErr_SetString(PyExc_TypeError, "lutt_per_channel(x, thresholds, eps, table, axis, mult, clip_min, clip_max)"); return nullptr; }
   int64_t axis; double eps, mult, cmin, cmax;
   if (!as_double(args[2], &eps) || !as_i64(args[4], &axis) || !as_double(args[5], &mult) || !as_double(args[6], &cmin) ||
@@ -247,6 +265,7 @@ PyObject* py_lutt_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs
                                        (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_lutt_per_channel");
   return THPVariable_Wrap(std::move(y));
+  END_HANDLE_TH_ERRORS
 }
 
 // ---- a list of weights in ONE launch ------------------------------------------------------------------
@@ -254,6 +273,7 @@ PyObject* py_lutt_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs
 // axis None = per tensor (scales / zero_points are 1-element device tensors).  Returns a list of new tensors,
 // or NotImplemented if any item is not eligible (the caller then quantizes them one by one).
 PyObject* py_fq_batched(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+  HANDLE_TH_ERRORS
   if (nargs != 1) { PyErr_SetString(PyExc_TypeError, "fq_batched(items)"); return nullptr; }
   PyObject* seq = PySequence_Fast(args[0], "fq_batched expects a sequence of tuples");
   if (!seq) return nullptr;
@@ -310,6 +330,7 @@ PyObject* py_fq_batched(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
   if (!list) return nullptr;
   for (Py_ssize_t i = 0; i < n; ++i) PyList_SET_ITEM(list, i, THPVariable_Wrap(std::move(outs[(size_t)i])));
   return list;
+  END_HANDLE_TH_ERRORS
 }
 
 // ---- pre-packed launch arguments: plan = AffinePlan(scale, zp, qmin, qmax) / AffinePlan(scales, zps|None, axis, qmin, qmax);
@@ -384,6 +405,7 @@ struct LutPlan {
 };
 
 PyObject* lutplan_vectorcall(PyObject* self, PyObject* const* args, size_t nargsf, PyObject* kwnames) {
+  HANDLE_TH_ERRORS
   LutPlan* p = (LutPlan*)self;
   if (PyVectorcall_NARGS(nargsf) != 1 || (kwnames && PyTuple_GET_SIZE(kwnames))) {
     PyErr_SetString(PyExc_TypeError, "LutPlan.__call__(x)");
@@ -404,6 +426,7 @@ PyObject* lutplan_vectorcall(PyObject* self, PyObject* const* args, size_t nargs
                                       p->cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_lutt_per_tensor");
   return THPVariable_Wrap(std::move(y));
+  END_HANDLE_TH_ERRORS
 }
 
 PyObject* lutplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
@@ -454,6 +477,7 @@ struct BatchPlan {
 };
 
 PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, PyObject* kwnames) {
+  HANDLE_TH_ERRORS
   BatchPlan* p = (BatchPlan*)self;
   if (PyVectorcall_NARGS(nargsf) != 0 || (kwnames && PyTuple_GET_SIZE(kwnames))) {
     PyErr_SetString(PyExc_TypeError, "BatchPlan.__call__()");
@@ -480,6 +504,7 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
     if (rc) return raise_rc(rc, "mctq_fq_batched");
   }
   Py_RETURN_NONE;
+  END_HANDLE_TH_ERRORS
 }
 
 void batchplan_dealloc(PyObject* self) {
@@ -490,6 +515,7 @@ void batchplan_dealloc(PyObject* self) {
 }
 
 PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
+  HANDLE_TH_ERRORS
   if (PyTuple_GET_SIZE(args) != 1) { PyErr_SetString(PyExc_TypeError, "BatchPlan(items)"); return nullptr; }
   PyObject* seq = PySequence_Fast(PyTuple_GET_ITEM(args, 0), "BatchPlan expects a sequence of tuples");
   if (!seq) return nullptr;
@@ -542,6 +568,7 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   Py_DECREF(seq);
   if (err) { Py_DECREF(p); PyErr_Format(PyExc_TypeError, "BatchPlan: %s", err); return nullptr; }
   return (PyObject*)p;
+  END_HANDLE_TH_ERRORS
 }
 
 PyTypeObject BatchPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};

@@ -164,6 +164,10 @@ def _hip_fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
     dt = _DTYPES.get(x.dtype)
     if dt is None:
         _dtype_code(x, "fq_per_tensor")
+    if not qmin <= zero_point <= qmax:                  # ATen's checks and messages
+        if qmin > qmax:
+            raise RuntimeError("`quant_min` should be less than or         equal to `quant_max`.")
+        raise RuntimeError("`zero_point` must be between `quant_min` and `quant_max`.")
     lib = native.load()
     if not x.is_contiguous():
         x = _dense_input(x)

@@ -594,3 +594,18 @@ def test_batched_weight_quantization_with_persistent_buffers(lib):
     handle.remove()
     assert torch.equal(model(x), ref(x)) and model[0].layer.weight is not w_obj
     assert all("_prequantized_plan" not in m.__dict__ for m in model)
+
+
+def test_per_tensor_argument_errors_match_aten(lib):
+    """ATen validates the host-known per-tensor qparams before launching; same exception type and message here,
+    through both bindings."""
+    from mct_quantizers_amd.hip import native, ops
+    x = torch.randn(16, device="cuda")
+    for args in ((0.1, 300, 0, 255), (0.1, -1, 0, 255), (0.1, 0, 5, 3)):
+        with pytest.raises(RuntimeError) as want:
+            torch.fake_quantize_per_tensor_affine(x, *args)
+        msg = str(want.value).splitlines()[0]
+        for f in (ops.fq_per_tensor, ops._hip_fq_per_tensor, native.fast().fq_per_tensor):
+            with pytest.raises(RuntimeError) as got:
+                f(x, *args)
+            assert str(got.value).splitlines()[0] == msg, (args, f)
