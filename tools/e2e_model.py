@@ -99,6 +99,32 @@ ours, y1 = timeit(conv_stack(False), x, 50)
 aten, y2 = timeit(conv_stack(True), x, 50)
 mb = conv_stack(False); batch_weight_quantization(mb); batched, y3 = timeit(mb, x, 50)
 mp = conv_stack(False); batch_weight_quantization(mp, reuse_buffers=True); planned, y4 = timeit(mp, x, 50)
+# the same forward replayed from one hipGraph (every kernel of the package is capture-legal): host cost gone
+def graphed_ms(model):
+    xs_ = x.clone()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(3): model(xs_)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        yg = model(xs_)
+    for _ in range(5): g.replay()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(50): g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / 50 * 1e3, yg
+g1, yg1 = graphed_ms(conv_stack(False))
+mgb = conv_stack(False); batch_weight_quantization(mgb, reuse_buffers=True)
+g2, yg2 = graphed_ms(mgb)
+print(f"  ... replayed from one hipGraph: this package {g1:7.3f} ms/forward, with the weights batched into one launch {g2:7.3f} ms; "
+      f"equal={torch.equal(yg1, y1) and torch.equal(yg2, y1)}", flush=True)
+try:
+    g3, yg3 = graphed_ms(conv_stack(True))
+    print(f"  ... ATen fake-quant ops under the same capture: {g3:7.3f} ms", flush=True)
+except Exception as e:  # noqa: BLE001
+    print(f"  ... ATen's fake_quantize_per_channel_affine cannot be captured (its zero-point range check reads the device): {str(e).splitlines()[0]}", flush=True)
+    torch.cuda.synchronize()
 print(f"36 wrapped convolutions (1x1 / 3x3, 64-256 channels) + holders, batch 1 at 14x14: this package {ours:7.3f} ms/forward, "
       f"ATen fake-quant ops {aten:7.3f} ms (x{aten/ours:.2f}), weights batched {batched:7.3f} ms, pre-packed plan {planned:7.3f} ms "
       f"(x{aten/planned:.2f}); outputs equal={torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(y1, y4)}", flush=True)
