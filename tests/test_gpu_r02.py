@@ -103,6 +103,8 @@ def test_float64_raw_abi_against_oracle_all_layouts(lib):
 def test_compiled_and_ctypes_bindings_agree_with_the_oracle(lib):
     from mct_quantizers_amd.hip import native, ops
     from oracle import mctq_oracle as O
+    if os.environ.get("MCTQ_BINDING") == "ctypes":
+        pytest.skip("MCTQ_BINDING=ctypes: the compiled binding is switched off for this run")
     fast = native.fast()
     assert fast is not None, "the compiled binding must load on the GPU box (python -m mct_quantizers_amd.hip.build)"
     rng = np.random.default_rng(11)
@@ -572,6 +574,9 @@ def test_batched_weight_quantization_with_persistent_buffers(lib):
     x = torch.randn(7, 64, device="cuda")
     handle = batch_weight_quantization(model, reuse_buffers=True)
     y1 = model(x)
+    if os.environ.get("MCTQ_BINDING") == "ctypes":
+        assert handle._plan is None and torch.equal(y1, ref(x))       # no BatchPlan without the compiled binding:
+        pytest.skip("MCTQ_BINDING=ctypes: per-forward batching stands in (checked), the plan itself needs the binding")
     assert handle._plan is not None and torch.equal(y1, ref(x))
     w_obj = model[0].layer.weight
     for _ in range(3):
@@ -605,7 +610,8 @@ def test_per_tensor_argument_errors_match_aten(lib):
         with pytest.raises(RuntimeError) as want:
             torch.fake_quantize_per_tensor_affine(x, *args)
         msg = str(want.value).splitlines()[0]
-        for f in (ops.fq_per_tensor, ops._hip_fq_per_tensor, native.fast().fq_per_tensor):
+        fns = [ops.fq_per_tensor, ops._hip_fq_per_tensor] + ([native.fast().fq_per_tensor] if native.fast() is not None else [])
+        for f in fns:
             with pytest.raises(RuntimeError) as got:
                 f(x, *args)
             assert str(got.value).splitlines()[0] == msg, (args, f)
