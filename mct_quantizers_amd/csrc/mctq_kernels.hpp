@@ -826,8 +826,8 @@ __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __res
     if (VEC && off + V <= count) {
       float in[V], out[V];
       io::unpack(v[u], in);
-      if (same_row) {                                        // uniform: one parameter set per lane-vector
-        run<false, (int)V>(op, in, out, Op::get(tab, li, stride), book);
+      if (same_row || lrem + V <= inner) {                  // the lane-vector lies inside one row (always, when rows
+        run<false, (int)V>(op, in, out, Op::get(tab, li, stride), book);   // are whole vectors): one parameter set
       } else
 #pragma unroll
       for (uint32_t j = 0; j < V; ++j) {
@@ -928,7 +928,10 @@ inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st,
         default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;    \
       }                                                                                     \
     } else {                                                                                \
-      constexpr int U = 4; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__);                         \
+      switch (U_) {       /* 16-bit storage: 8 elements per lane-vector, so rows are half as many vectors */ \
+        case 1: case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break; \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;   \
+      }                                                                                     \
     }                                                                                       \
   } while (0)
 
@@ -1074,7 +1077,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         const int64_t waste = tiles * per - innerv;
         if (best_waste < 0 || waste <= best_waste) { best_waste = waste; best_u = u; }
       }
-      if (!(std::is_same<TI, float>::value && std::is_same<TO, float>::value)) best_u = 4;
+      if (!(std::is_same<TI, float>::value && std::is_same<TO, float>::value) && best_u < 2) best_u = 2;   // built: U = 2, 4
       const int64_t per = (int64_t)kThreads * best_u;
       const int64_t tiles = (innerv + per - 1) / per;
       if (rows * tiles <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
