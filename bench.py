@@ -181,6 +181,7 @@ def main():
             for st in streams:
                 torch.cuda.current_stream().wait_stream(st)
         ev1.record()
+        return ev1                                 # the region's closing synchronize polls this event first
 
     wall = bench_dist.timed_region(run_all, 1, device, dist)
     dev_ms = ev0.elapsed_time(ev1)            # events on the stream the kernels were launched on

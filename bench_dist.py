@@ -42,12 +42,16 @@ def init_process_group(backend: str, device: torch.device, force_gloo: bool = Fa
     return dist, control
 
 
-def sync(device: torch.device):
+def sync(device: torch.device, spin_on=None):
     """torch.cuda.synchronize(), reached by polling an event first: the blocking wait of the runtime wakes up tens of
-    microseconds after the GPU has finished, which a 20-step timed region of ~0.5 ms would otherwise carry as cost."""
+    microseconds after the GPU has finished, which a 20-step timed region of ~0.5 ms would otherwise carry as cost.
+    ``spin_on``: an event the caller has already recorded behind its last launch (saves one more marker packet,
+    ~15 us on an idle stream, tools/sync_probe.py)."""
     if device.type == "cuda":
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = spin_on
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record()
         while not ev.query():
             pass
         torch.cuda.synchronize(device)
@@ -59,9 +63,10 @@ def timed_region(step: Callable[[int], None], steps: int, device: torch.device, 
         dist.barrier()
     sync(device)
     t0 = time.perf_counter()
+    last = None
     for i in range(steps):
-        step(i)
-    sync(device)
+        last = step(i)
+    sync(device, last if device.type == "cuda" and isinstance(last, torch.cuda.Event) else None)
     if dist is not None:
         dist.barrier()
     return time.perf_counter() - t0
