@@ -615,3 +615,58 @@ def test_per_tensor_argument_errors_match_aten(lib):
             with pytest.raises(RuntimeError) as got:
                 f(x, *args)
             assert str(got.value).splitlines()[0] == msg, (args, f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_every_16_bit_input_value_affine_and_lut(lib, dtype):
+    """ALL 65 536 bit patterns of a float16 / bfloat16 tensor (finite ones inside the parity domain, plus NaN / inf
+    handling checked separately) through the per-tensor and per-channel affine kernels against ATen's CPU operators,
+    and through the LUT quantizers (decision table AND literal scan, weights and activation flavours) against the
+    oracle."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native, ops
+    from oracle import mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    name = str(dtype).replace("torch.", "")
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(dtype)
+    finite = torch.isfinite(x.float())
+    # affine: parity domain |x / s| < 2^31 -> keep every finite value whose quotient is in range for the scale used
+    for scale, zp, qmin, qmax in ((0.0371, 17, 0, 255), (2.0 ** -7, 0, -128, 127), (3.0, -2, -8, 7)):
+        ok = finite & ((x.float().abs() / scale) < 2.0 ** 31)
+        xs = x[ok]
+        want = torch.fake_quantize_per_tensor_affine(xs, scale, zp, qmin, qmax)
+        got = ops.fq_per_tensor(xs.cuda(), scale, zp, qmin, qmax)
+        assert got.dtype == dtype and torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (name, scale)
+        # per channel: the same values laid out as 3 channels with different scales
+        xc = xs[: (xs.numel() // 24) * 24].reshape(3, -1)
+        sc = torch.tensor([scale, scale * 1.7, scale * 0.31], dtype=torch.float32)
+        zc = torch.tensor([zp, qmin, qmax], dtype=torch.int32)
+        okc = (xc.float().abs() / sc[:, None]) < 2.0 ** 31
+        xc = torch.where(okc, xc, torch.zeros_like(xc))
+        want = torch.fake_quantize_per_channel_affine(xc, sc, zc, 0, qmin, qmax)
+        got = ops.fq_per_channel(xc.cuda(), sc.cuda(), zc.cuda(), 0, qmin, qmax)
+        assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (name, scale, "per channel")
+    # saturation outside the domain: +inf -> qmax, -inf / NaN -> qmin (documented divergence from the CPU's UB)
+    special = torch.tensor([float("inf"), float("-inf"), float("nan")]).to(dtype).cuda()
+    y = ops.fq_per_tensor(special, 0.5, 0, -8, 7).float().cpu()
+    assert y.tolist() == [3.5, -4.0, -4.0]
+    # LUT: every finite value; decision table and literal scan; activation (Python-float threshold, per-step rounding
+    # in the tensor's type) and weights (float32 tensor threshold, promoted chain)
+    lut = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+    xf = x[finite]
+    xw = xf.float().numpy()
+    code = native.DT_F16 if dtype == torch.float16 else native.DT_BF16
+    lut_d = torch.tensor(lut, device="cuda")
+    for thr in (2.0, 0.5):
+        qa = Q.ActivationLutPOTInferableQuantizer(4, lut, [thr], True)
+        want = O.lut_quantize(xw, lut, thr, True, 8, 1e-8, step_dtype=name)
+        got = qa(xf.cuda())
+        assert got.dtype == torch.float32 and bits_equal(got.cpu().numpy(), want), (name, thr, "table", first_mismatch(got.cpu().numpy(), want, xw))
+        div = float(torch.tensor([thr + 1e-8], dtype=torch.float64).to(dtype).item())
+        got = ops._hip_lut_per_tensor(xf.cuda(), lut_d, div, thr, 128.0, -128.0, 127.0, None, code)
+        assert bits_equal(got.cpu().numpy(), want), (name, thr, "scan", first_mismatch(got.cpu().numpy(), want, xw))
+        qw = Q.WeightsLUTSymmetricInferableQuantizer(4, lut, [thr], False)
+        want = O.lut_quantize(xw, lut, np.float32([thr]), True, 8, 1e-8)
+        got = qw(xf.cuda())
+        assert bits_equal(got.cpu().numpy(), want), (name, thr, "weights", first_mismatch(got.cpu().numpy(), want, xw))
