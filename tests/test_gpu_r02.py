@@ -670,3 +670,40 @@ def test_every_16_bit_input_value_affine_and_lut(lib, dtype):
         want = O.lut_quantize(xw, lut, np.float32([thr]), True, 8, 1e-8)
         got = qw(xf.cuda())
         assert bits_equal(got.cpu().numpy(), want), (name, thr, "weights", first_mismatch(got.cpu().numpy(), want, xw))
+
+
+def test_float64_large_random_and_tie_inputs_against_aten_cpu(lib):
+    """2^22 doubles per case -- random mantissas over 40 binades, exact ties of the double product and their one-ulp
+    neighbours -- through the float64 kernels against ATen's CPU operators (per tensor with float and with tensor
+    qparams, per channel along both axes)."""
+    from mct_quantizers_amd.hip import ops
+    rng = np.random.default_rng(97)
+    n = 1 << 22
+    for scale, zp, qmin, qmax in ((0.0371, 17, 0, 255), (2.0 ** -7, 0, -128, 127), (1.0 / 3.0, -3, -8, 7)):
+        sf = np.float32(scale)
+        inv = np.float64(np.float32(1.0) / sf)
+        x = rng.standard_normal(n) * np.exp2(rng.integers(-20, 20, size=n))
+        k = rng.integers(qmin - 4, qmax + 5, size=n // 4).astype(np.float64) - zp + 0.5
+        ties = k / inv
+        x[: n // 4] = np.where(rng.random(n // 4) < 0.34, ties, np.where(rng.random(n // 4) < 0.5, np.nextafter(ties, np.inf), np.nextafter(ties, -np.inf)))
+        x = x[np.abs(x * inv) < 2.0 ** 31]
+        xt = torch.from_numpy(x)
+        want = torch.fake_quantize_per_tensor_affine(xt, float(sf), zp, qmin, qmax)
+        got = ops.fq_per_tensor(xt.cuda(), float(sf), zp, qmin, qmax)
+        assert got.dtype == torch.float64 and torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), scale
+        st, zt = torch.tensor([sf]), torch.tensor([zp], dtype=torch.int32)
+        want = torch.fake_quantize_per_tensor_affine(xt, st, zt, qmin, qmax)
+        got = ops.fq_per_tensor_tqp(xt.cuda(), st.cuda(), zt.cuda(), qmin, qmax)
+        assert torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), (scale, "tensor qparams")
+        m = (x.size // 96) * 96
+        for shape, axis in (((3, m // 3), 0), ((m // 32, 32), 1)):
+            xc = xt[:m].reshape(shape)
+            C = shape[axis]
+            sc = torch.from_numpy((sf * rng.uniform(0.5, 2.0, size=C)).astype(np.float32))
+            zc = torch.from_numpy(rng.integers(qmin, qmax + 1, size=C).astype(np.int32))
+            bs = [1, 1]; bs[axis] = -1
+            okc = (xc.abs() * (1.0 / sc.double()).reshape(bs)) < 2.0 ** 31
+            xc = torch.where(okc, xc, torch.zeros_like(xc))
+            want = torch.fake_quantize_per_channel_affine(xc, sc, zc, axis, qmin, qmax)
+            got = ops.fq_per_channel(xc.cuda(), sc.cuda(), zc.cuda(), axis, qmin, qmax)
+            assert torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), (scale, shape, axis)
