@@ -772,6 +772,16 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __r
 // (channel-last layouts: inner == 1, C small) the whole table is staged instead and indexed
 // modulo C.
 // ------------------------------------------------------------------------------------------
+// n / d for n < 2^24 (exactly representable in float32) and a wave-uniform d with r = 1.0f / d: the float quotient
+// is off by at most one, two integer corrections make it exact -- 7 VALU ops instead of the ~25 of a 32-bit
+// unsigned division.  The window kernel's positions are offsets inside one tile (+ one row).
+__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t d, float r) {
+  uint32_t q = (uint32_t)((float)n * r);
+  q -= (q * d > n) ? 1u : 0u;
+  q += ((q + 1u) * d <= n) ? 1u : 0u;
+  return q;
+}
+
 template <class Op, class TI, class TO, int U, bool VEC, int NT, typename IdxT>
 __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT n,
                                                           uint32_t inner, uint32_t channels,
@@ -814,15 +824,21 @@ __global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __res
   }
   __syncthreads();
 
+  // positions inside the tile are small: exact division through one float multiply when they fit 24 bits (uniform)
+  const bool small = (uint64_t)rem0 + TILE < (1u << 24) && (uint64_t)c0 + nrows < (1u << 24);
+  const float r_inner = 1.0f / (float)inner, r_channels = 1.0f / (float)channels;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * V;
     if (off >= count) continue;
     const uint32_t pos = rem0 + off;
-    uint32_t lrow = pos / inner;
+    uint32_t lrow = small ? div_small(pos, inner, r_inner) : pos / inner;
     uint32_t lrem = pos - lrow * inner;
     uint32_t li = lrow;
-    if (whole) li = (c0 + lrow) % channels;
+    if (whole) {
+      const uint32_t cc = c0 + lrow;
+      li = small ? cc - div_small(cc, channels, r_channels) * channels : cc % channels;
+    }
     if (VEC && off + V <= count) {
       float in[V], out[V];
       io::unpack(v[u], in);
