@@ -22,6 +22,9 @@ def __getattr__(name):
     if name in ("compat", "sharded", "workloads", "consumers"):
         import importlib
         return importlib.import_module(f"mct_quantizers_amd.{name}")
+    if name == "capture_forward":                    # the whole forward replayed from one hipGraph
+        from mct_quantizers_amd.pytorch.graphs import capture_forward
+        return capture_forward
     if name == "batch_weight_quantization":          # all wrapped weights of a model in ONE launch per forward
         from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
         return batch_weight_quantization

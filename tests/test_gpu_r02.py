@@ -707,3 +707,40 @@ def test_float64_large_random_and_tie_inputs_against_aten_cpu(lib):
             want = torch.fake_quantize_per_channel_affine(xc, sc, zc, axis, qmin, qmax)
             got = ops.fq_per_channel(xc.cuda(), sc.cuda(), zc.cuda(), axis, qmin, qmax)
             assert torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), (scale, shape, axis)
+
+
+def test_capture_forward_replays_the_model_and_follows_weight_updates(lib):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+
+    def build():
+        torch.manual_seed(9)
+        mods = []
+        cin = 16
+        for cout, k in ((32, 3), (32, 1), (16, 3)):
+            conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2)
+            thr = [float(v) + 1e-6 for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+            mods += [mq.PytorchQuantizationWrapper(conv, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)}),
+                     mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0]))]
+            cin = cout
+        mods.append(mq.PytorchActivationQuantizationHolder(Q.ActivationLutPOTInferableQuantizer(
+            2, [-100.0, 0.0, 60.0, 127.0], [4.0], True)))
+        return torch.nn.Sequential(*mods).cuda()
+
+    ref, model = build(), build()
+    x = torch.randn(2, 16, 12, 12, device="cuda")
+    for batch_weights in (True, False):
+        cap = mq.capture_forward(model, x, batch_weights=batch_weights)
+        with torch.no_grad():
+            assert torch.equal(cap(x), ref(x))
+            x2 = torch.randn_like(x)
+            assert torch.equal(cap(x2), ref(x2))
+            for m, r in zip(model, ref):                             # in-place weight update: seen by the next replay
+                if isinstance(m, mq.PytorchQuantizationWrapper):
+                    m.weight.mul_(0.8); r.weight.mul_(0.8)
+            assert torch.equal(cap(x2), ref(x2))
+        with pytest.raises(ValueError):
+            cap(torch.randn(3, 16, 12, 12, device="cuda"))
+        cap.release()
+        with torch.no_grad():
+            assert torch.equal(model(x), ref(x))
