@@ -565,17 +565,25 @@ _lib_def.define("lut_per_tensor(Tensor x, Tensor lut, float thr_div, float thr_m
 _lib_def.define("lut_per_channel(Tensor x, Tensor lut, Tensor thresholds, float eps, int axis, float mult, "
                 "float clip_min, float clip_max) -> Tensor")
 
-# decision tables for codebooks that reach the ops without their quantizer (fx graphs): built once per codebook
+# decision tables for codebooks that reach the ops without their quantizer (fx graphs): built once per codebook TENSOR
+# OBJECT (weak reference + version counter: an address can be reused by another tensor, an object cannot)
 _op_tables = {}
 
 
 def _op_table(lut, mult, cmin, cmax):
-    key = (lut.data_ptr(), lut._version, lut.numel(), str(lut.device), mult, cmin, cmax)
-    if key not in _op_tables:
-        if len(_op_tables) > 256:
-            _op_tables.clear()
-        _op_tables[key] = make_lut_table(lut.detach().cpu().numpy(), mult, cmin, cmax, lut.device)
-    return _op_tables[key]
+    import weakref
+    key = (id(lut), mult, cmin, cmax)
+    hit = _op_tables.get(key)
+    if hit is not None and hit[0]() is lut and hit[1] == lut._version:
+        return hit[2]
+    if len(_op_tables) > 256:
+        _op_tables.clear()
+    table = make_lut_table(lut.detach().cpu().numpy(), mult, cmin, cmax, lut.device)
+    try:
+        _op_tables[key] = (weakref.ref(lut), lut._version, table)
+    except TypeError:                                   # not weak-referenceable: do not cache
+        pass
+    return table
 
 
 def _op_hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round=0):
