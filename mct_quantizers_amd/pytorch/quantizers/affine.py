@@ -103,7 +103,7 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
     #    the private launch state (host copies of scalars, decision tables) is rebuilt on load.
     def __getstate__(self):
         state = dict(self.__dict__)
-        for k in ("_plan", "_plan_key"):            # handles of the compiled binding: rebuilt on first use
+        for k in ("_plan", "_plan_key", "_versioned_key", "_versioned_pending"):   # binding handles, weak references
             state.pop(k, None)
         return state
 
@@ -125,10 +125,17 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
         if self.enable_reuse and not self.quantizer_first_run:
             return True
         if inputs is not None and self.__dict__.get("_versioned_reuse") and isinstance(inputs, torch.Tensor):
+            # the tensor OBJECT (weak reference: a freed tensor's address can be handed to another one), its version
+            # counter and its storage address (``.data`` of a Parameter can be re-pointed without a version bump)
+            import weakref
             key = (inputs.data_ptr(), inputs._version, tuple(inputs.shape), inputs.stride(), inputs.dtype,
                    inputs.device)
-            hit = key == self.__dict__.get("_versioned_key") and self.resue_outputs is not None
-            self.__dict__["_versioned_pending"] = key
+            old = self.__dict__.get("_versioned_key")
+            hit = (old is not None and old[1] == key and old[0]() is inputs and self.resue_outputs is not None)
+            try:
+                self.__dict__["_versioned_pending"] = (weakref.ref(inputs), key)
+            except TypeError:
+                self.__dict__["_versioned_pending"] = None
             return hit
         return False
 

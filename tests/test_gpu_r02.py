@@ -744,3 +744,21 @@ def test_capture_forward_replays_the_model_and_follows_weight_updates(lib):
         cap.release()
         with torch.no_grad():
             assert torch.equal(model(x), ref(x))
+
+
+def test_versioned_reuse_is_not_fooled_by_a_recycled_address(lib):
+    """The caching allocator hands a freed block to the next tensor of that size: same address, same shape, same
+    version counter, different values.  The cache must key on the tensor OBJECT."""
+    import mct_quantizers_amd as mq
+    q = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0, 3.0, 4.0], True, 0)
+    q.enable_versioned_reuse()
+    a = torch.randn(4, 1024, device="cuda")
+    ptr = a.data_ptr()
+    ya = q(a)
+    assert q(a) is ya
+    del a
+    b = torch.randn(4, 1024, device="cuda")
+    if b.data_ptr() != ptr:
+        pytest.skip("the allocator did not recycle the block")
+    yb = q(b)
+    assert yb is not ya and torch.equal(yb, torch.fake_quantize_per_channel_affine(b, q.scales, q.zero_points, 0, -128, 127))
