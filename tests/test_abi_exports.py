@@ -96,3 +96,40 @@ def test_table_builder_under_address_and_ub_sanitizers(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "table builder ok" in out.stdout
+
+
+def test_compiled_binding_builds_loads_and_declines_cpu_tensors():
+    """The CPython binding of the hot entry points (csrc/binding/mctq_torch.cpp): builds with g++ here, loads without a
+    GPU, exports every callable the Python side uses, reports the library's ABI version, and answers NotImplemented
+    (never a wrong result, never a crash) for anything that is not a plain eager HIP tensor."""
+    import importlib.util
+    import torch
+    from mct_quantizers_amd.hip import build, native
+    build.build()
+    path = build.build_binding()
+    assert os.path.exists(path)
+    native.load()
+    spec = importlib.util.spec_from_file_location(native.FAST_NAME, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.abi_version() == native.ABI_VERSION
+    for name in ("fq_per_tensor", "fq_per_channel", "fq_per_tensor_tqp", "lutt_per_tensor", "lutt_per_channel", "fq_batched",
+                 "AffinePlan", "LutPlan", "BatchPlan"):
+        assert callable(getattr(mod, name)), name
+    x = torch.randn(4, 8)
+    s, z = torch.ones(4), torch.zeros(4, dtype=torch.int32)
+    assert mod.fq_per_tensor(x, 0.1, 0, -8, 7) is NotImplemented
+    assert mod.fq_per_channel(x, s, z, 0, -8, 7) is NotImplemented
+    assert mod.fq_per_tensor_tqp(x, s[:1], z[:1], -8, 7) is NotImplemented
+    assert mod.fq_batched([(x, s, None, 0, -8, 7)]) is NotImplemented
+    assert mod.fq_batched([]) == []
+    assert mod.AffinePlan(0.1, 0, -8, 7)(x) is NotImplemented
+    assert mod.AffinePlan(s, None, 0, -8, 7)(x) is NotImplemented
+    assert mod.LutPlan(torch.zeros(5, 2), 1.0, 1.0, 1.0, 1.0, 128.0, -128.0, 127.0, 1)(x) is NotImplemented
+    assert mod.fq_per_tensor("not a tensor", 0.1, 0, -8, 7) is NotImplemented
+    with pytest.raises(TypeError):
+        mod.fq_per_tensor(x, 0.1, 0, -8)                      # wrong arity
+    with pytest.raises(TypeError):
+        mod.BatchPlan([(x, x, s, None, 0, -8, 7)])            # a plan needs HIP tensors
+    with pytest.raises(TypeError):
+        mod.AffinePlan(0.1, 0)
