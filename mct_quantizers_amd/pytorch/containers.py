@@ -125,19 +125,29 @@ class PytorchQuantizationWrapper(nn.Module):
             self._weights_vars.append((name, weight_var, quantizer))
 
     def set_quantize_weights(self, quantized_weights: dict):
-        """Install freshly quantized weights where the wrapped op will read them."""
+        """Install freshly quantized weights where the wrapped op will read them.
+
+        ``_set_weights_vars`` left every target as a PLAIN attribute (the layer's parameter was deleted and a tensor
+        put in its place), for which ``nn.Module.__setattr__`` ends in ``object.__setattr__`` after ~3 us of
+        parameter / buffer / module bookkeeping per weight per forward; writing the instance dictionary is the same
+        assignment.  Anything else (the attribute is not a plain one any more) goes through ``setattr``."""
         for key in self.weights_quantizers:
             value = quantized_weights.get(key)
             if self.is_str_attr:
-                setattr(self.layer, key, value)
+                owner, name = self.layer, key
             else:
-                setattr(self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{key}', value)
+                owner, name = self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{key}'
+            d = getattr(owner, "__dict__", None)
+            if d is not None and name in d and isinstance(value, torch.Tensor) and not isinstance(value, nn.Parameter):
+                d[name] = value
+            else:
+                setattr(owner, name, value)
 
     def get_weights_vars(self) -> List[Tuple[str, Any, BaseInferableQuantizer]]:
         return self._weights_vars
 
     def forward(self, *args: List[Any], **kwargs: Dict[str, Any]) -> Union[torch.Tensor, List[torch.Tensor]]:
-        if self.is_weights_quantization:
+        if self._weights_vars:
             # tensors a batched launch has already prepared for THIS forward (pytorch/batching.py); used once
             d = self.__dict__
             ready = d.pop("_prequantized", None)
@@ -164,10 +174,12 @@ class PytorchQuantizationWrapper(nn.Module):
             for pos in sorted(w[0] for w in self._weights_vars):
                 args.insert(pos, getattr(self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{pos}'))
 
-        call_kwargs = {**self.op_call_kwargs, **kwargs}
-        if self.is_inputs_as_list:
-            return self.layer(args, *self.op_call_args, **call_kwargs)
-        return self.layer(*args, *self.op_call_args, **call_kwargs)
+        if self.op_call_kwargs or self.op_call_args or kwargs or self.is_inputs_as_list:
+            call_kwargs = {**self.op_call_kwargs, **kwargs}
+            if self.is_inputs_as_list:
+                return self.layer(args, *self.op_call_args, **call_kwargs)
+            return self.layer(*args, *self.op_call_args, **call_kwargs)
+        return self.layer(*args)
 
     def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
         return {name: quantizer(w) for name, w, quantizer in self.get_weights_vars()}
