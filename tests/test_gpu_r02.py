@@ -103,8 +103,8 @@ def test_float64_raw_abi_against_oracle_all_layouts(lib):
 def test_compiled_and_ctypes_bindings_agree_with_the_oracle(lib):
     from mct_quantizers_amd.hip import native, ops
     from oracle import mctq_oracle as O
-    if os.environ.get("MCTQ_BINDING") == "ctypes":
-        pytest.skip("MCTQ_BINDING=ctypes: the compiled binding is switched off for this run")
+    if os.environ.get("MCTQ_BINDING") == "ctypes" or native.TRACE:
+        pytest.skip("the compiled binding is switched off for this run (MCTQ_BINDING=ctypes / MCTQ_ROCTX=1)")
     fast = native.fast()
     assert fast is not None, "the compiled binding must load on the GPU box (python -m mct_quantizers_amd.hip.build)"
     rng = np.random.default_rng(11)
@@ -574,9 +574,10 @@ def test_batched_weight_quantization_with_persistent_buffers(lib):
     x = torch.randn(7, 64, device="cuda")
     handle = batch_weight_quantization(model, reuse_buffers=True)
     y1 = model(x)
-    if os.environ.get("MCTQ_BINDING") == "ctypes":
+    from mct_quantizers_amd.hip import native
+    if native.fast() is None:                                         # MCTQ_BINDING=ctypes or MCTQ_ROCTX=1
         assert handle._plan is None and torch.equal(y1, ref(x))       # no BatchPlan without the compiled binding:
-        pytest.skip("MCTQ_BINDING=ctypes: per-forward batching stands in (checked), the plan itself needs the binding")
+        pytest.skip("compiled binding switched off: per-forward batching stands in (checked), the plan itself needs it")
     assert handle._plan is not None and torch.equal(y1, ref(x))
     w_obj = model[0].layer.weight
     for _ in range(3):
