@@ -272,6 +272,37 @@ int mctq_lutt_per_channel(const void* x, float* y,
                           void* stream);
 
 /*
+ * Threshold-list ("steps") form of the LUT quantizer: INTEGER codebooks whose clip range is too large for the decision
+ * table (lut_values_bitwidth > 10; clip bounds and centres within +-2^20).  For such codebooks the literal scan's
+ * result is a non-decreasing staircase of the scaled value with one hand-over per pair of adjacent sorted centres;
+ * mctq_lut_build_steps() -- host code -- finds each hand-over's exact float32 threshold by bisecting the literal
+ * scan over float bit patterns and checks the model on sample points; the mctq_luts_* kernels count the thresholds
+ * <= t with a branchless binary search in LDS (log2 of the codebook size reads per element instead of 4 VALU ops per
+ * entry), bit-identically to the literal scan (tested for all 2^32 inputs).
+ *   mctq_lut_steps_words : upper bound of the array size in floats for a codebook of n_lut entries.
+ *   mctq_lut_build_steps : fills steps_host (HOST) and *n_words with the actual size 2 * P + 2; MCTQ_E_ARG for a
+ *                          non-integer codebook or one that fails the staircase check (use the literal kernels then).
+ *   mctq_luts_per_tensor / _per_channel : as mctq_lutt_*, with `steps` (DEVICE copy) and `n_words` in place of the table.
+ */
+int32_t mctq_lut_steps_words(int32_t n_lut);
+
+int mctq_lut_build_steps(const float* lut_host, int32_t n_lut, float mult, float clip_min, float clip_max,
+                         float* steps_host, int32_t* n_words);
+
+int mctq_luts_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32_t step_round,
+                         float thr_div, float thr_mul,
+                         const float* steps, int32_t n_words,
+                         float mult, float clip_min, float clip_max,
+                         void* stream);
+
+int mctq_luts_per_channel(const void* x, float* y,
+                          int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
+                          const float* thresholds, float eps,
+                          const float* steps, int32_t n_words,
+                          float mult, float clip_min, float clip_max,
+                          void* stream);
+
+/*
  * Export-time arithmetic: what the reference's quantizers compute while an ONNX export traces them
  * (`self._use_custom_impl and torch.jit.is_tracing()`), a different last-ulp contract from the fake-quant
  * entry points above: clip, TRUE division by the step, round half even, scale back.

@@ -130,7 +130,7 @@ struct AffineOp {
 #else
   static constexpr bool kHeavy = false;       // a few VALU ops per element: pure streaming
 #endif
-  static constexpr bool kFallback = false;
+  static constexpr int kFixedU = 0;            // 0: every launch variant is built; else only <kFixedU lane-vectors, non-temporal>
 
   __host__ __device__ __forceinline__ static Param make(float s, int32_t zp) {
     Param p;
@@ -199,7 +199,7 @@ struct GridOp {
   typedef NoBook Book;
   static constexpr int kWords = 3;
   static constexpr bool kHeavy = false;
-  static constexpr bool kFallback = false;
+  static constexpr int kFixedU = 0;            // 0: every launch variant is built; else only <kFixedU lane-vectors, non-temporal>
 
   __host__ __device__ __forceinline__ static Param make(float lo, float hi, float d) {
     Param p; p.lo = lo; p.hi = hi; p.d = d; return p;
@@ -251,7 +251,7 @@ struct LutCommon {
   struct Param { float d, t, r, ds; };
   static constexpr int kWords = 4;
   static constexpr bool kHeavy = true;         // launched through the heavy-op dispatch
-  static constexpr bool kFallback = false;     // overridden by the literal-scan op
+  static constexpr int kFixedU = 0;            // overridden by the literal-scan and the steps op (one variant each)
 
   __host__ __device__ __forceinline__ static Param make(float d, float t, float mult) {
     Param p; p.d = d; p.t = t;
@@ -332,9 +332,9 @@ struct LutOp : LutCommon {
   static constexpr const char* kName = LP > 0 ? "LutOp<registers>" : "LutOp<lds>";
   const float* __restrict__ lut;       // [n_lut] device codebook, caller's order
   int n_lut;
-  // Fallback path (non-integer codebooks, bit widths the decision table does not cover): built in one
-  // launch variant only (2 lane-vectors per lane, non-temporal, one tile per block) to keep the library small.
-  static constexpr bool kFallback = true;
+  // Fallback path (non-integer codebooks): built in one launch variant only (2 lane-vectors per lane,
+  // non-temporal, one tile per block) to keep the library small.
+  static constexpr int kFixedU = 2;
 
   typedef typename std::conditional<(LP > 0), RegBook<(LP > 0 ? LP : 1)>, LdsBook>::type Book;
 
@@ -468,6 +468,73 @@ struct LutTableOp : LutCommon {
 #endif
 #pragma unroll
     for (int i = 0; i < NE; ++i) out[i] = decide<FAST>(in[i], v[i], e[i], p, b);
+  }
+};
+
+// Threshold-list ("steps") codebook quantizer: any INTEGER codebook, any clip range the decision table above is too
+// large for (lut_values_bitwidth > 10).  For integer centres at most 2^20 apart from t the float32 distances
+// fl(|t - c|) of two centres on the same side of t never tie (they differ by >= 1, the rounding error is < 2^-3), so
+// the literal first-minimum scan is a non-decreasing staircase of t whose steps are the hand-overs between ADJACENT
+// sorted centres; mctq_lut_build_steps() finds every step's exact float32 threshold T_k by bisection of the literal
+// scan over float bit patterns (list-order tie-breaking included) and checks the model on sample points.  The kernel
+// counts the thresholds <= t by a branchless binary search over the sorted list in LDS -- log2(P) reads per element
+// instead of the scan's 4 VALU ops per codebook entry -- and reads the dequantized centre.
+// Layout (floats): T[0 .. P-1] (T[0] unused, padding +inf), Q[0 .. P-1], q for NaN input, P.  P = power of two >= centres.
+struct LutStepsBook { const float* T; const float* Q; float nan_q; };
+
+struct LutStepsOp : LutCommon {
+  static constexpr const char* kName = "LutStepsOp";
+  static constexpr int kFixedU = 4;
+  const float* __restrict__ steps;     // device, 2 * P + 2 words
+  int P;
+
+  typedef LutStepsBook Book;
+  __device__ __forceinline__ uint32_t book_words() const { return ((uint32_t)(2 * P + 2) + 3u) & ~3u; }
+
+  __device__ __forceinline__ Book setup(float* lds) const {
+    for (int j = threadIdx.x; j < 2 * P + 2; j += kThreads) lds[j] = steps[j];
+    __syncthreads();
+    Book b; b.T = lds; b.Q = lds + P; b.nan_q = lds[2 * P];
+    return b;
+  }
+
+  template <bool FAST>
+  __device__ __forceinline__ float clipped(float x, const Param& p) const {
+    const float v = scaled<FAST>(x, p);
+    float t = fminf(fmaxf(v, cmin), cmax);
+    t = (x != x) ? x : t;                              // torch.clip keeps NaN (see LutOp::apply)
+    t = (v != v) ? v : t;
+    return t;
+  }
+
+  template <bool FAST = false>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
+    const float t = clipped<FAST>(x, p);
+    int idx = 0;
+    for (int s = P >> 1; s > 0; s >>= 1) idx += (t >= b.T[idx + s]) ? s : 0;     // NaN: no threshold is <= t
+    const float q = (t != t) ? b.nan_q : b.Q[idx];
+    return q * p.t;
+  }
+
+  // a whole tile level by level: the NE reads of a level are issued back to back
+  template <bool FAST, int NE>
+  __device__ __forceinline__ void tile(const float* in, float* out, const Param& p, const Book& b) const {
+    float t[NE];
+    int idx[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { t[i] = clipped<FAST>(in[i], p); idx[i] = 0; }
+    for (int s = P >> 1; s > 0; s >>= 1) {
+      float th[NE];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) th[i] = b.T[idx[i] + s];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) idx[i] += (t[i] >= th[i]) ? s : 0;
+    }
+    float q[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) q[i] = b.Q[idx[i]];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) out[i] = ((t[i] != t[i]) ? b.nan_q : q[i]) * p.t;
   }
 };
 
@@ -953,8 +1020,8 @@ inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st,
 
 #define MCTQ_DISPATCH_HEAVY(U_, NT_, ...)                                                   \
   do {                                                                                      \
-    if constexpr (Op::kFallback) {                                                          \
-      constexpr int U = 2; constexpr int NT = 1; __VA_ARGS__;                               \
+    if constexpr (Op::kFixedU != 0) {                                                       \
+      constexpr int U = Op::kFixedU; constexpr int NT = 1; __VA_ARGS__;                     \
     } else if constexpr (std::is_same<TI, float>::value) {                                  \
       switch (U_) {                                                                         \
         case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
@@ -1000,7 +1067,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
   }
   const int64_t nv = n / io::N;
   if constexpr (Op::kHeavy) {
-    if (Op::kFallback || !g_heavy_persistent) {
+    if (Op::kFixedU != 0 || !g_heavy_persistent) {
       MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, nt_mode(n * (int64_t)sizeof(TO)), {
         int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
         if (blocks == 0) blocks = 1;
@@ -1011,7 +1078,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
       });
       return check_launch("flat launch");
     }
-    if constexpr (!Op::kFallback) MCTQ_DISPATCH_HEAVY(2, nt_mode(n * (int64_t)sizeof(TO)), {
+    if constexpr (Op::kFixedU == 0) MCTQ_DISPATCH_HEAVY(2, nt_mode(n * (int64_t)sizeof(TO)), {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       const int64_t cap = (int64_t)cu_count() * 16;
       if (blocks > cap) blocks = cap;
@@ -1061,11 +1128,11 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         if ((cap - innerv) * 8 <= cap) { u_sel = u; break; }
       }
       if (g_heavy_unroll) u_sel = g_heavy_unroll;
-      if (Op::kFallback) u_sel = 2;                       // the only variant built for the fallback ops
+      if (Op::kFixedU != 0) u_sel = Op::kFixedU;          // the only variant built for these ops
       const int64_t per = (int64_t)kThreads * u_sel;
       const int64_t tiles = (innerv + per - 1) / per;
       const int64_t total = rows * tiles;
-      if ((Op::kFallback || !g_heavy_persistent) && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+      if ((Op::kFixedU != 0 || !g_heavy_persistent) && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
                              st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
@@ -1073,7 +1140,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         });
         return check_launch("rows launch");
       }
-      if constexpr (!Op::kFallback) if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+      if constexpr (Op::kFixedU == 0) if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           int64_t grid = (int64_t)cu_count() * persist_blocks_per_cu<Op, TI, TO, U, NT>(book_bytes);
           if (grid > total) grid = total;

@@ -107,4 +107,80 @@ inline const char* build(const float* lut, int n_lut, float mult, float clip_min
   return nullptr;
 }
 
+// ---- threshold list ("steps") for integer codebooks of any clip range (LutStepsOp in mctq_kernels.hpp) ----------
+// P = smallest power of two >= number of DISTINCT centres; the array holds 2 * P + 2 floats.
+inline int steps_pow2(int n_distinct) { int p = 1; while (p < n_distinct) p <<= 1; return p; }
+inline int steps_words_for(int n_lut) { return 2 * steps_pow2(n_lut) + 2; }     // upper bound from the list length
+
+// Fills steps[2 * P + 2] (P returned through *p_out); returns NULL on success or a static message.
+inline const char* build_steps(const float* lut, int n_lut, float mult, float clip_min, float clip_max, float* steps,
+                               int* p_out) {
+  if (!lut || !steps || !p_out) return "NULL pointer";
+  if (n_lut < 1 || n_lut > 4096) return "n_lut must be in [1, 4096]";
+  int e = 0;
+  if (!(mult > 0.0f) || frexpf(mult, &e) != 0.5f) return "mult must be a positive power of two";
+  if (!(clip_min < clip_max) || fabsf(clip_min) > 1048576.0f || fabsf(clip_max) > 1048576.0f) return "clip range unsupported";
+  for (int j = 0; j < n_lut; ++j)
+    if (!(lut[j] == floorf(lut[j])) || fabsf(lut[j]) > 1048576.0f) return "the threshold list needs an integer codebook within 2^20";
+  // distinct centres, ascending (insertion sort: n <= 4096, construction time only)
+  float vs[4096];
+  int D = 0;
+  for (int j = 0; j < n_lut; ++j) {
+    int pos = 0;
+    while (pos < D && vs[pos] < lut[j]) ++pos;
+    if (pos < D && vs[pos] == lut[j]) continue;
+    for (int k = D; k > pos; --k) vs[k] = vs[k - 1];
+    vs[pos] = lut[j];
+    ++D;
+  }
+  const int P = steps_pow2(D);
+  float* T = steps;
+  float* Qv = steps + P;
+  for (int k = 0; k < P; ++k) { T[k] = INFINITY; Qv[k] = vs[D - 1] / mult; }
+  T[0] = -INFINITY;                                       // unused by the search
+  const uint32_t olo = f2ord(clip_min), ohi = f2ord(clip_max);
+  for (int k = 0; k < D; ++k) Qv[k] = vs[k] / mult;
+  for (int k = 1; k < D; ++k) {
+    // T_k = the smallest t in [clip_min, clip_max] whose literal result is >= vs[k] (monotone predicate)
+    if (literal(clip_min, lut, n_lut) >= vs[k]) { T[k] = -INFINITY; continue; }
+    if (literal(clip_max, lut, n_lut) < vs[k]) { T[k] = INFINITY; continue; }
+    uint32_t a = olo, b = ohi;                            // literal(a) < vs[k] <= literal(b)
+    while (b - a > 1) {
+      const uint32_t m = a + (b - a) / 2;
+      if (literal(ord2f(m), lut, n_lut) >= vs[k]) b = m; else a = m;
+    }
+    T[k] = ord2f(b);
+  }
+  for (int k = 2; k < D; ++k)
+    if (T[k] < T[k - 1]) return "codebook decision is not a monotone staircase";
+  // check the staircase model against the literal scan: at every threshold and its predecessor, and on pseudo-random
+  // points of the clip range
+  auto model = [&](float t) {
+    int idx = 0;
+    for (int sft = P >> 1; sft > 0; sft >>= 1) idx += (t >= T[idx + sft]) ? sft : 0;
+    return Qv[idx] * mult;
+  };
+  uint32_t rng = 0x2545F491u;
+  for (int k = 1; k < D; ++k) {
+    if (!(T[k] > -INFINITY && T[k] < INFINITY)) continue;
+    const uint32_t o = f2ord(T[k]);
+    for (int d = -2; d <= 2; ++d) {
+      const uint32_t oo = o + (uint32_t)d;
+      if (oo < olo || oo > ohi) continue;
+      const float t = ord2f(oo);
+      if (literal(t, lut, n_lut) != model(t)) return "codebook decision is not a monotone staircase";
+    }
+  }
+  const uint32_t span = ohi - olo;
+  for (int r = 0; r < 4096; ++r) {
+    rng = rng * 1664525u + 1013904223u;
+    const float t = ord2f(olo + (span ? rng % (span + 1u) : 0u));
+    if (literal(t, lut, n_lut) != model(t)) return "codebook decision is not a monotone staircase";
+  }
+  steps[2 * P + 0] = lut[0] / mult;                       // NaN input: argmin over all-NaN distances = index 0
+  steps[2 * P + 1] = (float)P;
+  *p_out = P;
+  return nullptr;
+}
+
 }  // namespace mctq_tb

@@ -106,6 +106,15 @@ SIGNATURES = {
     "mctq_lut_table_entries": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float]),
     "mctq_lut_build_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_void_p]),
+    "mctq_lut_steps_words": (ctypes.c_int32, [ctypes.c_int32]),
+    "mctq_lut_build_steps": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "mctq_luts_per_tensor": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_float, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+    "mctq_luts_per_channel": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_int32, _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mctq_lutt_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                                 _c_f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_void_p]),
@@ -156,6 +165,23 @@ def load():
             handle.mctq_set_tuning(b"cached_store_max_mb", int(mb))
         _lib = handle
     return _lib
+
+
+def build_lut_steps(lut_values, mult: float, clip_min: float, clip_max: float):
+    """Host-side threshold list for an integer codebook of any clip range (numpy float32 [2 P + 2], see
+    include/mctq_hip.h: mctq_lut_build_steps), or None when the codebook does not qualify."""
+    import numpy as np
+    lib = load()
+    lut = np.ascontiguousarray(np.asarray(lut_values, dtype=np.float32).reshape(-1))
+    cap = lib.mctq_lut_steps_words(lut.size)
+    if cap < 0:
+        return None
+    steps = np.zeros(cap, dtype=np.float32)
+    n_words = ctypes.c_int32(0)
+    rc = lib.mctq_lut_build_steps(lut.ctypes.data, lut.size, mult, clip_min, clip_max, steps.ctypes.data, ctypes.byref(n_words))
+    if rc != 0:
+        return None
+    return steps[: n_words.value].copy()
 
 
 # ------------------------------------------------------------------------------------------

@@ -280,7 +280,7 @@ def _hip_fq_batched(items):
 
 
 def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
-                        step_round: int = 0, thr_div64: float = None):
+                        step_round: int = 0, thr_div64: float = None, steps=None):
     """LUT quantizer, one threshold.  Output is float32 whatever x's type (the reference's chain promotes).
     ``thr_div64``: for float64 tensors whose divisor is a Python float (the activation quantizer) the divisor
     stays a double."""
@@ -307,6 +307,11 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
             table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
                                           table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
+        elif steps is not None:
+            # integer codebook too wide for the table: sorted threshold list, binary search in LDS
+            steps = _param_on(x, steps, "steps", torch.float32)
+            rc = _launch(lib.mctq_luts_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
+                         steps.data_ptr(), steps.numel(), mult, cmin, cmax, _stream(x))
         else:
             # literal first-minimum scan (non-integer codebooks, wide bit widths): every storage type, incl. the
             # per-step half-precision roundings of a half activation (step_round)
@@ -318,7 +323,7 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
 
 
 def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float,
-                         table=None):
+                         table=None, steps=None):
     dt = _dtype_code(x, "lut_per_channel")
     _check_axis(x, thresholds.numel(), axis)
     if dt != native.DT_F64 and table is not None and native.TRACE is False:
@@ -338,6 +343,10 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
             table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                            eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
+        elif steps is not None and dt != native.DT_F64:
+            steps = _param_on(x, steps, "steps", torch.float32)
+            rc = _launch(lib.mctq_luts_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
+                         eps, steps.data_ptr(), steps.numel(), mult, cmin, cmax, _stream(x))
         else:
             rc = _launch(lib.mctq_lut_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                           eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
@@ -503,6 +512,17 @@ def make_lut_table(lut_values, mult: float, cmin: float, cmax: float, device):
     if table is None:
         return None
     return torch.from_numpy(table).to(device)
+
+
+def make_lut_steps(lut_values, mult: float, cmin: float, cmax: float, device):
+    """Device copy of an integer codebook's sorted threshold list (include/mctq_hip.h: mctq_lut_build_steps), or None.
+    The quantizers ask for it only when the decision table does not apply (lut_values_bitwidth > 10)."""
+    if torch.device(device).type != "cuda":
+        return None
+    steps = native.build_lut_steps(lut_values, mult, cmin, cmax)
+    if steps is None:
+        return None
+    return torch.from_numpy(steps).to(device)
 
 
 # ------------------------------------------------------------------------------------------
@@ -710,25 +730,26 @@ def fq_batched(items):
 
 
 def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
-                   step_round: int = 0, thr_div64: float = None):
+                   step_round: int = 0, thr_div64: float = None, steps=None):
     if _is_real(x):
         if _tracing():                                        # the reference's own op chain is what gets recorded
             return _cpu_lut_per_tensor(x, lut, thr_div if thr_div64 is None else thr_div64, thr_mul, mult, cmin, cmax,
                                        step_round)
         if x.is_cuda:
-            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round, thr_div64)
+            return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round, thr_div64, steps)
         if x.device.type == "cpu":
             _cpu_route_allowed()
             return _cpu_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round)
     return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, max(step_round, 0))
 
 
-def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float, table=None):
+def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float, table=None,
+                    steps=None):
     if _is_real(x):
         if _tracing():
             return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
         if x.is_cuda:
-            return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, table)
+            return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, table, steps)
         if x.device.type == "cpu":
             _cpu_route_allowed()
             return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)

@@ -96,6 +96,9 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         # codebook compiled once into an LDS decision table (None -> literal scan kernels)
         self._lut_table_torch = ops.make_lut_table(self._lut_values_np, *lut_domain(self.lut_values_bitwidth, True),
                                                    dev)
+        # ... or, for clip ranges too wide for the table, into a sorted threshold list (None -> literal scan)
+        self._lut_steps_torch = None if self._lut_table_torch is not None else \
+            ops.make_lut_steps(self._lut_values_np, *lut_domain(self.lut_values_bitwidth, True), dev)
 
     _export_function = "WeightsLUTSymmetricF"
 
@@ -114,10 +117,10 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
                 raise RuntimeError(f'input_rank={self.input_rank} does not match a tensor of rank {inputs.dim()}')
             axis = self.channel_axis % inputs.dim()
             out = ops.lut_per_channel(inputs, self._lut_values_torch, self._threshold_torch, float(self.eps), axis,
-                                      mult, cmin, cmax, self._lut_table_torch)
+                                      mult, cmin, cmax, self._lut_table_torch, self.__dict__.get("_lut_steps_torch"))
         else:
             out = ops.lut_per_tensor(inputs, self._lut_values_torch, self._thr_div0, self._thr_mul0, mult, cmin, cmax,
-                                     self._lut_table_torch)
+                                     self._lut_table_torch, steps=self.__dict__.get("_lut_steps_torch"))
         return self._remember(out)
 
 
@@ -164,6 +167,8 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
                                   for dt in (torch.float32, torch.float16, torch.bfloat16)}
         self._lut_table_torch = ops.make_lut_table(self._lut_values_np,
                                                    *lut_domain(self.lut_values_bitwidth, self.signed), dev)
+        self._lut_steps_torch = None if self._lut_table_torch is not None else \
+            ops.make_lut_steps(self._lut_values_np, *lut_domain(self.lut_values_bitwidth, self.signed), dev)
         # pre-packed launch (compiled binding): activations are launch-bound, see ActivationSymmetric.__call__.
         # Rebuilt here only: threshold / eps / lut_values of a LUT quantizer are construction-time constants
         # (the decision table is compiled from them).
@@ -193,4 +198,4 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         # a float64 tensor divided by the Python-float threshold + eps: the divisor stays a double
         div64 = float(self.threshold) + self.eps if dt is torch.float64 else None
         return ops.lut_per_tensor(inputs, self.lut_values, thr_div, self._thr_mul0, mult, cmin, cmax,
-                                  self._lut_table_torch, step, div64)
+                                  self._lut_table_torch, step, div64, self.__dict__.get("_lut_steps_torch"))

@@ -29,6 +29,33 @@ static int check(const std::vector<float>& lut, float mult, float cmin, float cm
   return bad != 0;
 }
 
+// threshold list: the binary search over T equals the literal scan around every threshold and on a coarse sweep
+static int check_steps(const std::vector<float>& lut, float mult, float cmin, float cmax) {
+  std::vector<float> steps(mctq_tb::steps_words_for((int)lut.size()));
+  int P = 0;
+  if (const char* err = mctq_tb::build_steps(lut.data(), (int)lut.size(), mult, cmin, cmax, steps.data(), &P)) { printf("build_steps: %s\n", err); return 1; }
+  if (2 * P + 2 > (int)steps.size() || steps[2 * P + 1] != (float)P) { printf("bad P\n"); return 1; }
+  const float* T = steps.data();
+  const float* Q = T + P;
+  auto model = [&](float t) { int idx = 0; for (int s = P >> 1; s > 0; s >>= 1) idx += (t >= T[idx + s]) ? s : 0; return Q[idx]; };
+  long bad = 0;
+  for (int k = 1; k < P; ++k) {
+    if (!(T[k] > -INFINITY && T[k] < INFINITY)) continue;
+    for (int d = -200; d <= 200; ++d) {
+      const float t = mctq_tb::ord2f(mctq_tb::f2ord(T[k]) + (uint32_t)d);
+      if (!(t >= cmin && t <= cmax)) continue;
+      if (model(t) != mctq_tb::literal(t, lut.data(), (int)lut.size()) / mult) ++bad;
+    }
+  }
+  const double span = (double)cmax - (double)cmin;
+  for (int i = 0; i <= 200000; ++i) {
+    const float t = (float)((double)cmin + span * i / 200000.0);
+    if (model(t) != mctq_tb::literal(t, lut.data(), (int)lut.size()) / mult) ++bad;
+  }
+  if (bad) printf("steps: %ld mismatches\n", bad);
+  return bad != 0;
+}
+
 int main() {
   int rc = 0;
   for (uint32_t h = 0; h < 65536; ++h) {                    // binary16 round trip
@@ -47,6 +74,18 @@ int main() {
   rc |= check(all, 128, -128, 127);
   float bad_lut[2] = {0.5f, 1.0f}; float tmp[8];
   if (!mctq_tb::build(bad_lut, 2, 128, -128, 127, tmp)) { printf("non-integer codebook accepted\n"); rc = 1; }
+  rc |= check_steps({-5, 5}, 2048, -2048, 2047);
+  rc |= check_steps({3, 3, -8}, 2048, -2048, 2047);
+  rc |= check_steps({7}, 2048, -2048, 2047);
+  rc |= check_steps({2047, -2048, 0, 1, -1, 1000, -1000, 512, 3}, 2048, -2048, 2047);
+  rc |= check_steps({0, 1, 2, 4095, 4096, 77, 900}, 4096, 0, 4095);                       // centre above the clip range
+  std::vector<float> w16; for (int v = -32768; v < 32768; v += 257) w16.push_back((float)(((v * 31) % 65536 + 65536) % 65536 - 32768));
+  rc |= check_steps(w16, 32768, -32768, 32767);
+  rc |= check_steps(all, 128, -128, 127);
+  {
+    std::vector<float> st(mctq_tb::steps_words_for(2)); int P = 0;
+    if (!mctq_tb::build_steps(bad_lut, 2, 2048, -2048, 2047, st.data(), &P)) { printf("non-integer codebook accepted (steps)\n"); rc = 1; }
+  }
   printf(rc ? "FAILED\n" : "table builder ok\n");
   return rc;
 }

@@ -80,6 +80,42 @@ def test_decision_table_builder_matches_the_oracle_scan():
     assert native.build_lut_table([1.0], 2.0 ** 12, -2048.0, 2047.0) is None         # too wide for LDS
 
 
+def test_threshold_list_builder_matches_the_oracle_scan():
+    """Host-only: the sorted threshold list (wide integer codebooks, lut_values_bitwidth > 10) reproduces the literal
+    first-minimum scan: +-60 ulps around every threshold, at every half-integer of a window, and on random points."""
+    import numpy as np
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(1)
+    cases = [([-5.0, 5.0], True, 12), ([3.0, 3.0, -8.0], True, 12), ([7.0], True, 12),
+             ([float(v) for v in rng.choice(np.arange(-2048, 2048), 16, replace=False)], True, 12),
+             ([float(v) for v in rng.choice(np.arange(-32768, 32768), 256, replace=False)], True, 16),
+             ([float(v) for v in rng.choice(np.arange(0, 4097), 64, replace=False)], False, 12),
+             ([float(v) for v in rng.permutation(np.arange(-128, 128))], True, 8)]
+    for lut, signed, B in cases:
+        mult = float(2 ** (B - int(signed)))
+        cmin, cmax = (float(-2 ** (B - 1)), float(2 ** (B - 1) - 1)) if signed else (0.0, float(2 ** B - 1))
+        st = native.build_lut_steps(lut, mult, cmin, cmax)
+        assert st is not None
+        P = int(st[-1])
+        assert st.shape == (2 * P + 2,) and P & (P - 1) == 0 and P >= len(set(lut))
+        T, Q = st[:P], st[P:2 * P]
+        assert np.all(np.diff(T[1:]) >= 0) or P <= 2
+        fin = T[1:][np.isfinite(T[1:])]
+        b = fin.view(np.int32).astype(np.int64)[:, None]
+        off = np.arange(-60, 61, dtype=np.int64)[None, :]
+        near = np.where(fin[:, None] > 0, b + off, b - off).astype(np.int32).view(np.float32).reshape(-1)
+        halves = (rng.integers(int(2 * cmin), int(2 * cmax) + 1, size=20000) * 0.5).astype(np.float32)
+        t = np.concatenate([near, halves, rng.uniform(cmin, cmax, 50000).astype(np.float32)])
+        t = np.clip(t, cmin, cmax).astype(np.float32)
+        want = O.lut_quantize(t, lut, np.asarray([mult], np.float32), signed, B, 0.0)      # thr = mult, eps = 0: t == x
+        idx = np.searchsorted(T[1:], t, side="right")                                      # thresholds <= t
+        got = Q[idx] * np.float32(mult)
+        assert np.array_equal(got, want), (lut[:8], B)
+        assert st[2 * P] == np.float32(lut[0]) / np.float32(mult)                          # NaN input -> codebook entry 0
+    assert native.build_lut_steps([0.5, 1.0], 2048.0, -2048.0, 2047.0) is None             # non-integer codebook
+
+
 def test_table_builder_under_address_and_ub_sanitizers(tmp_path):
     """The host half of the library (decision-table construction) is plain C++: build it alone with
     AddressSanitizer + UBSan and run its self-check (GPU sanitizers are unavailable on this pool)."""

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, bits_equal, first_mismatch, load_json
+from conftest import GOLDEN, bits_equal, finite_equal, first_mismatch, load_json
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,10 @@ def lib():
     from mct_quantizers_amd.hip import native
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     return native.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _dev(a):
@@ -763,3 +767,132 @@ def test_versioned_reuse_is_not_fooled_by_a_recycled_address(lib):
         pytest.skip("the allocator did not recycle the block")
     yb = q(b)
     assert yb is not ya and torch.equal(yb, torch.fake_quantize_per_channel_affine(b, q.scales, q.zero_points, 0, -128, 127))
+
+
+# ---------------------------------------------------------------------------------------------
+# wide integer codebooks (lut_values_bitwidth > 10): sorted threshold list, binary search in LDS
+# ---------------------------------------------------------------------------------------------
+
+def _wide_codebooks():
+    rng = np.random.default_rng(77)
+    return {
+        "s12_l16": ([float(v) for v in rng.choice(np.arange(-2048, 2048), 16, replace=False)], True, 12),
+        "s12_l3dup": ([3.0, 3.0, -8.0], True, 12),
+        "u12_l64": ([float(v) for v in rng.choice(np.arange(0, 4097), 64, replace=False)], False, 12),
+        "s16_l256": ([float(v) for v in rng.choice(np.arange(-32768, 32768), 256, replace=False)], True, 16),
+        "s11_l5": ([-1024.0, 1023.0, 0.0, 1.0, -1.0], True, 11),
+    }
+
+
+def _domain(signed, B):
+    mult = float(2 ** (B - int(signed)))
+    return (mult, float(-2 ** (B - 1)), float(2 ** (B - 1) - 1)) if signed else (mult, 0.0, float(2 ** B - 1))
+
+
+@pytest.mark.parametrize("name", list(_wide_codebooks()))
+def test_threshold_list_equals_literal_scan_for_every_float(lib, name):
+    """All 2^32 float32 inputs: the threshold-list kernel == the literal first-minimum scan kernel."""
+    from mct_quantizers_amd.hip import native
+    lut, signed, B = _wide_codebooks()[name]
+    mult, cmin, cmax = _domain(signed, B)
+    st = native.build_lut_steps(lut, mult, cmin, cmax)
+    assert st is not None
+    lut_d, st_d = _dev(np.asarray(lut, dtype=np.float32)), _dev(st)
+    chunk = 1 << 28
+    y_lit = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    y_st = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    for c in range(16):
+        bits = torch.arange(c * chunk - (1 << 31), (c + 1) * chunk - (1 << 31), dtype=torch.int64, device="cuda")
+        x = bits.to(torch.int32).view(torch.float32)
+        del bits
+        # thr_div = thr_mul = 1: t = clamp(x * mult) sweeps every float of the clip range
+        assert lib.mctq_lut_per_tensor_f32(x.data_ptr(), y_lit.data_ptr(), chunk, 1.0, 1.0, lut_d.data_ptr(),
+                                           len(lut), mult, cmin, cmax, _stream()) == 0
+        assert lib.mctq_luts_per_tensor(x.data_ptr(), y_st.data_ptr(), chunk, native.DT_F32, 0, 1.0, 1.0,
+                                        st_d.data_ptr(), st_d.numel(), mult, cmin, cmax, _stream()) == 0, lib.mctq_last_error()
+        if not torch.equal(y_lit.view(torch.int32), y_st.view(torch.int32)):
+            i = int(torch.nonzero(y_lit.view(torch.int32) != y_st.view(torch.int32))[0])
+            raise AssertionError(f"chunk {c}: x={x[i].item()!r} literal={y_lit[i].item()!r} steps={y_st[i].item()!r}")
+        del x
+    assert "LutStepsOp" in native.last_launch(), native.last_launch()
+
+
+@pytest.mark.parametrize("name", ["s12_l16", "u12_l64", "s16_l256"])
+@pytest.mark.parametrize("outer,C,inner", [(1, 3, 1), (4, 6, 5), (2, 6, 1024), (3, 5, 1028), (1, 16, 11008), (1, 3000, 3),
+                                           (41, 64, 1), (3, 4096, 1)])
+def test_threshold_list_per_channel_vs_oracle(lib, name, outer, C, inner):
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    lut, signed, B = _wide_codebooks()[name]
+    mult, cmin, cmax = _domain(signed, B)
+    rng = np.random.default_rng(C * 7 + inner)
+    thr = rng.uniform(0.05, 4.0, size=C).astype(np.float32)
+    shape = (outer, C, inner)
+    tb = thr.reshape(1, C, 1)
+    x_np = rng.standard_normal(shape).astype(np.float32) * tb * np.float32(0.7)
+    # a third of the elements at midpoints between adjacent centres (ties / hand-overs)
+    srt = np.sort(np.unique(np.float32(lut)))
+    mids = (srt[:-1] + srt[1:]) * np.float32(0.5)
+    pick = mids[rng.integers(0, mids.size, size=shape)] / np.float32(mult) * tb
+    x_np = np.where(rng.integers(0, 3, size=shape) == 0, pick, x_np).astype(np.float32)
+    x_np.reshape(-1)[:3] = np.float32([0.0, -0.0, 1e30])[: min(3, x_np.size)]
+    st_d = _dev(native.build_lut_steps(lut, mult, cmin, cmax))
+    want = O.lut_quantize(x_np, lut, thr, signed, B, 1e-8, per_channel=True, channel_axis=1)
+    for dt, code in ((torch.float32, native.DT_F32), (torch.float16, native.DT_F16), (torch.bfloat16, native.DT_BF16)):
+        x = _dev(x_np).to(dt)
+        t_d = _dev(thr)
+        y = torch.empty(shape, dtype=torch.float32, device="cuda")
+        rc = lib.mctq_luts_per_channel(x.data_ptr(), y.data_ptr(), outer, C, inner, code, t_d.data_ptr(), 1e-8,
+                                       st_d.data_ptr(), st_d.numel(), mult, cmin, cmax, _stream())
+        assert rc == 0, lib.mctq_last_error()
+        if dt is not torch.float32:
+            xw = x.float().cpu().numpy()
+            want_h = O.lut_quantize(xw, lut, thr, signed, B, 1e-8, per_channel=True, channel_axis=1)
+            assert bits_equal(y.cpu().numpy(), want_h), (dt, first_mismatch(y.cpu().numpy(), want_h, xw))
+        else:
+            assert bits_equal(y.cpu().numpy(), want), first_mismatch(y.cpu().numpy(), want, x_np)
+
+
+def test_wide_codebook_quantizer_classes_take_the_threshold_list(lib):
+    """lut_values_bitwidth = 12 / 16 through the reference's classes: bit-equal to the oracle, launched as LutStepsOp;
+    a non-integer codebook (operator layer only) still runs the literal scan."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(5)
+    for name in ("s12_l16", "s16_l256"):
+        lut, signed, B = _wide_codebooks()[name]
+        nb = int(np.log2(len(lut)))
+        thr = rng.uniform(0.5, 3.0, size=8).astype(np.float32)
+        w_np = (rng.standard_normal((8, 33, 3, 3)) * 1.1).astype(np.float32)
+        q = Q.WeightsLUTSymmetricInferableQuantizer(nb, lut, [float(t) for t in thr], True, 0, 4, lut_values_bitwidth=B)
+        assert q._lut_table_torch is None and q._lut_steps_torch is not None
+        got = q(_dev(w_np))
+        assert "LutStepsOp" in native.last_launch(), native.last_launch()
+        want = O.lut_quantize(w_np, lut, thr, True, B, 1e-8, per_channel=True, channel_axis=0)
+        assert bits_equal(got.cpu().numpy(), want)
+        q1 = Q.WeightsLUTPOTInferableQuantizer(nb, lut, [2.0], False, lut_values_bitwidth=B)
+        got = q1(_dev(w_np))
+        assert "LutStepsOp" in native.last_launch(), native.last_launch()
+        assert bits_equal(got.cpu().numpy(), O.lut_quantize(w_np, lut, np.float32([2.0]), True, B, 1e-8))
+        # activation quantizer, float32 and half inputs (per-step half roundings)
+        qa = Q.ActivationLutPOTInferableQuantizer(nb, lut, [4.0], True, lut_values_bitwidth=B)
+        x_np = (rng.standard_normal((4, 3, 17, 19)) * 2.0).astype(np.float32)
+        got = qa(_dev(x_np))
+        assert "LutStepsOp" in native.last_launch(), native.last_launch()
+        assert bits_equal(got.cpu().numpy(), O.lut_quantize(x_np, lut, 4.0, True, B, 1e-8))
+        for dt, dname in ((torch.float16, "float16"), (torch.bfloat16, "bfloat16")):
+            xh = torch.from_numpy(x_np).to(dt)
+            got = qa(xh.cuda())
+            assert "LutStepsOp" in native.last_launch(), native.last_launch()
+            want = O.lut_quantize(xh.float().numpy(), lut, 4.0, True, B, 1e-8, step_dtype=dname)
+            assert finite_equal(got.float().cpu().numpy(), want, xh.float().numpy()), dname
+    # the classes only accept integer codebooks (base_lut_symmetric_inferable_quantizer.py:66); a non-integer one handed
+    # to the operator layer has neither table nor threshold list and runs the literal scan
+    from mct_quantizers_amd.hip import ops
+    assert ops.make_lut_steps(np.float32([-100.5, 3.25, 7.0, 900.0]), 2048.0, -2048.0, 2047.0, "cuda") is None
+    w_np = (rng.standard_normal((64, 65)) * 1.1).astype(np.float32)
+    got = ops.lut_per_tensor(_dev(w_np), _dev(np.float32([-100.5, 3.25, 7.0, 900.0])), 1.5, 1.5, 2048.0, -2048.0, 2047.0)
+    assert "LutOp" in native.last_launch(), native.last_launch()
+    assert bits_equal(got.cpu().numpy(), O.lut_quantize(w_np, [-100.5, 3.25, 7.0, 900.0], np.float32([1.5]), True, 12, 0.0))
