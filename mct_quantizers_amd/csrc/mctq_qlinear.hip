@@ -514,6 +514,386 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Many rows AND many columns: the 64 x 64 wave tile above needs 8 KB of LDS reads per 256 MFMA cycles and wave --
+// with the direct-to-LDS copies more than the CU's 128 B/clk, so it is LDS-bound near a third of the int8 peak.
+// Here one wave owns (16 TM) x (16 TN) outputs (128 x 128 for the 256 x 256 block tile: 16 KB of reads per 1024
+// MFMA cycles, half the LDS bandwidth with 4 waves), accumulators in the 512-register file of a 1-wave-per-SIMD block.
+// K advances in 64-byte steps through a ring of 4 LDS stages: stage kt is multiplied from registers (its fragments were
+// read during stage kt-1), stage kt+1 is certified by the one barrier of the iteration (placed in the middle of the
+// MFMA stream, so the matrix pipe has work queued while waves meet), stages kt+2 and kt+3 are in flight.
+// Whole tiles only (M % BM == N % BN == K % 64 == 0); other shapes use the kernels above.
+// ------------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void ql_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ql_static_for<I + 1, N>(f); }
+}
+template <int OFF>
+__device__ __forceinline__ void ql_ds_read16(i32x4& v, uint32_t lds_byte) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte), "n"(OFF));
+}
+
+// A statement that NAMES the A fragments: everything the compiler itself does with them is ordered against it.
+// WAIT: the LDS reads that filled them have returned.  Otherwise: a few idle cycles between the compiler's VALU
+// writes to them and the matrix instructions (in asm, so their operand hazards are invisible to the compiler).
+template <int TM, bool WAIT>
+__device__ __forceinline__ void ql_fence_frags(i32x4* f) {
+  static_assert(TM == 4 || TM == 8, "4 or 8 row tiles");
+  if constexpr (TM == 8) {
+    if constexpr (WAIT)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
+    else
+      asm volatile("s_nop 4" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+  } else {
+    if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) :: "memory");
+    else asm volatile("s_nop 4" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+  }
+}
+
+template <int TN>
+__device__ __forceinline__ void ql_settle_row(i32x4 (&row)[TN]) {
+  static_assert(TN == 4 || TN == 8, "row of 4 or 8 tiles");
+  if constexpr (TN == 8)
+    asm volatile("s_nop 7" : "+a"(row[0]), "+a"(row[1]), "+a"(row[2]), "+a"(row[3]), "+a"(row[4]), "+a"(row[5]), "+a"(row[6]), "+a"(row[7]));
+  else
+    asm volatile("s_nop 15" : "+a"(row[0]), "+a"(row[1]), "+a"(row[2]), "+a"(row[3]));
+}
+
+// products E .. END-1 of a step: tile (E / TN, E % TN) of the wave's TM x TN accumulator grid
+template <int TM, int TN, int E, int END>
+__device__ __forceinline__ void ql_mfma_run(i32x4 (&acc)[TM][TN], const i32x4* fa, const i32x4* fb) {
+  if constexpr (E < END) {
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[E / TN][E % TN]) : "v"(fa[E / TN]), "v"(fb[E % TN]));
+    ql_mfma_run<TM, TN, E + 1, END>(acc, fa, fb);
+  }
+}
+template <int TM, int FB, int Q, int QEND>
+__device__ __forceinline__ void ql_frag_reads(i32x4* na, i32x4* nb, uint32_t pa, uint32_t pb) {
+  if constexpr (Q < QEND) {
+    if constexpr (Q < TM) ql_ds_read16<Q * FB>(na[Q], pa);
+    else ql_ds_read16<(Q - TM) * FB>(nb[Q - TM], pb);
+    ql_frag_reads<TM, FB, Q + 1, QEND>(na, nb, pa, pb);
+  }
+}
+// second half of a step's products (tiles TM/2 .. TM-1) with the NEXT stage's TM + TN fragment reads spread between them
+template <int TM, int TN, int FB, bool NEXT, int E>
+__device__ __forceinline__ void ql_second_half(i32x4 (&acc)[TM][TN], const i32x4* fa, const i32x4* fb, i32x4* na,
+                                               i32x4* nb, uint32_t pa, uint32_t pb) {
+  constexpr int H2 = (TM - TM / 2) * TN, NR = TM + TN;
+  if constexpr (E < H2) {
+    if constexpr (NEXT) {
+      constexpr int first = E == 0 ? 0 : ((E - 1) * NR) / H2 + 1;
+      constexpr int last = (E * NR) / H2 < NR - 1 ? (E * NR) / H2 : NR - 1;
+      ql_frag_reads<TM, FB, first, last + 1>(na, nb, pa, pb);
+    }
+    constexpr int t = TM / 2 + E / TN, u = E % TN;
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[t][u]) : "v"(fa[t]), "v"(fb[u]));
+    ql_second_half<TM, TN, FB, NEXT, E + 1>(acc, fa, fb, na, nb, pa, pb);
+  }
+}
+
+template <int TM, int TN, bool A_U8>
+__global__ __launch_bounds__(256, 1) void qgemm_i8_wide_kernel(
+    const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, QlOut oq) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, CPR = 4, S = 4;
+  constexpr int SA = BM * CPR, SB = BN * CPR, SLOTS = SA + SB;      // 16-byte slots of one stage
+  constexpr int LA = SA / 256, LB = SB / 256, LT = LA + LB;          // copies per thread per stage
+  __shared__ i32x4 lds[S * SLOTS];
+
+  const int total = m_blocks * n_blocks;
+  int id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);    // an XCD takes consecutive tiles ...
+  constexpr int GM = 4;                                              // ... which form GM-row bands: shared A rows / W rows stay in its L2
+  const int per_band = GM * n_blocks;
+  const int band = id / per_band, in_band = id - band * per_band;
+  const int band_rows = min(GM, m_blocks - band * GM);
+  const int mb = band * GM + in_band % band_rows, nb = in_band / band_rows;
+  const int m0 = mb * BM, n0 = nb * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  // copy j of a stage fills slots j * 256 + tid: row 64 j + tid / 4, physical chunk tid & 3 <- source chunk ^ swizzle.
+  // swizzle(row) = (-(row >> 2)) & 3: a ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31},
+  // {32-35,44-47,52-59}, {36-43,48-51,60-63}; with lane = 16 g + r reading row r, chunk g, the four rows of a group that
+  // share (r & 3) -- and with it the 64-byte bank segment -- must sit in four different 16-byte slots:
+  // {f(0), f(3), f(1)^1, f(2)^1} and {f(1), f(2), f(0)^1, f(3)^1} are permutations of 0..3 for f(x) = -x mod 4.
+  const int crow = tid >> 2, cchunk = (tid & 3) ^ ((0 - (crow >> 2)) & 3);
+  const int8_t* pa = a + (int64_t)(m0 + crow) * K + 16 * cchunk;
+  const int8_t* pw = w + (int64_t)(n0 + crow) * K + 16 * cchunk;
+  const int64_t jstride = 64 * K;
+  auto copy_stage = [&](int slot, int kt) {
+    i32x4* dst = lds + (slot & (S - 1)) * SLOTS + wave * 64;
+    const int64_t k0 = (int64_t)kt * 64;
+#pragma unroll
+    for (int j = 0; j < LA; ++j)
+      __builtin_amdgcn_global_load_lds((ql_glb_void*)(pa + j * jstride + k0), (ql_lds_void*)(dst + j * 256), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      __builtin_amdgcn_global_load_lds((ql_glb_void*)(pw + j * jstride + k0), (ql_lds_void*)(dst + SA + j * 256), 16, 0, 0);
+  };
+
+  // Fragment of tile row 16 t + r, k bytes [16 g, 16 g + 16): slot row * 4 + (g ^ swizzle(row)).
+  // Fragment reads and products are inline asm: the compiler would otherwise retire all but the newest direct-to-LDS
+  // copies before any LDS read (it cannot tell the stages apart), and it keeps the accumulators in VGPRs in some loop
+  // blocks and AGPRs in others, copying 128-256 registers per step.  "a" operands pin them to the AGPR half.
+  const uint32_t lane_byte = (uint32_t)(r * CPR + (g ^ ((0 - (r >> 2)) & 3))) * 16u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(ql_lds_void*)lds;
+  const uint32_t a_byte = lds0 + lane_byte + (uint32_t)(wm * 16 * TM * CPR) * 16u;
+  const uint32_t b_byte = lds0 + lane_byte + (uint32_t)(SA + wn * 16 * TN * CPR) * 16u;
+  constexpr uint32_t kStageBytes = SLOTS * 16u;
+  constexpr int kFragBytes = 16 * CPR * 16;
+
+  i32x4 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) acc[t][u] = i32x4{0, 0, 0, 0};
+
+  const int kt_n = (int)(K / 64);                      // even and >= 4 (host check)
+  constexpr int H1 = TM / 2 * TN, NR = TM + TN;
+  i32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+
+  // One K step, the same code for every kt (a loop of ONE basic block keeps the register allocation of the accumulators
+  // stable): near the end of K the request for stage kt+3 re-fetches the last stage into a ring slot nobody reads again,
+  // and the fragment reads of the non-existent stage kt_n land in registers nobody uses.
+  const int kt_last = kt_n - 1;
+  auto step = [&](int kt, i32x4* fa, const i32x4* fb, i32x4* na, i32x4* nb_) {
+    // this stage's fragments (requested half a step ago); the A fragments are operands so that the compiler's own
+    // uses of them (the uint8 re-bias below) stay behind the wait
+    ql_fence_frags<TM, true>(fa);
+    if constexpr (A_U8) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) fa[t] = fa[t] ^ (int)0x80808080;     // uint8 codes -> int8 (za carries the -128)
+      ql_fence_frags<TM, false>(fa);
+    }
+    ql_mfma_run<TM, TN, 0, H1>(acc, fa, fb);
+    // stage kt+1 complete in LDS for every wave (own copies retired, then the barrier); stage kt+2 may still fly
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LT) : "memory");
+    copy_stage(kt + 3, min(kt + 3, kt_last));            // into the slot of kt-1, whose fragments were consumed a step ago
+    const uint32_t so = (uint32_t)((kt + 1) & (S - 1)) * kStageBytes;
+    ql_second_half<TM, TN, kFragBytes, true, 0>(acc, fa, fb, na, nb_, a_byte + so, b_byte + so);
+  };
+
+  copy_stage(0, 0);
+  copy_stage(1, 1);
+  copy_stage(2, 2);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LT) : "memory");
+  ql_frag_reads<TM, kFragBytes, 0, NR>(fa0, fb0, a_byte, b_byte);
+  for (int kt = 0; kt < kt_n; kt += 2) {                // kt_n is even (host check)
+    step(kt, fa0, fb0, fa1, fb1);
+    step(kt + 1, fa1, fb1, fa0, fb0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // The compiler does not see the matrix pipe behind the asm statements: without a barrier that NAMES the
+  // accumulators it may read a tile (v_accvgpr_read) right behind the asm of that tile's last product, before the
+  // result has left the pipe.  One statement per row of tiles, after the last product, 8 x 8 idle cycles in all.
+  ql_static_for<0, TM>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    ql_settle_row<TN>(acc[t]);
+  });
+
+  auto epilogue = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int n = n0 + wn * 16 * TN + 16 * u + r;
+      const int e_corr = za * w_rowsum[n];
+      const float e_scale = sa * w_scales[n];
+      const float e_bias = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t idx = (int64_t)(m0 + wm * 16 * TM + 16 * t + 4 * g + i) * N + n;
+          float out = (float)(acc[t][u][i] - e_corr) * e_scale;
+          if (bias) out = out + e_bias;
+          if constexpr (MODE == 0) {
+            static_cast<float*>(y)[idx] = out;
+          } else {
+            float q = fminf(fmaxf(__builtin_rintf(out * oq.inv) + oq.zf, oq.lo), oq.hi);
+            if constexpr (MODE == 1) static_cast<int8_t*>(y)[idx] = (int8_t)(int)q;
+            else static_cast<uint8_t*>(y)[idx] = (uint8_t)(int)q;
+          }
+        }
+      }
+    }
+  };
+  if (oq.mode == 0) epilogue(std::integral_constant<int, 0>{});
+  else if (oq.mode == 1) epilogue(std::integral_constant<int, 1>{});
+  else epilogue(std::integral_constant<int, 2>{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same 256 x 256 block tile with EIGHT waves in two groups that alternate between a memory phase and a product
+// phase.  Issuing a direct-to-LDS copy holds a wave's instruction stream for ~100 cycles; with one wave per SIMD
+// the matrix pipe idles meanwhile (counters on the 4-wave kernel above: pipe 47 % busy, half of the wave time
+// spent waiting to issue).  Here waves w and w + 4 share a SIMD and belong to different groups: while one requests the
+// next stage (4 copies) and reads its 12 fragments, the other issues its 32 products; a workgroup barrier swaps the
+// roles twice per K step.  Wave tile 128 x 64 (TM 8 x TN 4), fragments single-buffered, ring of 4 stages with the
+// request running 3 stages ahead.
+//   slot:      2k            2k+1           2k+2
+//   group 0:   MEM(k)    |   CMP(k)     |   MEM(k+1)
+//   group 1:   CMP(k-1)  |   MEM(k)     |   CMP(k)
+// Stage k+1 is certified by the barrier that ends slot 2k+1 (every wave first retires its own copies of it); the
+// slot overwritten by MEM(k) held stage k-1, whose last fragment reads (group 1, slot 2k-1) were awaited before
+// the barrier that ended that slot.
+// ------------------------------------------------------------------------------------------------
+template <bool A_U8>
+__global__ __launch_bounds__(512, 1) void qgemm_i8_pp_kernel(
+    const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
+    const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
+    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, QlOut oq) {
+  constexpr int TM = 8, TN = 4, BM = 256, BN = 256, CPR = 4, S = 4;
+  constexpr int SA = BM * CPR, SB = BN * CPR, SLOTS = SA + SB;      // 2048 16-byte slots per stage
+  constexpr int LA = SA / 512, LB = SB / 512, LT = LA + LB;          // copies per thread per stage: 2 + 2
+  __shared__ i32x4 lds[S * SLOTS];
+
+  const int total = m_blocks * n_blocks;
+  int id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  constexpr int GM = 4;
+  const int per_band = GM * n_blocks;
+  const int band = id / per_band, in_band = id - band * per_band;
+  const int band_rows = min(GM, m_blocks - band * GM);
+  const int mb = band * GM + in_band % band_rows, nb = in_band / band_rows;
+  const int m0 = mb * BM, n0 = nb * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = (wave >> 1) & 3;
+  const int r = lane & 15, g = lane >> 4;
+
+  // copy j of a stage fills slots j * 512 + tid: row 128 j + tid / 4, physical chunk tid & 3 (swizzle as above)
+  const int crow = tid >> 2, cchunk = (tid & 3) ^ ((0 - (crow >> 2)) & 3);
+  const int8_t* pa = a + (int64_t)(m0 + crow) * K + 16 * cchunk;
+  const int8_t* pw = w + (int64_t)(n0 + crow) * K + 16 * cchunk;
+  const int64_t jstride = 128 * K;
+  auto copy_stage = [&](int slot, int kt) {
+    i32x4* dst = lds + (slot & (S - 1)) * SLOTS + wave * 64;
+    const int64_t k0 = (int64_t)kt * 64;
+#pragma unroll
+    for (int j = 0; j < LA; ++j)
+      __builtin_amdgcn_global_load_lds((ql_glb_void*)(pa + j * jstride + k0), (ql_lds_void*)(dst + j * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      __builtin_amdgcn_global_load_lds((ql_glb_void*)(pw + j * jstride + k0), (ql_lds_void*)(dst + SA + j * 512), 16, 0, 0);
+  };
+
+  const uint32_t lane_byte = (uint32_t)(r * CPR + (g ^ ((0 - (r >> 2)) & 3))) * 16u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(ql_lds_void*)lds;
+  const uint32_t a_byte = lds0 + lane_byte + (uint32_t)(wm * 16 * TM * CPR) * 16u;
+  const uint32_t b_byte = lds0 + lane_byte + (uint32_t)(SA + wn * 16 * TN * CPR) * 16u;
+  constexpr uint32_t kStageBytes = SLOTS * 16u;
+  constexpr int kFragBytes = 16 * CPR * 16;
+
+  i32x4 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) acc[t][u] = i32x4{0, 0, 0, 0};
+
+  const int kt_n = (int)(K / 64), kt_last = kt_n - 1;
+  i32x4 fa[TM], fb[TN];
+
+  auto mem_phase = [&](int kt) {
+    const uint32_t so = (uint32_t)(kt & (S - 1)) * kStageBytes;
+    ql_frag_reads<TM, kFragBytes, 0, TM + TN>(fa, fb, a_byte + so, b_byte + so);
+    copy_stage(kt + 3, min(kt + 3, kt_last));
+  };
+  auto cmp_phase = [&]() {
+    if constexpr (A_U8) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) fa[t] = fa[t] ^ (int)0x80808080;
+      ql_fence_frags<TM, false>(fa);
+    }
+    ql_mfma_run<TM, TN, 0, TM * TN>(acc, fa, fb);
+  };
+
+  copy_stage(0, 0);
+  copy_stage(1, 1);
+  copy_stage(2, 2);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LT) : "memory");
+  if (wave < 4) {
+    for (int kt = 0; kt < kt_n; ++kt) {
+      mem_phase(kt);
+      ql_fence_frags<TM, true>(fa);                                        // fragments in registers (lgkmcnt 0)
+      asm volatile("s_barrier" ::: "memory");                              // b(2k)
+      cmp_phase();
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LT) : "memory");   // own copies of stage k+1 retired; b(2k+1)
+    }
+  } else {
+    asm volatile("s_barrier" ::: "memory");                                // b0
+    for (int kt = 0; kt < kt_n; ++kt) {
+      mem_phase(kt);
+      ql_fence_frags<TM, true>(fa);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LT) : "memory");   // b(2k+1)
+      cmp_phase();
+      if (kt + 1 < kt_n) asm volatile("s_barrier" ::: "memory");           // b(2k+2)
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  ql_static_for<0, TM>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    ql_settle_row<TN>(acc[t]);
+  });
+
+  auto epilogue = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int n = n0 + wn * 16 * TN + 16 * u + r;
+      const int e_corr = za * w_rowsum[n];
+      const float e_scale = sa * w_scales[n];
+      const float e_bias = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t idx = (int64_t)(m0 + wm * 16 * TM + 16 * t + 4 * g + i) * N + n;
+          float out = (float)(acc[t][u][i] - e_corr) * e_scale;
+          if (bias) out = out + e_bias;
+          if constexpr (MODE == 0) {
+            static_cast<float*>(y)[idx] = out;
+          } else {
+            float q = fminf(fmaxf(__builtin_rintf(out * oq.inv) + oq.zf, oq.lo), oq.hi);
+            if constexpr (MODE == 1) static_cast<int8_t*>(y)[idx] = (int8_t)(int)q;
+            else static_cast<uint8_t*>(y)[idx] = (uint8_t)(int)q;
+          }
+        }
+      }
+    }
+  };
+  if (oq.mode == 0) epilogue(std::integral_constant<int, 0>{});
+  else if (oq.mode == 1) epilogue(std::integral_constant<int, 1>{});
+  else epilogue(std::integral_constant<int, 2>{});
+}
+
+template <bool A_U8>
+static int launch_pp(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
+                     const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                     const QlOut& oq, hipStream_t stream) {
+  if (M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || K < 256) return fail_arg("ping-pong tiled kernel needs whole 256 x 256 tiles, K % 64 == 0 and K >= 256");
+  const int mbl = (int)(M / 256), nbl = (int)(N / 256);
+  hipLaunchKernelGGL((qgemm_i8_pp_kernel<A_U8>), dim3((unsigned)(mbl * nbl)), dim3(512), 0, stream,
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, oq);
+  return check_launch("mctq_qlinear_i8 (ping-pong tiles)");
+}
+
+template <int TM, int TN, bool A_U8>
+static int launch_wide(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
+                       const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
+                       const QlOut& oq, hipStream_t stream) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  if (M % BM != 0 || N % BN != 0 || K % 128 != 0 || K < 256) return fail_arg("wide tiled kernel needs whole tiles, K % 128 == 0 and K >= 256");
+  const int mbl = (int)(M / BM), nbl = (int)(N / BN);
+  hipLaunchKernelGGL((qgemm_i8_wide_kernel<TM, TN, A_U8>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, oq);
+  return check_launch("mctq_qlinear_i8 (wide tiles)");
+}
+
 }  // namespace mctq
 
 using namespace mctq;
@@ -558,6 +938,17 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
 #define MCTQ_QG(BM_, BN_, BK_)                                                                                    \
   (u8 ? launch_glds<BM_, BN_, BK_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+#define MCTQ_QW(TM_, TN_)                                                                                         \
+  (u8 ? launch_wide<TM_, TN_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)      \
+      : launch_wide<TM_, TN_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  switch (g_ql_variant) {
+    case 2588: return MCTQ_QW(8, 8);
+    case 2548: return MCTQ_QW(4, 8);
+    case 2584: return MCTQ_QW(8, 4);
+    case 2560: return u8 ? launch_pp<true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)
+                         : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
+    default: break;
+  }
   switch (g_ql_variant) {
     case 1212: return MCTQ_QG(128, 128, 128);
     case 612: return MCTQ_QG(64, 128, 128);
@@ -576,6 +967,20 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   // up to 128 rows: weight streaming, unless there are enough 64 x 64 tiles to occupy more than half the chip --
   // then the tiled kernel's shared activation tile wins (64 x 11008 x 4096: 19.1 vs 25.5 us; 256 x 4096^2: 18.7 vs 26.6)
   if (M <= 128 && blocks(64, 64) * 2 <= cus) return MCTQ_QLL(8, 4);
+  // Many rows and columns, whole tiles: the 256 x 256 ping-pong kernel (2.2-2.3 POP/s against 1.5 for the 128 x 128
+  // tiles; profiles/r02/qgemm_wide_probe.log) or, when there are too few such tiles for the chip, 128 x 256 wave-wide
+  // tiles -- weighed by how full their last round of blocks is (one block per CU; the 128 x 128 kernel fits two).
+  // Only where the 128 x 128 kernel would fill the chip: smaller problems keep its finer tiles.
+  if (K % 128 == 0 && K >= 256 && N % 256 == 0 && M % 128 == 0 && blocks(128, 128) >= 2 * cus) {
+    const auto fill = [&](int64_t nb, int64_t slots) { return (double)nb / (double)(((nb + slots - 1) / slots) * slots); };
+    const double old_rate = 1.5 * fill(blocks(128, 128), 2 * cus);
+    const double pp_rate = M % 256 == 0 ? 2.25 * fill(blocks(256, 256), cus) : 0.0;
+    const double w48_rate = 2.0 * fill(blocks(128, 256), cus);
+    if (pp_rate >= w48_rate && pp_rate > old_rate)
+      return u8 ? launch_pp<true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)
+                : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
+    if (w48_rate > old_rate) return MCTQ_QW(4, 8);
+  }
   {                                                  // tiled: the largest tile that still gives every CU two blocks
     if (blocks(128, 128) >= 2 * cus) return MCTQ_QG(128, 128, 128);
     if (blocks(64, 128) >= 2 * cus) return MCTQ_QG(64, 128, 128);
@@ -583,6 +988,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     return MCTQ_QG(64, 64, 256);                     // few blocks: longer K steps hide the copy latency instead
   }
 #undef MCTQ_QG
+#undef MCTQ_QW
 #undef MCTQ_QL
 #undef MCTQ_QLL
 }

@@ -432,7 +432,15 @@ def qlinear_i8(a_codes: np.ndarray, a_zero_point: int, a_scale: float, w_codes: 
     It evaluates what PytorchQuantizationWrapper.forward (quantize_wrapper.py:231-257) computes for a wrapped
     torch.nn.Linear fed by an activation holder, F.linear(fake_quant(x), fake_quant(W), bias), on the clamp
     indices instead of the dequantized float32 values (the two differ by float32 rounding of the long sum)."""
-    acc = (np.asarray(a_codes).astype(np.int64) - int(a_zero_point)) @ np.asarray(w_codes).astype(np.int64).T
+    a64 = np.asarray(a_codes).astype(np.int64) - int(a_zero_point)
+    w64 = np.asarray(w_codes).astype(np.int64)
+    if a64.shape[0] * w64.shape[0] * a64.shape[1] <= 1 << 24:
+        acc = a64 @ w64.T
+    else:
+        # large cases: the same integer sum through float64 BLAS -- exact, every partial sum is an integer below
+        # 2^53 (|a - za| <= 383, |w| <= 128, K <= 32768), whatever the summation order; tests/test_consumers.py checks
+        # the two branches against each other
+        acc = np.rint(a64.astype(np.float64) @ w64.astype(np.float64).T).astype(np.int64)
     assert np.all(np.abs(acc) < 2 ** 31)
     sc = (F32(a_scale) * np.asarray(w_scales, dtype=F32).reshape(-1)).astype(F32)
     y = (acc.astype(np.int32).astype(F32) * sc[None, :]).astype(F32)

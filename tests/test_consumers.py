@@ -49,6 +49,20 @@ def _model(K=64, N=24, bits_w=8, bits_a=8, per_channel=True, act="uniform", seed
 # CPU
 # ------------------------------------------------------------------------------------------------
 
+def test_oracle_large_case_branch_equals_the_integer_branch():
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(9)
+    a, za, sa, w, ws, bias = _problem(rng, 64, 96, 4096, True)                # 2^24.6 products: float64-BLAS branch
+    got = O.qlinear_i8(a, za, sa, w, ws, bias)
+    acc = (a.astype(np.int64) - za) @ w.astype(np.int64).T
+    want = (acc.astype(np.int32).astype(np.float32) * (np.float32(sa) * ws)).astype(np.float32) + bias
+    assert bits_equal(got, want.astype(np.float32))
+    a[:] = 255
+    w[:] = -128
+    got = O.qlinear_i8(a, 0, sa, w, ws, None)
+    assert np.all(got == (np.float32(-255 * 128 * 4096) * (np.float32(sa) * ws)).astype(np.float32)[None, :])
+
+
 def test_oracle_is_the_exact_product_of_the_dequantized_operands():
     from oracle import mctq_oracle as O
     rng = np.random.default_rng(3)
@@ -265,6 +279,56 @@ def test_chained_consumers_pass_codes_between_layers_cpu():
 @pytest.mark.gpu
 def test_chained_consumers_pass_codes_between_layers_gpu():
     _check_chain("cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [2560, 2588, 2548, 2584, 0])
+def test_dense_tile_kernels_are_bit_exact_and_requantize(variant):
+    """Whole-tile shapes of the many-rows kernels (256 x 256 ping-pong, wave-wide 256 x 256 / 128 x 256 / 256 x 128):
+    exact against the int64 oracle for int8 and uint8 activation codes (extreme codes at the longest K included), the
+    requantizing epilogue equal to the codes kernel, shapes they cannot take refused; variant 0 = what the dispatch picks
+    for a chip-filling shape."""
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd import consumers
+    from mct_quantizers_amd.hip import native, ops
+    lib = native.load()
+    rng = np.random.default_rng(variant + 7)
+    dev = torch.device("cuda")
+    assert lib.mctq_set_tuning(b"ql_variant", variant) == 0
+    try:
+        shapes = [(256, 256, 256), (256, 512, 384), (768, 512, 640), (512, 256, 32768), (1024, 768, 1152)]
+        if variant == 0:
+            shapes = [(4096, 4096, 256), (2048, 4096, 384)]
+        for (M, N, K) in shapes:
+            for u8 in (False, True):
+                a, za, sa, w, ws, bias = _problem(rng, M, N, K, u8, with_bias=(M // 256 + N // 256) % 2 == 1)
+                if K == 32768:
+                    a[:] = 255 if u8 else -128
+                    w[:] = -128
+                    za = 0 if u8 else 127
+                got = _run_kernel(lib, native, a, u8, za, sa, w, ws, bias)
+                want = O.qlinear_i8(a, za, sa, w, ws, bias)
+                assert bits_equal(got, want), f"variant {variant} M={M} N={N} K={K} u8={u8}: {first_mismatch(got, want)}"
+        # requantizing epilogue (int8 / uint8 / 4-bit-range codes of the next layer)
+        M, N, K = 512, 512, 512
+        a, za, sa, w, ws, bias = _problem(rng, M, N, K, True)
+        at, wt, wst, bt = (torch.from_numpy(v).to(dev) for v in (a, w, ws, bias))
+        rs = wt.sum(dim=1, dtype=torch.int32)
+        y = consumers.qlinear_i8(at, za, sa, wt, wst, rs, bt)
+        for out in ((0.05, 3, -128, 127), (0.11, 100, 0, 255), (0.5, 0, -8, 7)):
+            got = consumers.qlinear_i8(at, za, sa, wt, wst, rs, bt, out)
+            want_codes = ops.fq_codes(y, None, None, None, out[2], out[3], out[0], out[1])
+            assert got.dtype == want_codes.dtype and torch.equal(got, want_codes), out
+        if variant:
+            a, za, sa, w, ws, bias = _problem(rng, 300, 256, 256, True)                 # ragged rows: refused, not misread
+            at, wt, wst = (torch.from_numpy(v).to(dev) for v in (a, w, ws))
+            rs = wt.sum(dim=1, dtype=torch.int32)
+            yb = torch.empty(300, 256, device=dev)
+            rc = lib.mctq_qlinear_i8(at.data_ptr(), native.CODE_U8, za, sa, wt.data_ptr(), wst.data_ptr(), rs.data_ptr(), None,
+                                     yb.data_ptr(), 300, 256, 256, torch.cuda.current_stream().cuda_stream)
+            assert rc == native.MCTQ_E_ARG
+    finally:
+        lib.mctq_set_tuning(b"ql_variant", 0)
 
 
 @pytest.mark.gpu
