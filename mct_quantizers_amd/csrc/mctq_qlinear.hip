@@ -515,14 +515,14 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Many rows AND many columns: the 64 x 64 wave tile above needs 8 KB of LDS reads per 256 MFMA cycles and wave --
-// with the direct-to-LDS copies more than the CU's 128 B/clk, so it is LDS-bound near a third of the int8 peak.
-// Here one wave owns (16 TM) x (16 TN) outputs (128 x 128 for the 256 x 256 block tile: 16 KB of reads per 1024
-// MFMA cycles, half the LDS bandwidth with 4 waves), accumulators in the 512-register file of a 1-wave-per-SIMD block.
+// Many rows AND many columns: the 64 x 64 wave tile above needs 8 KB of LDS reads per 256 MFMA cycles and wave; with
+// two blocks per CU and the direct-to-LDS copies that is most of the LDS bandwidth, and the kernel stays near a third
+// of the int8 peak.  Here one wave owns (16 TM) x (16 TN) outputs (128 x 128 for the 256 x 256 block tile: 16 KB of
+// reads per 1024 MFMA cycles), accumulators in the 512-register file of a 1-wave-per-SIMD block.
 // K advances in 64-byte steps through a ring of 4 LDS stages: stage kt is multiplied from registers (its fragments were
 // read during stage kt-1), stage kt+1 is certified by the one barrier of the iteration (placed in the middle of the
 // MFMA stream, so the matrix pipe has work queued while waves meet), stages kt+2 and kt+3 are in flight.
-// Whole tiles only (M % BM == N % BN == K % 64 == 0); other shapes use the kernels above.
+// Whole tiles only (M % BM == N % BN == K % 128 == 0); other shapes use the kernels above.
 // ------------------------------------------------------------------------------------------------
 template <int I, int N, class F>
 __device__ __forceinline__ void ql_static_for(F&& f) {
