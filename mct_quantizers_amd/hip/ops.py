@@ -591,6 +591,7 @@ _op_tables = {}
 
 
 def _op_table(lut, mult, cmin, cmax):
+    """(decision table | None, threshold list | None) of a codebook tensor."""
     import weakref
     key = (id(lut), mult, cmin, cmax)
     hit = _op_tables.get(key)
@@ -598,22 +599,30 @@ def _op_table(lut, mult, cmin, cmax):
         return hit[2]
     if len(_op_tables) > 256:
         _op_tables.clear()
-    table = make_lut_table(lut.detach().cpu().numpy(), mult, cmin, cmax, lut.device)
+    lut_np = lut.detach().cpu().numpy()
+    table = make_lut_table(lut_np, mult, cmin, cmax, lut.device)
+    books = (table, None if table is not None else make_lut_steps(lut_np, mult, cmin, cmax, lut.device))
     try:
-        _op_tables[key] = (weakref.ref(lut), lut._version, table)
+        _op_tables[key] = (weakref.ref(lut), lut._version, books)
     except TypeError:                                   # not weak-referenceable: do not cache
         pass
-    return table
+    return books
 
 
 def _op_hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round=0):
-    return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax,
-                               None if x.dtype == torch.float64 else _op_table(lut, mult, cmin, cmax), step_round)
+    if x.dtype == torch.float64:
+        # the schema's float is a double: the activation quantizer's double divisor arrives intact, and a weights
+        # quantizer's float32 divisor is the same number either way
+        return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, None, 0, thr_div)
+    table, steps = _op_table(lut, mult, cmin, cmax)
+    return _hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, table, step_round, None, steps)
 
 
 def _op_hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax):
-    return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax,
-                                None if x.dtype == torch.float64 else _op_table(lut, mult, cmin, cmax))
+    if x.dtype == torch.float64:
+        return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, None)
+    table, steps = _op_table(lut, mult, cmin, cmax)
+    return _hip_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax, table, steps)
 
 
 def _cpu_fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax):
@@ -649,7 +658,12 @@ def _tracing() -> bool:
     return torch._C._get_tracing_state() is not None
 
 
+_compiling = torch.compiler.is_compiling      # dynamo / export in progress: the graph must see torch.ops.mctq_amd.*
+
+
 def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
+    if _compiling():
+        return torch.ops.mctq_amd.fq_per_tensor(x, scale, zero_point, qmin, qmax)
     f = _FAST if _FAST_READY else _fast_mod()
     if f is not None:
         y = f.fq_per_tensor(x, scale, zero_point, qmin, qmax)
@@ -669,6 +683,8 @@ def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
 def fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
     """``torch.fake_quantize_per_tensor_affine(x, scale_tensor, zero_point_tensor, qmin, qmax)``: the parameters are
     1-element tensors (float32 / int32) that the kernel reads on the device."""
+    if _compiling():
+        return torch.ops.mctq_amd.fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
     f = _FAST if _FAST_READY else _fast_mod()
     if f is not None:
         y = f.fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
@@ -686,6 +702,8 @@ def fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
 
 
 def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero_zps: bool = False):
+    if _compiling():
+        return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
     f = _FAST if _FAST_READY else _fast_mod()
     if f is not None:
         y = f.fq_per_channel(x, scales, None if zero_zps else zero_points, axis, qmin, qmax)
@@ -731,6 +749,9 @@ def fq_batched(items):
 
 def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
                    step_round: int = 0, thr_div64: float = None, steps=None):
+    if _compiling():
+        return torch.ops.mctq_amd.lut_per_tensor(x, lut, thr_div if thr_div64 is None else thr_div64, thr_mul, mult, cmin,
+                                                 cmax, max(step_round, 0))
     if _is_real(x):
         if _tracing():                                        # the reference's own op chain is what gets recorded
             return _cpu_lut_per_tensor(x, lut, thr_div if thr_div64 is None else thr_div64, thr_mul, mult, cmin, cmax,
@@ -745,6 +766,8 @@ def lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: fl
 
 def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float, table=None,
                     steps=None):
+    if _compiling():
+        return torch.ops.mctq_amd.lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)
     if _is_real(x):
         if _tracing():
             return _cpu_lut_per_channel(x, lut, thresholds, eps, axis, mult, cmin, cmax)

@@ -38,6 +38,9 @@ def _takes_training_flag(quantizer) -> bool:
     return flag
 
 
+_is_compiling = torch.compiler.is_compiling
+
+
 class PytorchQuantizationWrapper(nn.Module):
     """Wrap a layer (or a function with constant inputs) and fake-quantize its weights on every forward.
 
@@ -137,7 +140,7 @@ class PytorchQuantizationWrapper(nn.Module):
                 owner, name = self.layer, key
             else:
                 owner, name = self, f'{QUANTIZED_POSITIONAL_WEIGHT}_{key}'
-            d = getattr(owner, "__dict__", None)
+            d = None if _is_compiling() else getattr(owner, "__dict__", None)
             if d is not None and name in d and isinstance(value, torch.Tensor) and not isinstance(value, nn.Parameter):
                 d[name] = value
             else:
@@ -150,8 +153,9 @@ class PytorchQuantizationWrapper(nn.Module):
         if self._weights_vars:
             # tensors a batched launch has already prepared for THIS forward (pytorch/batching.py); used once
             d = self.__dict__
-            ready = d.pop("_prequantized", None)
-            if ready is None:
+            # (torch.compile traces the plain per-layer calls: none of this bookkeeping belongs in a graph)
+            ready = None if _is_compiling() else d.pop("_prequantized", None)
+            if ready is None and not _is_compiling():
                 # reuse_buffers mode: (generation cell, {name: persistent tensor}); valid once per generation, i.e.
                 # only for the forward whose pre-hook has just re-quantized into those tensors
                 plan = d.get("_prequantized_plan")

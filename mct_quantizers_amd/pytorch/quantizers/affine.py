@@ -288,7 +288,16 @@ class _WeightsAffineMixin:
                 self.max_quantized_domain)
 
     def _quantize_weights(self, inputs: torch.Tensor) -> torch.Tensor:
-        inputs.requires_grad = False            # the reference flips this on the caller's tensor
+        if inputs.requires_grad:                # the reference flips this on the caller's tensor (read first: a tensor
+            inputs.requires_grad = False        # that already has it off stays traceable by dynamo)
+        if _is_compiling():
+            # torch.compile: the graph records the library ops on the public attributes, as the reference's call sites
+            # read them (weights_symmetric_inferable_quantizer.py:139-151); no launch-state bookkeeping in a graph
+            if self.per_channel:
+                return ops.fq_per_channel(inputs, self.scales.flatten(), self.zero_points.flatten(), self.channel_axis,
+                                          self.min_quantized_domain, self.max_quantized_domain)
+            return ops.fq_per_tensor_tqp(inputs, self.scales, self.zero_points, self.min_quantized_domain,
+                                         self.max_quantized_domain)
         self._current()
         d = self.__dict__
         plan = d["_plan"]

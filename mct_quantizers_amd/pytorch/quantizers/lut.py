@@ -110,7 +110,8 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
             return self._remember(getattr(onnx_export, self._export_function).apply(
                 inputs, self.num_bits, self._lut_values_np, self._threshold_np, self.lut_values_bitwidth, self.eps,
                 self.per_channel, self.channel_axis, self.input_rank))
-        inputs.requires_grad = False
+        if inputs.requires_grad:                # (read first: a tensor that already has it off stays traceable by dynamo)
+            inputs.requires_grad = False
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, True)
         if self.per_channel:
             if self.input_rank != inputs.dim():

@@ -896,3 +896,37 @@ def test_wide_codebook_quantizer_classes_take_the_threshold_list(lib):
     got = ops.lut_per_tensor(_dev(w_np), _dev(np.float32([-100.5, 3.25, 7.0, 900.0])), 1.5, 1.5, 2048.0, -2048.0, 2047.0)
     assert "LutOp" in native.last_launch(), native.last_launch()
     assert bits_equal(got.cpu().numpy(), O.lut_quantize(w_np, [-100.5, 3.25, 7.0, 900.0], np.float32([1.5]), True, 12, 0.0))
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.compile (aot_eager): the traced graph calls the mctq_amd:: library ops, which launch the HIP kernels
+# ---------------------------------------------------------------------------------------------
+
+def test_torch_compile_runs_the_hip_ops_on_the_gpu(lib):
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(64, 24).cuda()
+    thr = [0.5 + 0.05 * i for i in range(24)]
+    lut = [-128.0, -64.0, -20.0, -5.0, 0.0, 5.0, 20.0, 64.0]
+    m = torch.nn.Sequential(
+        mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])),
+        mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)}),
+        mq.PytorchActivationQuantizationHolder(Q.ActivationLutPOTInferableQuantizer(3, lut, [4.0], True)),
+    ).cuda()
+    x = torch.randn(32, 64, device="cuda")
+    want = m(x)
+    torch._dynamo.reset()
+    cm = torch.compile(m, backend="aot_eager", fullgraph=True)         # one graph: no break at any quantizer
+    got = cm(x)
+    assert torch.equal(got, want)
+    ex = torch._dynamo.explain(m)(x)
+    targets = [str(n.target) for g in ex.graphs for n in g.graph.nodes if n.op == "call_function"]
+    assert ex.graph_break_count == 0 and {"mctq_amd.fq_per_tensor", "mctq_amd.fq_per_channel", "mctq_amd.lut_per_tensor"} <= set(targets)
+    assert "kernel" in native.last_launch()                              # a HIP kernel of this library ran last
+    # each quantizer's own output inside the compiled graph is the oracle's
+    xq = torch.compile(m[0], backend="aot_eager")(x)
+    s, z, qmin, qmax, _, _ = O.activation_uniform_params(8, [-2.5], [3.1])
+    assert bits_equal(xq.cpu().numpy(), O.fake_quant_affine(x.cpu().numpy(), np.float32(s), z, qmin, qmax))

@@ -277,9 +277,13 @@ def test_torch_compile_traces_through_the_custom_ops():
         PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 8, True, 0)}),
         PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])))
     x = torch.randn(4, 16)
-    want = m(x)
-    torch._dynamo.reset()
-    assert torch.equal(torch.compile(m, backend="aot_eager")(x), want)
+    want = m(x)                                        # (the first call turns requires_grad off on the weights, as the
+    torch._dynamo.reset()                              # reference does -- an attribute write dynamo would break on)
+    assert torch.equal(torch.compile(m, backend="aot_eager", fullgraph=True)(x), want)
+    ex = torch._dynamo.explain(m)(x)
+    targets = [str(n.target) for g in ex.graphs for n in g.graph.nodes if n.op == "call_function"]
+    assert ex.graph_count == 1 and ex.graph_break_count == 0
+    assert "mctq_amd.fq_per_channel" in targets and "mctq_amd.fq_per_tensor" in targets
 
 
 def test_versioned_reuse_requantizes_only_when_the_weight_changes():
