@@ -164,11 +164,21 @@ struct AffineOp {
   __device__ __forceinline__ Book setup(float*) const { return Book(); }
   __device__ __forceinline__ static bool can_fast(const Param&) { return true; }
 
+  // (clamp(r + z, lo, hi) - z) * s with r = rint(x * inv), evaluated as fma(med3(r, lo - z, hi - z), s, +0):
+  // four VALU ops per element instead of seven, and the shifted bounds are loop-invariant per parameter set.
+  // Identical bit for bit: r and z are integers, so r + z is exact wherever it lies inside [lo, hi] (|.| <= 2^24)
+  // and rounds monotonically outside, where both forms saturate to fl(lo - z) / fl(hi - z) -- the very rounding the
+  // subtraction q - z performs; v_med3_f32 answers min(lo - z, hi - z) for a NaN as fmax(NaN, lo) answers lo; and the
+  // +0 of the fma turns the -0 of a tiny negative x back into the +0 that (q - z) * s yields.
   template <bool FAST = true>
   __device__ __forceinline__ float apply(float x, const Param& p, const Book&) const {
-    float q = __builtin_rintf(x * p.inv) + p.zf;      // v_rndne_f32: ties to even
-    q = fminf(fmaxf(q, lo), hi);                      // NaN -> lo, +inf -> hi, -inf -> lo
-    return (q - p.zf) * p.s;
+    const float r = __builtin_rintf(x * p.inv);       // v_rndne_f32: ties to even
+    const float q = __builtin_amdgcn_fmed3f(r, lo - p.zf, hi - p.zf);   // NaN -> lo - z, +inf -> hi - z, -inf -> lo - z
+    float y = __builtin_fmaf(q, p.s, 0.0f);
+    // The product is a float32 VALUE before any narrowing: for half-precision outputs the compiler would otherwise fold
+    // the fma and the conversion into one v_fma_mix with a single rounding, where ATen rounds to float32 and then to half.
+    asm("" : "+v"(y));
+    return y;
   }
 };
 
