@@ -419,6 +419,7 @@ struct LutTableOp : LutCommon {
   const float* __restrict__ table;     // device, (entries + 1) x 2 words
   int entries;
   float koff;                          // 0.5 - 2*clip_min
+  float kmax;                          // entries - 1
 
   typedef LutTableBook Book;
   __device__ __forceinline__ uint32_t book_words() const { return ((uint32_t)(entries + 1) * 2u + 3u) & ~3u; }
@@ -438,8 +439,8 @@ struct LutTableOp : LutCommon {
   template <bool FAST>
   __device__ __forceinline__ void locate(float x, const Param& p, float& v, int& k) const {
     v = scaled<FAST>(x, p);
-    const int kk = (int)__builtin_fmaf(v, 2.0f, koff);  // nearest half-integer point (any tie is fine); saturating
-    k = min(max(kk, 0), entries - 1);
+    // nearest half-integer point (any tie is fine), clamped as a float (one v_med3_f32; NaN -> 0) before the conversion
+    k = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(v, 2.0f, koff), 0.0f, kmax);
   }
   // stage 3: pick the side of the step, dequantize
   template <bool FAST>
@@ -1294,7 +1295,7 @@ inline int make_table_op(LutTableOp& op, const float* thr, float eps, const floa
   if (int rc = check_pow2(mult)) return rc;
   if (entries != table_entries(cmin, cmax)) return fail_arg("entries does not match the clip range");
   fill_lut_common(op, thr, eps, mult, cmin, cmax, step_round);
-  op.table = table; op.entries = entries; op.koff = 0.5f - 2.0f * cmin;
+  op.table = table; op.entries = entries; op.koff = 0.5f - 2.0f * cmin; op.kmax = (float)(entries - 1);
   return 0;
 }
 inline size_t table_bytes(int32_t entries) { return (size_t)(((entries + 1) * 2 + 3) & ~3) * 4; }
