@@ -394,7 +394,8 @@ PyTypeObject AffinePlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 //      plan = LutPlan(table, thr_div_f32, thr_div_f16, thr_div_bf16, thr_mul, mult, clip_min, clip_max, half_steps);
 //      plan(x) -> float32 tensor | NotImplemented.  The divisor depends on the tensor's type because the reference
 //      narrows the Python-float `threshold + eps` to it (activation_lut_pot_inferable_quantizer.py:86-91);
-//      half_steps != 0: a half-precision tensor also rounds the quotient and the scaled value to its own type.
+//      half_steps != 0: a half-precision tensor also rounds the quotient and the scaled value to its own type;
+//      half_steps == 2: half-precision tensors are declined (NotImplemented) -- their clip bounds differ from the table's.
 struct LutPlan {
   PyObject_HEAD
   vectorcallfunc vectorcall;
@@ -414,6 +415,7 @@ PyObject* lutplan_vectorcall(PyObject* self, PyObject* const* args, size_t nargs
   int dt;
   const at::Tensor* xp = eligible(args[0], &dt);
   if (!xp || dt == MCTQ_DT_F64) return not_implemented();
+  if (p->half_steps == 2 && dt != MCTQ_DT_F32) return not_implemented();   // clip bounds not exact in a half type: general route
   const at::Tensor& x = *xp;
   const at::Tensor* tp = param_tensor(p->table, x, c10::ScalarType::Float, -1);
   if (!tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();

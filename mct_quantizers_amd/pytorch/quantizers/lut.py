@@ -141,6 +141,15 @@ class WeightsLUTPOTInferableQuantizer(WeightsLUTSymmetricInferableQuantizer):
         assert _is_pot(self._threshold_np), f'Expected threshold to be power of 2 but is {threshold}'
 
 
+def _bounds_in(dt, cmin: float, cmax: float):
+    """(clip_min, clip_max) as torch.clip sees them on a tensor of type ``dt``: converted to that type -- or the
+    message of the RuntimeError torch raises when a bound does not fit it."""
+    if dt is torch.float16 and max(abs(cmin), abs(cmax)) > 65504.0:
+        return "value cannot be converted to type c10::Half without overflow"
+    lo, hi = (float(torch.tensor(v, dtype=torch.float64).to(dt)) for v in (cmin, cmax))
+    return lo, hi
+
+
 @mark_quantizer(quantization_target=QuantizationTarget.Activation,
                 quantization_method=[QuantizationMethod.LUT_POT_QUANTIZER],
                 identifier=QuantizerID.INFERABLE)
@@ -175,11 +184,16 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         # (the decision table is compiled from them).
         plan = False
         fast = ops._fast_mod() if self._lut_table_torch is not None else None
+        mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
+        # torch.clip on a half-precision tensor converts the bounds to the tensor's type (quantizer_utils.py:129): bounds
+        # that are not exact there (511 -> 512 in bfloat16; 65535 does not fit float16 at all) are another clip range,
+        # which the codebook's table / threshold list was not built for
+        self._clip_by_dtype = {dt: _bounds_in(dt, cmin, cmax) for dt in (torch.float16, torch.bfloat16)}
+        exact = all(b == (cmin, cmax) for b in self._clip_by_dtype.values())
         if fast is not None:
-            mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
             d = self._thr_div_by_dtype
             plan = fast.LutPlan(self._lut_table_torch, d[torch.float32], d[torch.float16], d[torch.bfloat16],
-                                self._thr_mul0, mult, cmin, cmax, 1)
+                                self._thr_mul0, mult, cmin, cmax, 1 if exact else 2)
         self.__dict__["_plan"] = plan
 
     def __call__(self, inputs: torch.Tensor):
@@ -198,5 +212,13 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         thr_div = self._thr_div_by_dtype.get(dt, self._thr_div_by_dtype[torch.float32])
         # a float64 tensor divided by the Python-float threshold + eps: the divisor stays a double
         div64 = float(self.threshold) + self.eps if dt is torch.float64 else None
+        if step:
+            bounds = self.__dict__.get("_clip_by_dtype", {}).get(dt) or _bounds_in(dt, cmin, cmax)
+            if isinstance(bounds, str):
+                raise RuntimeError(bounds)                    # what torch.clip raises for this tensor type
+            if bounds != (cmin, cmax):                        # the tensor type's own clip range and its own table
+                table, steps = ops._op_table(self.lut_values, mult, bounds[0], bounds[1])
+                return ops.lut_per_tensor(inputs, self.lut_values, thr_div, self._thr_mul0, mult, bounds[0], bounds[1],
+                                          table, step, None, steps)
         return ops.lut_per_tensor(inputs, self.lut_values, thr_div, self._thr_mul0, mult, cmin, cmax,
                                   self._lut_table_torch, step, div64, self.__dict__.get("_lut_steps_torch"))

@@ -235,6 +235,14 @@ def lut_quantize(x: np.ndarray, lut_values, threshold, signed: bool,
     else:
         cmin, cmax = F32(0), F32(2 ** lut_values_bitwidth - 1)
 
+    if step_dtype != "float32":
+        # torch.clip(half_tensor, min=python_float, max=python_float) converts the bounds to the tensor's type
+        # (quantizer_utils.py:129): 2^k - 1 is not exact in bfloat16 beyond 8 bits, nor in float16 beyond 11, and
+        # 65535 does not fit float16 at all -- torch raises then (pinned by tests/golden/cases_half_bounds.*)
+        if step_dtype == "float16" and max(abs(float(cmin)), abs(float(cmax))) > 65504.0:
+            raise RuntimeError("value cannot be converted to type c10::Half without overflow")
+        cmin, cmax = (F32(narrow(np.asarray([b], dtype=F32), step_dtype)[0]) for b in (cmin, cmax))
+
     if isinstance(threshold, (float, int)):
         thr_mul = np.broadcast_to(F32(threshold), x.shape)
         div = F32(float(threshold) + eps)                                  # double add, then fp32

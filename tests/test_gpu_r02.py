@@ -930,3 +930,122 @@ def test_torch_compile_runs_the_hip_ops_on_the_gpu(lib):
     xq = torch.compile(m[0], backend="aot_eager")(x)
     s, z, qmin, qmax, _, _ = O.activation_uniform_params(8, [-2.5], [3.1])
     assert bits_equal(xq.cpu().numpy(), O.fake_quant_affine(x.cpu().numpy(), np.float32(s), z, qmin, qmax))
+
+
+# ---------------------------------------------------------------------------------------------
+# fuzz of the LUT quantizer classes: table / threshold-list / float64 kernels vs the torch op chain on CPU and the oracle
+# ---------------------------------------------------------------------------------------------
+
+def test_fuzz_lut_quantizers_shapes_axes_layouts_dtypes_and_codebook_widths(lib):
+    """Seeded fuzz over ranks, shapes, channel axes (negative ones too), permuted storage, gapped views, storage types,
+    codebook sizes and lut_values_bitwidth 4..16: the HIP result equals the op chain the reference runs on the CPU copy of
+    the same tensor (this package's CPU route = torch ops in the reference's order), and, for float32, the oracle."""
+    import os
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "77")))
+    seen = set()
+    for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "120"))):
+        rank = int(rng.integers(1, 5))
+        shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 64])) for _ in range(rank)]
+        if rng.random() < 0.3:
+            shape[int(rng.integers(0, rank))] = int(rng.choice([257, 1024, 1030, 4096]))
+        if int(np.prod(shape, dtype=np.int64)) > (1 << 22):
+            continue
+        B = int(rng.choice([4, 8, 8, 10, 12, 16]))
+        nb = int(rng.integers(1, min(B, 6) + 1))
+        dt = [torch.float32, torch.float32, torch.float16, torch.bfloat16, torch.float64][int(rng.integers(0, 5))]
+        kind = int(rng.integers(0, 3))                       # 0 weights per channel, 1 weights per tensor, 2 activation
+        signed = True if kind < 2 else bool(rng.integers(0, 2))
+        lo, hi = (-2 ** (B - 1), 2 ** (B - 1)) if signed else (0, 2 ** B + 1)
+        lut = [float(v) for v in rng.choice(np.arange(lo, hi), int(rng.integers(1, 2 ** nb + 1)), replace=False)]
+        axis = int(rng.integers(0, rank))
+        x = (torch.from_numpy(rng.standard_normal(shape).astype(np.float32)) * 1.5).to(dt)
+        perm = list(rng.permutation(rank))
+        x = x.permute(perm).contiguous().permute(list(np.argsort(perm)))
+        if rng.random() < 0.2 and shape[0] > 1:
+            x = x[::2]
+        C = x.shape[axis]
+        if kind == 0:
+            thr = [float(v) for v in rng.uniform(0.3, 3.0, size=C)]
+            ax = axis - rank if rng.random() < 0.3 else axis
+            q = Q.WeightsLUTSymmetricInferableQuantizer(nb, lut, thr, True, ax, rank, lut_values_bitwidth=B)
+        elif kind == 1:
+            thr = [float(2.0 ** rng.integers(-2, 3))]
+            q = Q.WeightsLUTPOTInferableQuantizer(nb, lut, thr, False, lut_values_bitwidth=B)
+        else:
+            thr = [float(2.0 ** rng.integers(-2, 3))]
+            q = Q.ActivationLutPOTInferableQuantizer(nb, lut, thr, signed, lut_values_bitwidth=B)
+        # CPU copy of the tensor and of the parameters: torch ops in the reference's order (ops._cpu_lut_*)
+        from mct_quantizers_amd.hip import ops
+        from mct_quantizers_amd.pytorch.quantizers.lut import lut_domain
+        mult, cmin, cmax = lut_domain(B, signed)
+        lut_t = torch.tensor(lut, dtype=torch.float32)
+        if kind == 0:
+            want = ops._cpu_lut_per_channel(x.clone(), lut_t, torch.tensor(thr, dtype=torch.float32), 1e-8, axis, mult, cmin, cmax)
+        elif kind == 1:
+            want = ops._cpu_lut_per_tensor(x.clone(), lut_t, q._thr_div0, q._thr_mul0, mult, cmin, cmax, 0)
+        else:
+            step = {torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}.get(dt, 0)
+            try:
+                want = ops._cpu_lut_per_tensor(x.clone(), lut_t, float(thr[0]) + 1e-8, q._thr_mul0, mult, cmin, cmax, step or -1)
+            except RuntimeError as e:                         # float16 tensor, clip bound 65535: torch refuses; so do we
+                with pytest.raises(RuntimeError) as e2:
+                    q(x.cuda())
+                assert str(e2.value) == str(e)
+                continue
+        got = q(x.cuda())
+        seen.add(native.last_launch().split("<")[1].split(",")[0] if "<" in native.last_launch() else native.last_launch())
+        info = (case, tuple(x.shape), x.stride(), axis, dt, kind, B, len(lut))
+        assert got.dtype == want.dtype and got.shape == want.shape, info
+        if dt in (torch.float16, torch.bfloat16) and kind == 2:
+            ok = finite_equal(got.float().cpu().numpy(), want.float().numpy(), x.float().numpy())
+        else:
+            ok = bits_equal(got.float().cpu().numpy(), want.float().numpy())
+        assert ok, (info, first_mismatch(got.float().cpu().numpy(), want.float().numpy(), x.float().numpy()))
+        if dt is torch.float32:
+            thr_o = np.float32(thr) if kind < 2 else thr[0]
+            w = O.lut_quantize(x.numpy(), lut, thr_o, signed, B, 1e-8, per_channel=(kind == 0),
+                               channel_axis=(axis if kind == 0 else None))
+            assert bits_equal(got.cpu().numpy(), w), info
+    assert {"LutTableOp", "LutStepsOp"} <= seen, seen
+
+
+def test_half_activation_lut_clip_bounds_follow_the_tensor_type(lib):
+    """float16 / bfloat16 activations with lut_values_bitwidth 9..16 (reference fixtures, cases_half_bounds): the clip
+    range is the one torch.clip uses on that tensor type (511 -> 512 in bfloat16 ...), served by a decision table /
+    threshold list built for THAT range; the float16 configuration torch refuses raises the same RuntimeError."""
+    import json
+    import warnings
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    Q = mq.pytorch_quantizers
+    with open(os.path.join(GOLDEN, "cases_half_bounds.json")) as f:
+        cases = json.load(f)["cases"]
+    arrays = np.load(os.path.join(GOLDEN, "cases_half_bounds.npz"))
+    kinds = set()
+    for c in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = Q.ActivationLutPOTInferableQuantizer(**c["kwargs"])
+        x32 = arrays[c["id"] + "_x"]
+        x = _dev(x32).to(getattr(torch, c["in_dtype"]))
+        if "error" in c:
+            with pytest.raises(RuntimeError) as e:
+                q(x)
+            assert str(e.value) == c["error"]
+            continue
+        y = q(x)
+        kinds.add(native.last_launch().split("<")[1].split(",")[0])
+        want = arrays[c["id"] + "_y"]
+        assert y.is_cuda and str(y.dtype) == "torch." + c["out_dtype"], c["id"]
+        assert finite_equal(y.float().cpu().numpy(), want, x32), (c["id"], first_mismatch(y.float().cpu().numpy(), want, x32))
+        # the float32 twin of the same quantizer keeps the float32 range
+        y32 = q(_dev(x32))
+        from oracle import mctq_oracle as O
+        kw = c["kwargs"]
+        assert bits_equal(y32.cpu().numpy(), O.lut_quantize(x32, kw["lut_values"], kw["threshold"][0], kw["signed"],
+                                                            kw["lut_values_bitwidth"], 1e-8))
+    assert kinds <= {"LutTableOp", "LutStepsOp"} and kinds, kinds

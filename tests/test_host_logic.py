@@ -448,3 +448,27 @@ def test_lut_quantizer_accepts_a_negative_channel_axis():
     a = lut_quantizer(x, lut, True, thr, 8, 1e-8, per_channel=True, channel_axis=-1, input_rank=3)
     b = lut_quantizer(x, lut, True, thr, 8, 1e-8, per_channel=True, channel_axis=2, input_rank=3)
     assert torch.equal(a, b)
+
+
+def test_half_activation_lut_on_cpu_tensors_matches_the_reference_fixtures():
+    """CPU tensors take the torch op chain of the reference; float16 / bfloat16 activations with wide codebooks incl. the
+    configuration torch refuses (tests/golden/cases_half_bounds.*, generated from the reference)."""
+    import json
+    import os
+    import warnings
+    from conftest import GOLDEN, bits_equal
+    with open(os.path.join(GOLDEN, "cases_half_bounds.json")) as f:
+        cases = json.load(f)["cases"]
+    arrays = np.load(os.path.join(GOLDEN, "cases_half_bounds.npz"))
+    for c in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = Q.ActivationLutPOTInferableQuantizer(**c["kwargs"])
+        x = torch.from_numpy(arrays[c["id"] + "_x"]).to(getattr(torch, c["in_dtype"]))
+        if "error" in c:
+            with pytest.raises(RuntimeError) as e:
+                q(x)
+            assert str(e.value) == c["error"]
+            continue
+        y = q(x)
+        assert str(y.dtype) == "torch." + c["out_dtype"] and bits_equal(y.float().numpy(), arrays[c["id"] + "_y"]), c["id"]

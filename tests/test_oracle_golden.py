@@ -173,3 +173,29 @@ def test_oracle_matches_reference_float64_cases():
         assert got.dtype == want.dtype and np.array_equal(got.view(view), want.view(view)), c["id"]
         kinds.add((c["cls"], bool(c["kwargs"].get("per_channel"))))
     assert len(kinds) >= 12        # all nine classes, per-tensor and per-channel where they exist
+
+
+def test_oracle_half_activation_lut_clip_bounds_in_the_tensor_type():
+    """ActivationLutPOT on float16 / bfloat16 tensors with lut_values_bitwidth 9..16: torch.clip's bounds are converted
+    to the tensor's type (511 -> 512 in bfloat16, 4095 -> 4096 in float16, 65535 -> RuntimeError in float16).  Fixtures
+    generated from the reference (tools/gen_golden.py --half-bounds-only)."""
+    import json
+    import os
+    import numpy as np
+    import pytest
+    from conftest import GOLDEN, bits_equal
+    from oracle import mctq_oracle as O
+    with open(os.path.join(GOLDEN, "cases_half_bounds.json")) as f:
+        cases = json.load(f)["cases"]
+    arrays = np.load(os.path.join(GOLDEN, "cases_half_bounds.npz"))
+    assert len(cases) == 14 and sum("error" in c for c in cases) == 1
+    for c in cases:
+        kw = c["kwargs"]
+        x = arrays[c["id"] + "_x"]
+        call = lambda: O.lut_quantize(x, kw["lut_values"], kw["threshold"][0], kw["signed"], kw["lut_values_bitwidth"], 1e-8,  # noqa: E731
+                                      step_dtype=c["in_dtype"])
+        if "error" in c:
+            with pytest.raises(RuntimeError, match="without overflow"):
+                call()
+            continue
+        assert bits_equal(call(), arrays[c["id"] + "_y"]), c["id"]

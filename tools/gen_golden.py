@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--pickles-only", action="store_true")
     ap.add_argument("--half-only", action="store_true")
+    ap.add_argument("--half-bounds-only", action="store_true")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     gen_affine_cases()
@@ -487,6 +488,51 @@ def gen_half_cases():
     with open(os.path.join(OUT, "cases_half.json"), "w") as f:
         json.dump(dict(meta=dict(generator="tools/gen_golden.py", torch=torch.__version__), cases=hc), f, indent=1)
     print(len(hc), "half-precision cases")
+
+
+def gen_half_bounds_cases():
+    """Half-precision ACTIVATIONS through ActivationLutPOT with lut_values_bitwidth > 8: torch.clip converts the clip
+    bounds to the tensor's type (quantizer_utils.py:129), so 2^k - 1 becomes 2^k in bfloat16 (and in float16 from 12 bits
+    on) and 65535 does not fit float16 at all (RuntimeError).  Inputs sit around the top and bottom of the clip range;
+    stored widened to float32 like cases_half."""
+    hc, ha = [], {}
+    g = np.random.default_rng(4242)
+    for dt_name in ("float16", "bfloat16"):
+        dt = getattr(torch, dt_name)
+        for B, signed in ((9, False), (10, True), (10, False), (12, True), (12, False), (16, True), (16, False)):
+            mult = float(2 ** (B - int(signed)))
+            cmin, cmax = (float(-2 ** (B - 1)), float(2 ** (B - 1) - 1)) if signed else (0.0, float(2 ** B - 1))
+            top = int(cmax)
+            lo_c = int(cmin)
+            # centres that make the two candidate clip bounds decide differently, plus a spread
+            lut = sorted({top - 3, top - 1, top if signed else top + 1, lo_c, lo_c + 2, 0, top // 2, top // 3})
+            lut = [float(v) for v in g.permutation(lut)]
+            nb = int(np.ceil(np.log2(len(lut))))
+            thr = [float(2.0 ** g.integers(-1, 3))]
+            u = np.concatenate([g.uniform(-1.3, 1.3, 600), (cmax + g.integers(-6, 7, 200)) / mult,
+                                (cmin + g.integers(-6, 7, 100)) / mult, [0.0, 1.0, -1.0, 0.999, 1.001]]).astype(np.float32)
+            x32 = (u * np.float32(thr[0])).astype(np.float32).reshape(5, -1)
+            xt = torch.from_numpy(np.ascontiguousarray(x32)).to(dt)
+            kwargs = dict(num_bits=nb, lut_values=lut, threshold=thr, signed=signed, lut_values_bitwidth=B)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                q = refq.ActivationLutPOTInferableQuantizer(**kwargs)
+            cid = f"hb{len(hc):03d}"
+            rec = dict(id=cid, cls="ActivationLutPOTInferableQuantizer", kwargs=kwargs, shape=list(x32.shape), in_dtype=dt_name)
+            ha[cid + "_x"] = xt.float().numpy()
+            try:
+                y = q(xt.clone())
+                ha[cid + "_y"] = y.detach().float().numpy()
+                rec["out_dtype"] = str(y.dtype).replace("torch.", "")
+            except RuntimeError as e:
+                rec["error"] = str(e)
+            hc.append(rec)
+    np.savez_compressed(os.path.join(OUT, "cases_half_bounds.npz"), **ha)
+    meta = dict(reference="sony/mct_quantizers v%s" % ref.__version__, torch=torch.__version__, numpy=np.__version__,
+                generator="tools/gen_golden.py --half-bounds-only")
+    with open(os.path.join(OUT, "cases_half_bounds.json"), "w") as f:
+        json.dump(dict(meta=meta, cases=hc), f, indent=1)
+    print(f"{len(hc)} half-bounds cases ({sum('error' in c for c in hc)} raising), {sum(a.nbytes for a in ha.values())} array bytes")
 
 
 def gen_f64_cases():
@@ -890,6 +936,8 @@ if __name__ == "__main__":
     if "--pickles-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         gen_pickled_reference_models()
+    elif "--half-bounds-only" in sys.argv:
+        gen_half_bounds_cases()
     elif "--half-only" in sys.argv:
         gen_half_cases()
     elif "--export-only" in sys.argv:
