@@ -1049,3 +1049,61 @@ def test_half_activation_lut_clip_bounds_follow_the_tensor_type(lib):
         assert bits_equal(y32.cpu().numpy(), O.lut_quantize(x32, kw["lut_values"], kw["threshold"][0], kw["signed"],
                                                             kw["lut_values_bitwidth"], 1e-8))
     assert kinds <= {"LutTableOp", "LutStepsOp"} and kinds, kinds
+
+
+def test_fuzz_affine_bit_widths_signs_and_every_class_against_aten_cpu(lib):
+    """Seeded fuzz over num_bits 1..16, all six affine classes (per tensor and per channel, signed and unsigned), storage
+    types and permuted layouts: the HIP result equals ATen's CPU operator on the same tensor with the same parameters."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "99")))
+    for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "150"))):
+        rank = int(rng.integers(1, 5))
+        shape = [int(rng.choice([1, 2, 3, 5, 8, 16, 33, 64])) for _ in range(rank)]
+        if rng.random() < 0.25:
+            shape[int(rng.integers(0, rank))] = int(rng.choice([257, 1024, 1030, 4096]))
+        if int(np.prod(shape, dtype=np.int64)) > (1 << 22):
+            continue
+        axis = int(rng.integers(0, rank))
+        C = shape[axis]
+        bits = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16]))
+        dt = [torch.float32, torch.float32, torch.float16, torch.bfloat16, torch.float64][int(rng.integers(0, 5))]
+        scale_mag = float(rng.choice([1e-3, 0.1, 1.0, 30.0]))
+        x = (torch.from_numpy(rng.standard_normal(shape).astype(np.float32)) * scale_mag * 2).to(dt)
+        perm = list(rng.permutation(rank))
+        x = x.permute(perm).contiguous().permute(list(np.argsort(perm)))
+        kind = int(rng.integers(0, 8))
+        pc = bool(rng.integers(0, 2))
+        n = C if pc else 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == 0:
+                q = Q.WeightsSymmetricInferableQuantizer(bits, [float(v) for v in rng.uniform(0.2, 4.0, n) * scale_mag], pc, axis if pc else None)
+            elif kind == 1:
+                q = Q.WeightsPOTInferableQuantizer(bits, [float(2.0 ** e) for e in rng.integers(-6, 5, n)], pc, axis if pc else None)
+            elif kind == 2:
+                lo = [float(v) for v in rng.uniform(-4.0, 0.5, n) * scale_mag]
+                hi = [float(a + d) for a, d in zip(lo, rng.uniform(0.2, 6.0, n) * scale_mag)]
+                q = Q.WeightsUniformInferableQuantizer(bits, lo, hi, pc, axis if pc else None)
+            elif kind == 3:
+                q = Q.ActivationSymmetricInferableQuantizer(bits, [float(rng.uniform(0.2, 4.0) * scale_mag)], bool(rng.integers(0, 2)))
+            elif kind == 4:
+                q = Q.ActivationPOTInferableQuantizer(bits, [float(2.0 ** rng.integers(-6, 5))], bool(rng.integers(0, 2)))
+            else:
+                lo = float(rng.uniform(-4.0, 0.5) * scale_mag)
+                q = Q.ActivationUniformInferableQuantizer(bits, [lo], [lo + float(rng.uniform(0.2, 6.0) * scale_mag)])
+        if kind <= 2:
+            s, z = q.scales.cpu(), q.zero_points.cpu()
+            if pc:
+                ref = torch.fake_quantize_per_channel_affine(x.clone(), s, z, axis, q.min_quantized_domain, q.max_quantized_domain)
+            else:
+                ref = torch.fake_quantize_per_tensor_affine(x.clone(), s, z, q.min_quantized_domain, q.max_quantized_domain)
+        elif kind <= 4:
+            ref = torch.fake_quantize_per_tensor_affine(x.clone(), q.scales, q.zero_points, q.min_quantized_domain, q.max_quantized_domain)
+        else:
+            ref = torch.fake_quantize_per_tensor_affine(x.clone(), q.scale, q.zero_point, q.min_quantized_domain, q.max_quantized_domain)
+        got = q(x.cuda())
+        info = (case, tuple(x.shape), x.stride(), axis, dt, kind, bits, pc)
+        assert got.dtype == ref.dtype and got.shape == ref.shape, info
+        same = torch.equal(got.cpu().double().view(torch.int64), ref.double().view(torch.int64))
+        assert same, (info, first_mismatch(got.cpu().double().numpy(), ref.double().numpy(), x.double().numpy()))
