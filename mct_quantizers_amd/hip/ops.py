@@ -781,18 +781,23 @@ def lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin
 
 def grid_per_tensor(x, lo: float, hi: float, step: float, shifted: bool = False):
     """clip -> true division -> round half even -> scale back, one parameter set (export-time arithmetic)."""
-    if x.is_cuda:
-        return _hip_grid_per_tensor(x, lo, hi, step, shifted)
-    _cpu_route_allowed()
     f32 = lambda v: torch.tensor(v, dtype=torch.float64).to(torch.float32)    # noqa: E731  (scalar -> float32, RNE)
+    if x.is_cuda:
+        if x.dtype is torch.float32:
+            return _hip_grid_per_tensor(x, lo, hi, step, shifted)
+        # export of a model kept in another storage type (once per export): the reference's op chain on the device
+        return _cpu_grid(x, f32(lo).to(x.device), f32(hi).to(x.device), f32(step).to(x.device), shifted)
+    _cpu_route_allowed()
     return _cpu_grid(x, f32(lo), f32(hi), f32(step), shifted)
 
 
 def grid_per_channel(x, los, his, steps, axis: int, shifted: bool = False):
     """Same with float32 parameter vectors along ``axis``."""
-    if x.is_cuda:
+    if x.is_cuda and x.dtype is torch.float32:
         return _hip_grid_per_channel(x, los, his, steps, axis, shifted)
-    _cpu_route_allowed()
+    if not x.is_cuda:
+        _cpu_route_allowed()
     shape = [1] * x.dim()
     shape[axis] = -1
-    return _cpu_grid(x, los.reshape(shape), his.reshape(shape), steps.reshape(shape), shifted)
+    los, his, steps = (t.to(x.device).reshape(shape) for t in (los, his, steps))     # non-float32 GPU tensors: see above
+    return _cpu_grid(x, los, his, steps, shifted)

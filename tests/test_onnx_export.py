@@ -229,6 +229,12 @@ def test_grid_entry_points_validate_arguments():
     assert lib.mctq_grid_per_tensor_f32(x.data_ptr(), x.data_ptr(), 8, 0.0, 1.0, 0.1, 2, s) == native.MCTQ_E_ARG
     assert lib.mctq_grid_per_channel_f32(x.data_ptr(), x.data_ptr(), 1, 8, 1, None, None, None, 0, s) == native.MCTQ_E_ARG
     assert lib.mctq_grid_per_tensor_f32(None, None, 0, 0.0, 1.0, 0.1, 0, s) == 0          # empty is fine
-    with pytest.raises(NotImplementedError):
-        from mct_quantizers_amd.hip import ops
-        ops.grid_per_tensor(x.half(), 0.0, 1.0, 0.1)
+    # other storage types (export of a half-precision model, once per export): the reference's op chain on the device,
+    # the same values as that chain on the CPU copy
+    from mct_quantizers_amd.hip import ops
+    xh = (torch.randn(5, 33, device="cuda") * 0.7).half()
+    got = ops.grid_per_tensor(xh, -1.0, 0.875, 0.125)
+    assert got.is_cuda and torch.equal(got.cpu(), ops.grid_per_tensor(xh.cpu(), -1.0, 0.875, 0.125))
+    lo, hi, st = torch.tensor([-1.0] * 5), torch.tensor([0.875] * 5), torch.tensor([0.125] * 5)
+    got = ops.grid_per_channel(xh, lo, hi, st, 0)
+    assert got.is_cuda and torch.equal(got.cpu(), ops.grid_per_channel(xh.cpu(), lo, hi, st, 0))
