@@ -945,6 +945,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     case 2588: return MCTQ_QW(8, 8);
     case 2548: return MCTQ_QW(4, 8);
     case 2584: return MCTQ_QW(8, 4);
+    case 2544: return MCTQ_QW(4, 4);
     case 2560: return u8 ? launch_pp<true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)
                          : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
     default: break;

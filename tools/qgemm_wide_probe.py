@@ -48,7 +48,7 @@ for variant in variants:
                 print("MISMATCH", variant, M, N, K, u8, int((y != ref).sum()), y.ravel()[:4].tolist(), ref.ravel()[:4].tolist())
 print("exactness failures:", bad, flush=True)
 
-for (M, N, K) in [(2048, 4096, 4096), (4096, 4096, 4096), (4096, 4096, 11008), (4096, 11008, 4096), (8192, 8192, 8192)]:
+for (M, N, K) in [(256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (4096, 4096, 4096), (4096, 4096, 11008), (4096, 11008, 4096), (8192, 8192, 8192)]:
     a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)
     w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev)
     sc = torch.rand(N, device=dev) * 0.01
