@@ -1107,3 +1107,35 @@ def test_fuzz_affine_bit_widths_signs_and_every_class_against_aten_cpu(lib):
         assert got.dtype == ref.dtype and got.shape == ref.shape, info
         same = torch.equal(got.cpu().double().view(torch.int64), ref.double().view(torch.int64))
         assert same, (info, first_mismatch(got.cpu().double().numpy(), ref.double().numpy(), x.double().numpy()))
+
+
+def test_lut_quantizers_follow_attribute_assignment(lib):
+    """The reference reads threshold / eps / lut_values (and the weights classes' private tensors) on every call; here
+    tables and pre-packed launches are derived from them, so assigning to one must re-derive that state."""
+    import mct_quantizers_amd as mq
+    from oracle import mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(11)
+    lut = [-128.0, -64.0, -20.0, -5.0, 0.0, 5.0, 20.0, 64.0]
+    x_np = (rng.standard_normal((3, 257)) * 3).astype(np.float32)
+    x = _dev(x_np)
+    q = Q.ActivationLutPOTInferableQuantizer(3, lut, [4.0], True)
+    assert bits_equal(q(x).cpu().numpy(), O.lut_quantize(x_np, lut, 4.0, True, 8, 1e-8))
+    q.threshold = 8.0
+    assert bits_equal(q(x).cpu().numpy(), O.lut_quantize(x_np, lut, 8.0, True, 8, 1e-8))
+    q.eps = 0.25
+    assert bits_equal(q(x).cpu().numpy(), O.lut_quantize(x_np, lut, 8.0, True, 8, 0.25))
+    q.lut_values = torch.tensor([-100.0, 0.0, 100.0], device="cuda")
+    assert bits_equal(q(x).cpu().numpy(), O.lut_quantize(x_np, [-100.0, 0.0, 100.0], 8.0, True, 8, 0.25))
+    q.lut_values_bitwidth = 10
+    q.lut_values = torch.tensor([-400.0, 3.0, 300.0], device="cuda")
+    assert bits_equal(q(x).cpu().numpy(), O.lut_quantize(x_np, [-400.0, 3.0, 300.0], 8.0, True, 10, 0.25))
+    w = Q.WeightsLUTSymmetricInferableQuantizer(3, lut, [1.0, 2.0, 0.5], True, 0, 2)
+    assert bits_equal(w(_dev(x_np)).cpu().numpy(), O.lut_quantize(x_np, lut, np.float32([1.0, 2.0, 0.5]), True, 8, 1e-8, per_channel=True, channel_axis=0))
+    w._threshold_torch = torch.tensor([3.0, 0.25, 1.5], device="cuda")
+    w._lut_values_torch = torch.tensor([-7.0, 1.0, 90.0], device="cuda")
+    assert bits_equal(w(_dev(x_np)).cpu().numpy(), O.lut_quantize(x_np, [-7.0, 1.0, 90.0], np.float32([3.0, 0.25, 1.5]), True, 8, 1e-8, per_channel=True, channel_axis=0))
+    wt = Q.WeightsLUTPOTInferableQuantizer(3, lut, [2.0], False)
+    wt(_dev(x_np))
+    wt.eps = 0.5                                            # enters the per-tensor divisor
+    assert bits_equal(wt(_dev(x_np)).cpu().numpy(), O.lut_quantize(x_np, lut, np.float32([2.0]), True, 8, 0.5))

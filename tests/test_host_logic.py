@@ -472,3 +472,21 @@ def test_half_activation_lut_on_cpu_tensors_matches_the_reference_fixtures():
             continue
         y = q(x)
         assert str(y.dtype) == "torch." + c["out_dtype"] and bits_equal(y.float().numpy(), arrays[c["id"] + "_y"]), c["id"]
+
+
+def test_lut_quantizers_follow_attribute_assignment_on_cpu():
+    lut = [-128.0, -64.0, -20.0, -5.0, 0.0, 5.0, 20.0, 64.0]
+    x = torch.randn(3, 50) * 3
+    q = Q.ActivationLutPOTInferableQuantizer(3, lut, [4.0], True)
+    a = q(x)
+    q.threshold = 8.0
+    assert torch.equal(q(x), Q.ActivationLutPOTInferableQuantizer(3, lut, [8.0], True)(x)) and not torch.equal(q(x), a)
+    q.eps = 0.5
+    assert torch.equal(q(x), Q.ActivationLutPOTInferableQuantizer(3, lut, [8.0], True, eps=0.5)(x))
+    w = Q.WeightsLUTSymmetricInferableQuantizer(3, lut, [1.0, 2.0, 0.5], True, 0, 2)
+    w(x.clone())
+    w._threshold_torch = torch.tensor([3.0, 0.25, 1.5])
+    assert torch.equal(w(x.clone()), Q.WeightsLUTSymmetricInferableQuantizer(3, lut, [3.0, 0.25, 1.5], True, 0, 2)(x.clone()))
+    import pickle
+    w2 = pickle.loads(pickle.dumps(w))
+    assert torch.equal(w2(x.clone()), w(x.clone())) and not w2.__dict__.get("_stale")
