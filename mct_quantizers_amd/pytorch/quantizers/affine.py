@@ -22,7 +22,7 @@ import torch
 from mct_quantizers_amd.common.registry import (BaseInferableQuantizer, QuantizationMethod, QuantizationTarget,
                                                QuantizerID, mark_quantizer)
 from mct_quantizers_amd.hip import ops
-from mct_quantizers_amd.pytorch.quantizer_utils import fix_range_to_include_zero, get_working_device, to_torch_tensor
+from mct_quantizers_amd.pytorch.quantizer_utils import fix_range_to_include_zero, get_working_device
 
 
 _is_compiling = torch.compiler.is_compiling
