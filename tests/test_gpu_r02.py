@@ -1139,3 +1139,28 @@ def test_lut_quantizers_follow_attribute_assignment(lib):
     wt(_dev(x_np))
     wt.eps = 0.5                                            # enters the per-tensor divisor
     assert bits_equal(wt(_dev(x_np)).cpu().numpy(), O.lut_quantize(x_np, lut, np.float32([2.0]), True, 8, 0.5))
+
+
+def test_bench_multi_process_leg_runs_over_rccl_on_one_gpu(lib):
+    """bench.py launched as the driver launches it for N > 1 (torch.distributed.run, one process per GPU), here with one
+    rank on the one GPU of the box: RCCL initialises, the barrier / max-over-ranks / sharded config-5 leg with its
+    all_gather_into_tensor execute, and the JSON line carries the keys the scaling run reads."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "1", "--gather", "--steps", "20", "--warmup", "5",
+           "--no-cpu", "--prewarm-seconds", "0.2", "--evidence-launches", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 1e11
+    assert d["config"]["control_plane"] == "nccl", d["config"]
+    leg = d["sharded_cfg5"]
+    for key in ("compute_ms", "compute_elems_per_s", "allgather_ms", "allgather_recv_bytes_per_rank", "compute_plus_allgather_elems_per_s", "gathered_rows_match_local"):
+        assert key in leg, leg
+    assert leg["gathered_rows_match_local"] is True and leg["rows_per_rank"] == 8192
