@@ -279,7 +279,8 @@ int mctq_lutt_per_channel(const void* x, float* y,
  * scan over float bit patterns and checks the model on sample points; the mctq_luts_* kernels count the thresholds
  * <= t with a branchless binary search in LDS (log2 of the codebook size reads per element instead of 4 VALU ops per
  * entry), bit-identically to the literal scan (tested for all 2^32 inputs).
- *   mctq_lut_steps_words : upper bound of the array size in floats for a codebook of n_lut entries.
+ *   mctq_lut_steps_words : upper bound of the array size in floats for a codebook of n_lut entries (lists of 128
+ *                          thresholds or more carry a cell index behind the 2 * P + 2 words: see LutCellsOp).
  *   mctq_lut_build_steps : fills steps_host (HOST) and *n_words with the actual size 2 * P + 2; MCTQ_E_ARG for a
  *                          non-integer codebook or one that fails the staircase check (use the literal kernels then).
  *   mctq_luts_per_tensor / _per_channel : as mctq_lutt_*, with `steps` (DEVICE copy) and `n_words` in place of the table.

@@ -110,7 +110,23 @@ inline const char* build(const float* lut, int n_lut, float mult, float clip_min
 // ---- threshold list ("steps") for integer codebooks of any clip range (LutStepsOp in mctq_kernels.hpp) ----------
 // P = smallest power of two >= number of DISTINCT centres; the array holds 2 * P + 2 floats.
 inline int steps_pow2(int n_distinct) { int p = 1; while (p < n_distinct) p <<= 1; return p; }
-inline int steps_words_for(int n_lut) { return 2 * steps_pow2(n_lut) + 2; }     // upper bound from the list length
+// Long lists (P >= kCellMinP) may carry a cell index behind the list: kCellHeader words {G, max thresholds per cell,
+// gscale, clip_min} and G words {first threshold of the cell | thresholds in it << 16} (see LutStepsOp).
+constexpr int kCellHeader = 4, kCellMinP = 128, kCellMaxPer = 4;
+inline int steps_cells_for(int P) { return P < kCellMinP ? 0 : (P <= 256 ? 1024 : (P <= 1024 ? 4096 : 8192)); }
+inline int steps_words_for(int n_lut) {                                         // upper bound from the list length
+  const int p = steps_pow2(n_lut);
+  return 2 * p + 2 + (p >= kCellMinP ? kCellHeader + steps_cells_for(p) : 0);
+}
+// the cell of a clipped value: the SAME float operations as the kernel (no contraction), monotone in t
+inline int steps_cell(float t, float clip_min, float gscale, int G) {
+  volatile float d = t - clip_min;
+  volatile float v = d * gscale;
+  const float vv = v;
+  if (!(vv > 0.0f)) return 0;                                                    // also -inf / NaN
+  if (vv >= (float)(G - 1)) return G - 1;
+  return (int)vv;
+}
 
 // Fills steps[2 * P + 2] (P returned through *p_out); returns NULL on success or a static message.
 inline const char* build_steps(const float* lut, int n_lut, float mult, float clip_min, float clip_max, float* steps,
@@ -181,6 +197,33 @@ inline const char* build_steps(const float* lut, int n_lut, float mult, float cl
   steps[2 * P + 1] = (float)P;
   *p_out = P;
   return nullptr;
+}
+
+// Cell index for a long threshold list (appended behind the 2 * P + 2 words build_steps wrote; `steps` must have room
+// for steps_words_for()).  Returns the number of words appended: 0 when the list is short or some cell would hold more
+// than kCellMaxPer thresholds (the kernel then keeps the binary search).  Exactness does not depend on where the cell
+// edges fall: cell() is monotone, so a threshold in an earlier cell than t's is <= t, one in a later cell is > t, and
+// the thresholds of t's own cell are compared one by one.
+inline int build_step_cells(float* steps, int P, int n_distinct, float clip_min, float clip_max) {
+  const int G = steps_cells_for(P);
+  if (!G) return 0;
+  const float gscale = (float)G / (clip_max - clip_min);
+  const float* T = steps;
+  uint32_t first[8192], count[8192];
+  for (int c = 0; c < G; ++c) first[c] = count[c] = 0;
+  int cells_of[4096];
+  for (int k = 1; k < n_distinct; ++k) { cells_of[k] = steps_cell(T[k], clip_min, gscale, G); ++count[cells_of[k]]; }
+  for (int k = 2; k < n_distinct; ++k) if (cells_of[k] < cells_of[k - 1]) return 0;    // (cannot happen: T is sorted)
+  uint32_t run = 0, maxc = 0;
+  for (int c = 0; c < G; ++c) { first[c] = run; run += count[c]; if (count[c] > maxc) maxc = count[c]; }
+  if (maxc > (uint32_t)kCellMaxPer) return 0;
+  float* out = steps + 2 * P + 2;
+  out[0] = (float)G; out[1] = (float)maxc; out[2] = gscale; out[3] = clip_min;
+  for (int c = 0; c < G; ++c) {
+    const uint32_t word = first[c] | (count[c] << 16);
+    memcpy(&out[kCellHeader + c], &word, 4);
+  }
+  return kCellHeader + G;
 }
 
 }  // namespace mctq_tb

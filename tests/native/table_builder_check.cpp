@@ -52,6 +52,35 @@ static int check_steps(const std::vector<float>& lut, float mult, float cmin, fl
     const float t = (float)((double)cmin + span * i / 200000.0);
     if (model(t) != mctq_tb::literal(t, lut.data(), (int)lut.size()) / mult) ++bad;
   }
+  // cell index of a long list: the count through the cells equals the binary search
+  int distinct = 0;
+  { std::vector<float> seen; for (float v : lut) { bool dup = false; for (float u : seen) dup = dup || u == v; if (!dup) seen.push_back(v); } distinct = (int)seen.size(); }
+  const int extra = mctq_tb::build_step_cells(steps.data(), P, distinct, cmin, cmax);
+  if (extra) {
+    const float* h = steps.data() + 2 * P + 2;
+    const int G = (int)h[0], maxc = (int)h[1];
+    const float gscale = h[2];
+    auto via_cells = [&](float t) {
+      const int c = mctq_tb::steps_cell(t, cmin, gscale, G);
+      uint32_t e; memcpy(&e, &h[4 + c], 4);
+      const int first = (int)(e & 0xffffu), n = (int)(e >> 16);
+      int idx = first;
+      for (int j = 0; j < maxc; ++j) { const int k = 1 + first + j < P - 1 ? 1 + first + j : P - 1; idx += (j < n && t >= T[k]) ? 1 : 0; }
+      return Q[idx];
+    };
+    if (G != mctq_tb::steps_cells_for(P)) { printf("bad G\n"); return 1; }
+    for (int i = 0; i <= 400000; ++i) {
+      const float t = (float)((double)cmin + span * i / 400000.0);
+      if (via_cells(t) != model(t)) ++bad;
+    }
+    for (int k = 1; k < P; ++k) {
+      if (!(T[k] > -INFINITY && T[k] < INFINITY)) continue;
+      for (int d = -3; d <= 3; ++d) {
+        const float t = mctq_tb::ord2f(mctq_tb::f2ord(T[k]) + (uint32_t)d);
+        if (t >= cmin && t <= cmax && via_cells(t) != model(t)) ++bad;
+      }
+    }
+  } else if (P >= mctq_tb::kCellMinP) { printf("note: no cell index for P=%d\n", P); }
   if (bad) printf("steps: %ld mismatches\n", bad);
   return bad != 0;
 }

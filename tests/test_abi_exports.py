@@ -91,14 +91,20 @@ def test_threshold_list_builder_matches_the_oracle_scan():
              ([float(v) for v in rng.choice(np.arange(-2048, 2048), 16, replace=False)], True, 12),
              ([float(v) for v in rng.choice(np.arange(-32768, 32768), 256, replace=False)], True, 16),
              ([float(v) for v in rng.choice(np.arange(0, 4097), 64, replace=False)], False, 12),
+             ([float(v) for v in rng.choice(np.arange(-32768, 32768), 1024, replace=False)], True, 16),
              ([float(v) for v in rng.permutation(np.arange(-128, 128))], True, 8)]
     for lut, signed, B in cases:
         mult = float(2 ** (B - int(signed)))
         cmin, cmax = (float(-2 ** (B - 1)), float(2 ** (B - 1) - 1)) if signed else (0.0, float(2 ** B - 1))
         st = native.build_lut_steps(lut, mult, cmin, cmax)
         assert st is not None
-        P = int(st[-1])
-        assert st.shape == (2 * P + 2,) and P & (P - 1) == 0 and P >= len(set(lut))
+        P = 1
+        while P < len(set(lut)):
+            P *= 2
+        G_for = 0 if P < 128 else (1024 if P <= 256 else (4096 if P <= 1024 else 8192))
+        assert int(st[2 * P + 1]) == P and st.shape[0] in (2 * P + 2, 2 * P + 2 + 4 + G_for)
+        has_cells = st.shape[0] != 2 * P + 2
+        assert has_cells == (P >= 128)
         T, Q = st[:P], st[P:2 * P]
         assert np.all(np.diff(T[1:]) >= 0) or P <= 2
         fin = T[1:][np.isfinite(T[1:])]
@@ -112,6 +118,18 @@ def test_threshold_list_builder_matches_the_oracle_scan():
         idx = np.searchsorted(T[1:], t, side="right")                                      # thresholds <= t
         got = Q[idx] * np.float32(mult)
         assert np.array_equal(got, want), (lut[:8], B)
+        if has_cells:                                                                      # the kernel's cell-index route
+            G, maxc, gscale, c0 = int(st[2 * P + 2]), int(st[2 * P + 3]), np.float32(st[2 * P + 4]), np.float32(st[2 * P + 5])
+            cells = st[2 * P + 6: 2 * P + 6 + G].view(np.uint32)
+            assert G == G_for and 0 < maxc <= 4 and c0 == np.float32(cmin)
+            v = ((t - c0).astype(np.float32) * gscale).astype(np.float32)
+            c = np.clip(v, 0, G - 1).astype(np.int32)
+            first, n = (cells[c] & 0xffff).astype(np.int64), (cells[c] >> 16).astype(np.int64)
+            idx2 = first.copy()
+            for j in range(maxc):
+                th = T[np.minimum(1 + first + j, P - 1)]
+                idx2 += ((j < n) & (t >= th)).astype(np.int64)
+            assert np.array_equal(idx2, idx), (B, len(lut))
         assert st[2 * P] == np.float32(lut[0]) / np.float32(mult)                          # NaN input -> codebook entry 0
     assert native.build_lut_steps([0.5, 1.0], 2048.0, -2048.0, 2047.0) is None             # non-integer codebook
 

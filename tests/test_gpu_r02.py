@@ -781,6 +781,7 @@ def _wide_codebooks():
         "u12_l64": ([float(v) for v in rng.choice(np.arange(0, 4097), 64, replace=False)], False, 12),
         "s16_l256": ([float(v) for v in rng.choice(np.arange(-32768, 32768), 256, replace=False)], True, 16),
         "s11_l5": ([-1024.0, 1023.0, 0.0, 1.0, -1.0], True, 11),
+        "s16_l1024": ([float(v) for v in rng.choice(np.arange(-32768, 32768), 1024, replace=False)], True, 16),
     }
 
 
@@ -814,7 +815,7 @@ def test_threshold_list_equals_literal_scan_for_every_float(lib, name):
             i = int(torch.nonzero(y_lit.view(torch.int32) != y_st.view(torch.int32))[0])
             raise AssertionError(f"chunk {c}: x={x[i].item()!r} literal={y_lit[i].item()!r} steps={y_st[i].item()!r}")
         del x
-    assert "LutStepsOp" in native.last_launch(), native.last_launch()
+    assert ("LutCellsOp" if len(set(lut)) > 64 else "LutStepsOp") in native.last_launch(), native.last_launch()
 
 
 @pytest.mark.parametrize("name", ["s12_l16", "u12_l64", "s16_l256"])
@@ -869,23 +870,23 @@ def test_wide_codebook_quantizer_classes_take_the_threshold_list(lib):
         q = Q.WeightsLUTSymmetricInferableQuantizer(nb, lut, [float(t) for t in thr], True, 0, 4, lut_values_bitwidth=B)
         assert q._lut_table_torch is None and q._lut_steps_torch is not None
         got = q(_dev(w_np))
-        assert "LutStepsOp" in native.last_launch(), native.last_launch()
+        assert "LutStepsOp" in native.last_launch() or "LutCellsOp" in native.last_launch(), native.last_launch()
         want = O.lut_quantize(w_np, lut, thr, True, B, 1e-8, per_channel=True, channel_axis=0)
         assert bits_equal(got.cpu().numpy(), want)
         q1 = Q.WeightsLUTPOTInferableQuantizer(nb, lut, [2.0], False, lut_values_bitwidth=B)
         got = q1(_dev(w_np))
-        assert "LutStepsOp" in native.last_launch(), native.last_launch()
+        assert "LutStepsOp" in native.last_launch() or "LutCellsOp" in native.last_launch(), native.last_launch()
         assert bits_equal(got.cpu().numpy(), O.lut_quantize(w_np, lut, np.float32([2.0]), True, B, 1e-8))
         # activation quantizer, float32 and half inputs (per-step half roundings)
         qa = Q.ActivationLutPOTInferableQuantizer(nb, lut, [4.0], True, lut_values_bitwidth=B)
         x_np = (rng.standard_normal((4, 3, 17, 19)) * 2.0).astype(np.float32)
         got = qa(_dev(x_np))
-        assert "LutStepsOp" in native.last_launch(), native.last_launch()
+        assert "LutStepsOp" in native.last_launch() or "LutCellsOp" in native.last_launch(), native.last_launch()
         assert bits_equal(got.cpu().numpy(), O.lut_quantize(x_np, lut, 4.0, True, B, 1e-8))
         for dt, dname in ((torch.float16, "float16"), (torch.bfloat16, "bfloat16")):
             xh = torch.from_numpy(x_np).to(dt)
             got = qa(xh.cuda())
-            assert "LutStepsOp" in native.last_launch(), native.last_launch()
+            assert "LutStepsOp" in native.last_launch() or "LutCellsOp" in native.last_launch(), native.last_launch()
             want = O.lut_quantize(xh.float().numpy(), lut, 4.0, True, B, 1e-8, step_dtype=dname)
             assert finite_equal(got.float().cpu().numpy(), want, xh.float().numpy()), dname
     # the classes only accept integer codebooks (base_lut_symmetric_inferable_quantizer.py:66); a non-integer one handed
@@ -1048,7 +1049,7 @@ def test_half_activation_lut_clip_bounds_follow_the_tensor_type(lib):
         kw = c["kwargs"]
         assert bits_equal(y32.cpu().numpy(), O.lut_quantize(x32, kw["lut_values"], kw["threshold"][0], kw["signed"],
                                                             kw["lut_values_bitwidth"], 1e-8))
-    assert kinds <= {"LutTableOp", "LutStepsOp"} and kinds, kinds
+    assert kinds <= {"LutTableOp", "LutStepsOp", "LutCellsOp"} and kinds, kinds
 
 
 def test_fuzz_affine_bit_widths_signs_and_every_class_against_aten_cpu(lib):
