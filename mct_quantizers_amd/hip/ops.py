@@ -279,6 +279,14 @@ def _hip_fq_batched(items):
     return outs
 
 
+def _lut_result(x, y):
+    """The reference's LUT op chain ends in an index gather (quantizer_utils.py:135-137), whose result is a CONTIGUOUS
+    tensor whatever the input's memory layout -- unlike ATen's fake-quant operators, which keep the input's strides.
+    The kernels work in storage order (same strides as the input); a permuted input pays one layout copy here to hand
+    back what the reference hands back."""
+    return y if x.is_contiguous() else y.contiguous()
+
+
 def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmin: float, cmax: float, table=None,
                         step_round: int = 0, thr_div64: float = None, steps=None):
     """LUT quantizer, one threshold.  Output is float32 whatever x's type (the reference's chain promotes).
@@ -290,8 +298,9 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
         if f is not None:
             y = f.lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, cmin, cmax)
             if y is not NotImplemented:
-                return y
+                return y if x.is_contiguous() else y.contiguous()      # see _lut_result
     lib = native.load()
+    x_in = x
     x = _dense_input(x)
     y = torch.empty_like(x, dtype=torch.float32)
     lut = _param_on(x, lut, "lut_values", torch.float32)
@@ -319,7 +328,7 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
                                          lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
         native.check(rc, "mctq_lut_per_tensor")
-    return y
+    return _lut_result(x_in, y)
 
 
 def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float,
@@ -331,8 +340,9 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
         if f is not None:
             y = f.lutt_per_channel(x, thresholds, eps, table, axis, mult, cmin, cmax)
             if y is not NotImplemented:
-                return y
+                return y if x.is_contiguous() else y.contiguous()      # see _lut_result
     lib = native.load()
+    x_in = x
     x = _dense_input(x)
     y = torch.empty_like(x, dtype=torch.float32)
     outer, c, inner = _channel_view(x, axis)
@@ -352,7 +362,7 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
                                           eps, lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
     if rc:
         native.check(rc, "mctq_lut_per_channel")
-    return y
+    return _lut_result(x_in, y)
 
 
 def _hip_grid_per_tensor(x, lo: float, hi: float, step: float, shifted: bool):
@@ -638,8 +648,8 @@ for _name, _gpu, _cpu in (("fq_per_tensor", _hip_fq_per_tensor, _cpu_fq_per_tens
     _lib_def.impl(_name, _cpu, "CPU")
 for _name in ("fq_per_tensor", "fq_per_tensor_tqp", "fq_per_channel"):
     _lib_def.impl(_name, (lambda x, *a: torch.empty_like(x)), "Meta")
-for _name in ("lut_per_tensor", "lut_per_channel"):          # the LUT chain's result is float32 for every input type
-    _lib_def.impl(_name, (lambda x, *a: torch.empty_like(x, dtype=torch.float32)), "Meta")
+for _name in ("lut_per_tensor", "lut_per_channel"):          # the LUT chain's result: float32, contiguous (_lut_result)
+    _lib_def.impl(_name, (lambda x, *a: torch.empty(x.shape, dtype=torch.float32, device=x.device)), "Meta")
 
 
 def _is_real(x) -> bool:

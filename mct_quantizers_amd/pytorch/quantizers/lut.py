@@ -237,7 +237,7 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         if plan is not False and not _is_compiling():
             y = plan(inputs)
             if y is not NotImplemented:
-                return y
+                return y if inputs.is_contiguous() else y.contiguous()      # ops._lut_result
         mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
         dt = getattr(inputs, "dtype", torch.float32)
         step = {torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}.get(dt, 0)

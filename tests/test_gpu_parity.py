@@ -54,6 +54,8 @@ def test_golden_cases_via_quantizer_classes(lib, golden_cases):
         assert y.is_cuda and y.shape == x.shape and y.dtype == torch.float32
         if "LUT" not in c["cls"] and "Lut" not in c["cls"]:
             assert y.stride() == x.stride(), c["id"]           # ATen keeps the input's strides
+        else:
+            assert y.is_contiguous(), c["id"]                  # the LUT chain ends in a gather: contiguous result
         got = y.cpu().numpy()
         assert bits_equal(got, want), f'{c["id"]} {c["cls"]} {c["shape"]} {c["memory_format"]}: ' \
                                       f'{first_mismatch(got, want, x_np)}'

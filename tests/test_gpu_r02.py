@@ -1000,7 +1000,7 @@ def test_fuzz_lut_quantizers_shapes_axes_layouts_dtypes_and_codebook_widths(lib)
         got = q(x.cuda())
         seen.add(native.last_launch().split("<")[1].split(",")[0] if "<" in native.last_launch() else native.last_launch())
         info = (case, tuple(x.shape), x.stride(), axis, dt, kind, B, len(lut))
-        assert got.dtype == want.dtype and got.shape == want.shape, info
+        assert got.dtype == want.dtype and got.shape == want.shape and got.is_contiguous() and want.is_contiguous(), info
         if dt in (torch.float16, torch.bfloat16) and kind == 2:
             ok = finite_equal(got.float().cpu().numpy(), want.float().numpy(), x.float().numpy())
         else:
