@@ -51,7 +51,11 @@ def _is_dense(x: torch.Tensor) -> bool:
 
 
 def _dense_input(x: torch.Tensor) -> torch.Tensor:
-    return x if _is_dense(x) else x.contiguous()
+    """A non-overlapping dense tensor the kernels can walk in storage order.  Gapped / overlapping views are compacted
+    the way ATen lays out the OUTPUT of its fake-quant operators for them -- ``empty_like(x)`` with the preserve-format
+    rule: dimensions keep their stride order (a gapped channels-last view stays channels-last) -- so the result, which
+    takes this tensor's strides, has the strides the reference's result has."""
+    return x if _is_dense(x) else torch.empty_like(x).copy_(x)
 
 
 def _channel_view(x: torch.Tensor, axis: int) -> Tuple[int, int, int]:

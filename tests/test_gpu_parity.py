@@ -752,6 +752,7 @@ def test_fuzz_shapes_axes_layouts_and_dtypes_against_aten_cpu(lib):
         got = q(x.cuda())
         info = (case, tuple(x.shape), x.stride(), axis, dt, kind)
         assert got.dtype == want.dtype and got.shape == want.shape, info
+        assert got.stride() == want.stride(), info             # ATen's preserve-format strides, gapped views included
         assert torch.equal(got.cpu().float().view(torch.int32), want.float().view(torch.int32)), info
         if x.is_contiguous() or kind != 2:
             pass

@@ -1105,7 +1105,7 @@ def test_fuzz_affine_bit_widths_signs_and_every_class_against_aten_cpu(lib):
             ref = torch.fake_quantize_per_tensor_affine(x.clone(), q.scale, q.zero_point, q.min_quantized_domain, q.max_quantized_domain)
         got = q(x.cuda())
         info = (case, tuple(x.shape), x.stride(), axis, dt, kind, bits, pc)
-        assert got.dtype == ref.dtype and got.shape == ref.shape, info
+        assert got.dtype == ref.dtype and got.shape == ref.shape and got.stride() == ref.stride(), info
         same = torch.equal(got.cpu().double().view(torch.int64), ref.double().view(torch.int64))
         assert same, (info, first_mismatch(got.cpu().double().numpy(), ref.double().numpy(), x.double().numpy()))
 
