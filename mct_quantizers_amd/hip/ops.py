@@ -190,7 +190,10 @@ def _hip_fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
 
 
 def _check_axis(x, n_params: int, axis: int):
-    if not 0 <= axis < x.dim():
+    d = x.dim()
+    if axis >= d or axis < -d:                    # ATen's own errors, in its order (fake_quantize_per_channel_affine)
+        raise IndexError(f"Dimension out of range (expected to be in range of [{-max(d, 1)}, {max(d, 1) - 1}], but got {axis})")
+    if axis < 0:
         raise RuntimeError("`axis` must be between 0 and number of dimensions of input")
     if n_params != x.shape[axis]:
         raise RuntimeError("dimensions of scale and zero-point are not consistent with input tensor")
@@ -222,8 +225,9 @@ def _hip_fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int,
 def _hip_fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
     """Tensor-qparams overload: ``scale`` float32[1] and ``zero_point`` int32[1] stay on the device (no .item())."""
     dt = _dtype_code(x, "fq_per_tensor_tqp")
-    if scale.numel() != 1 or zero_point.numel() != 1:
-        raise RuntimeError("fq_per_tensor_tqp: scale and zero_point must have exactly one element")
+    if scale.numel() < 1 or zero_point.numel() < 1:      # (ATen reads element 0 of longer tensors; so does the kernel)
+        raise RuntimeError("fq_per_tensor_tqp: scale and zero_point must have at least one element")
+    scale, zero_point = scale.reshape(-1)[:1], zero_point.reshape(-1)[:1]
     scale = _param_on(x, scale, "scale", torch.float32)
     zero_point = _param_on(x, zero_point, "zero_point", torch.int32)
     lib = native.load()

@@ -242,6 +242,11 @@ class _WeightsAffineMixin:
             host_scales, host_zps = host_scales.reshape(-1), host_zps.reshape(-1)
             zps_nonzero = bool(torch.any(host_zps != 0))
             host_zp0 = int(host_zps[0]) if host_zps.numel() else 0
+        # ATen validates the zero points of the per-channel operator on EVERY call (a device -> host read, most of its
+        # 46 us host cost); here once per parameter change (the call raises ATen's message, _quantize_weights)
+        zmin, zmax = ((int(host_zps.min()), int(host_zps.max())) if host_zps is not None and host_zps.numel()
+                      else (int(d["_zps_flat"].min().item()), int(d["_zps_flat"].max().item())) if d["_zps_flat"].numel() else (0, 0))
+        d["_zp_out_of_range"] = bool(self.per_channel) and (zmin < self.min_quantized_domain or zmax > self.max_quantized_domain)
         d["_zps_all_zero"] = not zps_nonzero                                     # symmetric: skip the table
         d["_scale0"] = float(host_scales[0]) if host_scales.numel() else 1.0
         d["_zp0"] = host_zp0
@@ -300,6 +305,8 @@ class _WeightsAffineMixin:
                                          self.max_quantized_domain)
         self._current()
         d = self.__dict__
+        if d["_zp_out_of_range"]:
+            raise RuntimeError("`zero_point` must be between `quant_min` and `quant_max`.")
         plan = d["_plan"]
         if plan is not None and not _is_compiling():
             y = plan(inputs)                    # compiled binding: checks + allocation + launch in one call

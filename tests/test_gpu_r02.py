@@ -1165,3 +1165,27 @@ def test_bench_multi_process_leg_runs_over_rccl_on_one_gpu(lib):
     for key in ("compute_ms", "compute_elems_per_s", "allgather_ms", "allgather_recv_bytes_per_rank", "compute_plus_allgather_elems_per_s", "gathered_rows_match_local"):
         assert key in leg, leg
     assert leg["gathered_rows_match_local"] is True and leg["rows_per_rank"] == 8192
+
+
+def test_error_behaviour_follows_aten_for_axis_zero_points_and_tensor_qparams(lib):
+    """What ATen raises (type and message) for an axis out of range, a negative axis and out-of-range per-channel zero
+    points, and what it accepts: tensor qparams longer than one element (element 0 is used)."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    Q = mq.pytorch_quantizers
+    x = torch.randn(4, 3, device="cuda")
+    s, z = torch.tensor([0.1, 0.2, 0.3], device="cuda"), torch.zeros(3, dtype=torch.int32, device="cuda")
+    for fn in (lambda a: torch.fake_quantize_per_channel_affine(x, s, z, a, -128, 127), lambda a: ops.fq_per_channel(x, s, z, a, -128, 127)):
+        with pytest.raises(IndexError, match=r"Dimension out of range \(expected to be in range of \[-2, 1\], but got 2\)"):
+            fn(2)
+        with pytest.raises(RuntimeError, match="`axis` must be between 0 and number of dimensions of input"):
+            fn(-1)
+    want = torch.fake_quantize_per_tensor_affine(x, s[:2], z[:2], -128, 127)            # ATen reads element 0
+    assert torch.equal(ops.fq_per_tensor_tqp(x, s[:2], z[:2], -128, 127), want)
+    q = Q.WeightsUniformInferableQuantizer(8, [-1.0, -2.0, -0.5], [1.0, 1.0, 2.0], True, 1)
+    q(x.clone())
+    q.zero_points = torch.tensor([0, 300, 0], dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="`zero_point` must be between `quant_min` and `quant_max`."):
+        q(x.clone())
+    with pytest.raises(RuntimeError, match="`zero_point` must be between `quant_min` and `quant_max`."):
+        torch.fake_quantize_per_channel_affine(x, q.scales, q.zero_points, 1, 0, 255)

@@ -12,7 +12,18 @@ sys.path.insert(0, REPO)
 REF_TESTS = "/root/reference/tests"
 assert os.path.isdir(REF_TESTS), "the reference checkout is only present in the build container"
 
+import random  # noqa: E402
+
+import numpy as np  # noqa: E402
 import pytest  # noqa: E402
+import torch  # noqa: E402
+
+# The reference's tests draw UNSEEDED random tensors and assert properties that hold only with high probability (e.g. that
+# every codebook entry occurs in every channel slice, test_weights_lut_inferable_quantizer.py:75) -- they fail now and then
+# against the reference itself.  Fixed seeds make this run reproducible; the seed is not tuned, 0 is the first one tried.
+random.seed(0)
+np.random.seed(0)
+torch.manual_seed(0)
 from mct_quantizers_amd import compat  # noqa: E402
 
 compat.install_reference_aliases(force=False)
