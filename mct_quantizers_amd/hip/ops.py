@@ -300,6 +300,8 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
     """LUT quantizer, one threshold.  Output is float32 whatever x's type (the reference's chain promotes).
     ``thr_div64``: for float64 tensors whose divisor is a Python float (the activation quantizer) the divisor
     stays a double."""
+    if not x.is_floating_point() and not x.is_complex():
+        x = x.to(torch.float32)          # integer / bool tensors: the chain's first op, a true division, promotes to float32
     dt = _dtype_code(x, "lut_per_tensor")
     if dt != native.DT_F64 and table is not None and native.TRACE is False:
         f = _FAST if _FAST_READY else _fast_mod()
@@ -341,6 +343,8 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
 
 def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float, cmin: float, cmax: float,
                          table=None, steps=None):
+    if not x.is_floating_point() and not x.is_complex():
+        x = x.to(torch.float32)          # as in _hip_lut_per_tensor
     dt = _dtype_code(x, "lut_per_channel")
     _check_axis(x, thresholds.numel(), axis)
     if dt != native.DT_F64 and table is not None and native.TRACE is False:

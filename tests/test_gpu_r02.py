@@ -1189,3 +1189,25 @@ def test_error_behaviour_follows_aten_for_axis_zero_points_and_tensor_qparams(li
         q(x.clone())
     with pytest.raises(RuntimeError, match="`zero_point` must be between `quant_min` and `quant_max`."):
         torch.fake_quantize_per_channel_affine(x, q.scales, q.zero_points, 1, 0, 255)
+
+
+def test_lut_quantizers_take_integer_tensors_like_the_reference_chain(lib):
+    """The reference's LUT chain starts with a true division, which promotes integer tensors to float32; the affine
+    operators (ATen) refuse them -- both behaviours are kept."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    Q = mq.pytorch_quantizers
+    lut = [-128.0, -64.0, -20.0, -5.0, 0.0, 5.0, 20.0, 64.0]
+    lut_t = torch.tensor(lut)
+    qa = Q.ActivationLutPOTInferableQuantizer(3, lut, [4.0], True)
+    qw = Q.WeightsLUTSymmetricInferableQuantizer(3, lut, [1.0, 2.0, 0.5], True, 1, 2)
+    for dt in (torch.int32, torch.int64, torch.uint8, torch.bool):
+        x = torch.randint(0, 2 if dt is torch.bool else 7, (5, 3)).to(dt)
+        want = ops._cpu_lut_per_tensor(x, lut_t, 4.0 + 1e-8, 4.0, 128.0, -128.0, 127.0, -1)
+        got = qa(x.cuda())
+        assert got.dtype == torch.float32 and torch.equal(got.cpu(), want), dt
+        want = ops._cpu_lut_per_channel(x, lut_t, torch.tensor([1.0, 2.0, 0.5]), 1e-8, 1, 128.0, -128.0, 127.0)
+        got = qw(x.cuda())
+        assert torch.equal(got.cpu(), want), dt
+    with pytest.raises(NotImplementedError):
+        Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])(torch.ones(3, dtype=torch.int32, device="cuda"))
