@@ -2,3 +2,13 @@ from mct_quantizers_amd.common import constants
 from mct_quantizers_amd.common.registry import (BaseInferableQuantizer, QuantizationMethod, QuantizationTarget,
                                                QuantizerID, get_all_subclasses, get_inferable_quantizer_class,
                                                mark_quantizer)
+
+
+def __getattr__(name):
+    # the reference's sub-modules are attributes of its packages (its top level imports them all); here they resolve on
+    # first access, so dotted paths like mct_quantizers.pytorch.quantize_wrapper work without an explicit import
+    import importlib
+    try:
+        return importlib.import_module(f"{__name__}.{name}")
+    except ModuleNotFoundError:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None

@@ -490,3 +490,21 @@ def test_lut_quantizers_follow_attribute_assignment_on_cpu():
     import pickle
     w2 = pickle.loads(pickle.dumps(w))
     assert torch.equal(w2(x.clone()), w(x.clone())) and not w2.__dict__.get("_stale")
+
+
+def test_dotted_module_paths_of_the_reference_resolve():
+    """Code written against the reference reaches classes through its package attributes without importing the
+    sub-modules (its top level imports them all): the same dotted paths resolve here, to the same objects."""
+    import mct_quantizers_amd as m
+    pq = m.pytorch_quantizers
+    assert pq.weights_inferable_quantizers.weights_symmetric_inferable_quantizer.WeightsSymmetricInferableQuantizer \
+        is pq.WeightsSymmetricInferableQuantizer
+    assert pq.activation_inferable_quantizers.activation_lut_pot_inferable_quantizer.ActivationLutPOTInferableQuantizer \
+        is pq.ActivationLutPOTInferableQuantizer
+    assert pq.base_pytorch_inferable_quantizer.BasePyTorchInferableQuantizer is pq.BasePyTorchInferableQuantizer
+    assert m.pytorch.quantize_wrapper.PytorchQuantizationWrapper is m.PytorchQuantizationWrapper
+    assert m.pytorch.activation_quantization_holder.PytorchActivationQuantizationHolder is m.PytorchActivationQuantizationHolder
+    assert m.common.base_inferable_quantizer.BaseInferableQuantizer is m.BaseInferableQuantizer
+    assert m.common.get_quantizers.get_inferable_quantizer_class is m.get_inferable_quantizer_class
+    with pytest.raises(AttributeError):
+        m.pytorch.no_such_module
