@@ -497,6 +497,12 @@ def test_full_size_config_matches_reference_digest(lib, cfg):
         thr0 = np.float32(wl.kwargs["threshold"][0])
         allowed = np.asarray(wl.kwargs["lut_values"], dtype=np.float32) / np.float32(128.0) * thr0
         assert np.all(np.isin(row, allowed))
+        assert torch.equal(q(y.clone()), y), "codebook values quantize to themselves"
+    # sortedness: the quantizer is monotone -- a sorted row stays sorted (parameters of row 0 / the whole tensor)
+    flat = x.reshape(x.shape[0], -1) if x.dim() > 1 else x.reshape(1, -1)
+    srt = torch.sort(flat, dim=1).values.reshape(x.shape)
+    ys = q(srt).reshape(flat.shape)
+    assert bool((ys[:, 1:] >= ys[:, :-1]).all()), "monotone in the input"
 
 
 # ---------------------------------------------------------------------------------------------
