@@ -1211,3 +1211,25 @@ def test_lut_quantizers_take_integer_tensors_like_the_reference_chain(lib):
         assert torch.equal(got.cpu(), want), dt
     with pytest.raises(NotImplementedError):
         Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])(torch.ones(3, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("world", [2, 8, 3])
+def test_dim0_shards_reassemble_to_the_reference_digest_of_config_5(lib, world):
+    """The multi-GPU partition of SURVEY 8(e) at FULL size on one GPU: each rank's row block of the 8192 x 8192 tensor,
+    quantized with that rank's slice of the thresholds (sharded.shard_kwargs / row_block), concatenates to the tensor
+    whose SHA-256 the reference produced (tests/golden/full_sha.json) -- even and ragged (3 ranks) splits."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd import sharded, workloads
+    rec = load_json("full_sha.json")["configs"]["cfg5"]
+    x_np = workloads.make_input("cfg5")
+    wl = workloads.make_workload("cfg5", x_np)
+    rows = x_np.shape[0]
+    h = hashlib.sha256()
+    covered = 0
+    for rank in range(world):
+        start, stop = sharded.row_block(rows, world, rank)
+        q = getattr(mq.pytorch_quantizers, wl.quantizer)(**sharded.shard_kwargs(wl.kwargs, rows, world, rank))
+        y = q(_dev(x_np[start:stop]))
+        h.update(np.ascontiguousarray(y.cpu().numpy()).tobytes())
+        covered += stop - start
+    assert covered == rows and h.hexdigest() == rec["y_sha256"]
