@@ -1150,9 +1150,13 @@ def test_bench_multi_process_leg_runs_over_rccl_on_one_gpu(lib):
     import subprocess
     import sys
     from conftest import REPO
+    import socket
+    with socket.socket() as sk:                           # a port that is free right now (the rendezvous store binds it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "1", "--gather", "--steps", "20", "--warmup", "5",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--gather", "--steps", "20", "--warmup", "5",
            "--no-cpu", "--prewarm-seconds", "0.2", "--evidence-launches", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
