@@ -1237,3 +1237,28 @@ def test_dim0_shards_reassemble_to_the_reference_digest_of_config_5(lib, world):
         h.update(np.ascontiguousarray(y.cpu().numpy()).tobytes())
         covered += stop - start
     assert covered == rows and h.hexdigest() == rec["y_sha256"]
+
+
+def test_integration_md_stub_runs_as_written(lib):
+    """The reference-side ctypes stub printed in INTEGRATION.md (blocks 1-3) is executed verbatim against the built
+    library and its per-channel replacement compared with the ATen operator it replaces."""
+    import re
+    from conftest import REPO
+    from mct_quantizers_amd.hip import native
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 3
+    src = "\n".join(blocks[:3]).replace('ctypes.CDLL("libmctq_hip.so")', f"ctypes.CDLL({native.lib_path()!r})")
+    ns = {}
+    exec(compile(src, "INTEGRATION.md", "exec"), ns)
+    x = torch.randn(6, 40, 7, device="cuda")
+    s = torch.rand(40, device="cuda") * 0.1 + 0.01
+    z = torch.randint(-5, 6, (40,), dtype=torch.int32, device="cuda")
+    got = ns["fake_quantize_per_channel_hip"](x, s, z, 1, -128, 127)
+    assert torch.equal(got, torch.fake_quantize_per_channel_affine(x, s, z, 1, -128, 127))
+    assert ctypes_sizeof(ns["FqItem"]) == 72
+
+
+def ctypes_sizeof(t):
+    import ctypes
+    return ctypes.sizeof(t)
