@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the inferable-quantizer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--batch N] [--no-cpu] ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--batched T] [--batch N] [--no-cpu] ...
 
 A *step* is one call of the configuration's quantizer (through the public class, hence through the
 C ABI and the gfx950 kernel) on one device-resident synthetic tensor.  Default workload: BASELINE
 config 2, WeightsSymmetricInferableQuantizer per-channel (axis 0) 8-bit on 4096x4096 float32.
+``--batched T``: a step is ONE batched launch over T such tensors (the launch a wrapped model issues per forward,
+pytorch/batching.py -> mctq_fq_batch_run; reference call site pytorch/quantize_wrapper.py:228-240), algorithmic bytes
+T x 128 MiB per launch.
 
 Protocol
   * cache: the 128 MiB in+out working set of config 2 fits the 256 MiB Infinity Cache, so the steps rotate
@@ -14,19 +17,30 @@ Protocol
   * clocks: before the W warm-up steps the same step loop runs for a FIXED, declared duration
     (``--prewarm-seconds``, default 1.0 s; reported as ``prewarm_s``) so that a 20-step run and a 1000-step run
     see the same clocks and a warm caching allocator.  It is outside the timed region.
-  * timed region: exactly K steps between barrier + synchronize on both sides; the wall clock gives ``value``,
-    HIP events on the launch stream -- one behind the first launch, one behind the last -- give ``roofline.kernel_us``
-    = the AVERAGE launch period of launches 2..K, bubbles between launches included; the event in front of the first
-    launch gives ``kernel_us_incl_first_launch_latency`` (the idle stream's start-up once per region on top).
+  * timed region: exactly K steps between barrier + synchronize on both sides.  Three clocks, one claim each:
+      - the host wall clock gives ``value``, ``ms_per_step``, ``achieved_gbs`` and ``roofline.frac_wall``;
+      - HIP events on the launch stream around the K launches give ``roofline.frac_events_whole_region`` (the idle
+        stream's start-up before the first launch included);
+      - the event behind the FIRST launch to the event behind the LAST gives ``roofline.kernel_us`` / ``achieved`` /
+        ``frac``: the average launch period of launches 2..K, bubbles between launches included -- the figure that
+        rocprofv3's average kernel duration (profiles/) must agree with.
   * per-launch evidence (after the timed region, outside it): >= 50 launches with an event between every two;
     median / mean / p10 / p90 of the per-launch periods are reported under ``roofline.per_launch``.
   * ``roofline.traffic`` is emitted only when profiles/pmc_traffic.json holds counters taken on the SAME kernel
     variant this run launched (``mctq_last_launch()``); otherwise null with the reason.
+  * the parity check compares the output of the LAST timed step with the CPU oracle.
+  * at N = 1 the default run appends ``batched_16x4096``: the same tensor 16 times in one batched launch, measured
+    after the judged region with the same event protocol (``--no-batched-extra`` skips it).
 
-With N > 1 (launched by torch.distributed.run, one process per GPU) every rank runs the same per-GPU
-workload (weak scaling; the path needs no collective); the value is the sum over ranks divided by
-the slowest rank's time.  BASELINE config 5 sharded by dim 0 + ONE all-gather (RCCL) is reported as
-``sharded_cfg5`` (outside the timed region; ``--gather`` forces it at N = 1 under torchrun).
+``--gpus N`` with N > 1 and no RANK in the environment: the script starts ``python -m torch.distributed.run`` on
+itself as a child process (before anything touches the GPU) and relays its output and exit status; launched by
+torch.distributed.run directly it is one rank.  Every rank runs the same per-GPU workload (weak scaling; the path
+needs no collective); ``value`` is the sum over ranks divided by the slowest rank's time.  BASELINE config 5 sharded by
+dim 0 + ONE all-gather (RCCL) is measured outside the timed region and reported as ``sharded_cfg5`` plus the top-level
+``sharded_cfg5_*`` fields (``--gather`` forces it at N = 1 under torchrun).
+
+``--device cpu`` is a dry run of the entry path (launcher, process group over gloo, barriers, max-over-ranks, JSON)
+on the config-1 plumbing workload for the CPU test-suite; its line says so and is not a measurement.
 
 Prints ONE JSON line on rank 0.
 """
@@ -56,6 +70,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--batched", type=int, default=0,
+                    help="T > 0: a step is ONE batched launch over T tensors of the configuration (affine configs)")
     ap.add_argument("--batch", type=int, default=64, help="N of config 3")
     ap.add_argument("--ring", type=int, default=0, help="buffer pairs to rotate over (0 = enough to exceed 512 MiB)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
@@ -68,20 +84,23 @@ def parse():
     ap.add_argument("--heavy-persistent", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-batched-extra", action="store_true", help="skip the batched_16x4096 object of the default run")
     ap.add_argument("--gather", action="store_true", help="run the sharded config-5 + all-gather leg even at N = 1 (needs torchrun)")
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
     ap.add_argument("--extras", action="store_true",
-                    help="after the judged region also measure: two-stream overlap, warm-cache rate, ATen's HIP operator "
-                         "(off by default so that a rocprofv3 summary of the default run contains only the judged launches)")
+                    help="after the judged region also measure: two-stream overlap, warm-cache rate, ATen's HIP operator")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue independent steps round-robin on this many HIP streams (default 1: the judged protocol)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: dry run of the entry path over gloo (tests); not a measurement")
     return ap.parse_args()
 
 
-def metric_label(config: str, wl) -> str:
-    if config == "cfg2":
+def metric_label(config: str, wl, batched: int) -> str:
+    if config == "cfg2" and not batched:
         return BASELINE_METRIC
-    return f"elems/s + achieved HBM GB/s, {wl.name} {'x'.join(str(s) for s in wl.shape)} fp32"
+    tail = f", {batched} tensors per launch" if batched else ""
+    return f"elems/s + achieved HBM GB/s, {wl.name} {'x'.join(str(s) for s in wl.shape)} fp32{tail}"
 
 
 def per_launch_periods(step, launches: int):
@@ -95,70 +114,122 @@ def per_launch_periods(step, launches: int):
     return [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(launches)]
 
 
+def batched_plans(quantizer, x0, tensors: int, ring: int):
+    """``ring`` pre-packed plans of ``tensors`` copies of x0 each (distinct input and output buffers everywhere):
+    what pytorch/batching.py builds for a model with that many wrapped weights.  Returns (plans, outputs per plan)."""
+    from mct_quantizers_amd.hip import native
+    fast = native.fast()
+    assert fast is not None, "the batched bench needs the compiled binding (lib/_mctq_torch.so)"
+    plans, outs = [], []
+    for _ in range(ring):
+        xs = [x0.clone() for _ in range(tensors)]
+        ys = [torch.empty_like(x0) for _ in range(tensors)]
+        items = []
+        for x, y in zip(xs, ys):
+            xi, scales, zps, axis, qmin, qmax = quantizer.batch_item(x)
+            items.append((xi, y, scales, zps, axis, qmin, qmax))
+        plans.append(fast.BatchPlan(items))
+        outs.append(ys)
+    return plans, outs
+
+
+def event_timed(step, steps: int):
+    """(average period of launches 2..K in us, average over all K incl. the idle stream's start-up) by HIP events."""
+    e0, ef, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(steps):
+        step(i)
+        if i == 0:
+            ef.record()
+    e1.record()
+    torch.cuda.synchronize()
+    return ef.elapsed_time(e1) * 1e3 / max(1, steps - 1), e0.elapsed_time(e1) * 1e3 / steps
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (child process; nothing here has touched the GPU)
+        sys.exit(bench_dist.self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dry = args.device == "cpu"
+    if dry:
+        device = torch.device("cpu")
+        args.config, args.batched, args.graph, args.streams, args.extras = "cfg1", 0, False, 1, False
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist, control_plane = None, None
     if world > 1 or (args.gather and "RANK" in os.environ):
-        dist, control_plane = bench_dist.init_process_group("nccl", device,
-                                                            force_gloo=bool(os.environ.get("MCTQ_BENCH_FORCE_GLOO")))
+        dist, control_plane = bench_dist.init_process_group(
+            "gloo" if dry else "nccl", device, force_gloo=bool(os.environ.get("MCTQ_BENCH_FORCE_GLOO")))
+    ranks_seen = dist.get_world_size() if dist is not None else 1
 
     import mct_quantizers_amd as mq
     from mct_quantizers_amd import workloads
     from mct_quantizers_amd.hip import native
-    native.load()
-    if args.nt is not None:
-        native.set_tuning("nt", args.nt)
-    if args.unroll is not None:
-        native.set_tuning("unroll", args.unroll)
-    if args.heavy_unroll is not None:
-        native.set_tuning("heavy_unroll", args.heavy_unroll)
-    if args.heavy_persistent is not None:
-        native.set_tuning("heavy_persistent", args.heavy_persistent)
+    if not dry:
+        native.load()
+        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll),
+                         ("heavy_persistent", args.heavy_persistent)):
+            if val is not None:
+                native.set_tuning(key, val)
 
     # ---- workload -------------------------------------------------------------------------
     x_np = workloads.make_input(args.config, batch=args.batch)
     wl = workloads.make_workload(args.config, x_np)
     quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
-    elems = wl.numel
+    tensors = max(1, args.batched)
+    elems = wl.numel * tensors
     alg_bytes = elems * wl.bytes_per_elem
     ring = args.ring or max(2, -(-(512 << 20) // alg_bytes) + 1)
-    x0 = torch.from_numpy(x_np).cuda()
-    xs = [x0] + [x0.clone() for _ in range(ring - 1)]
-    ys = [None] * ring
+    x0 = torch.from_numpy(x_np).to(device)
+    if args.batched:
+        if not hasattr(quantizer, "batch_item"):
+            raise SystemExit(f"--batched: {wl.quantizer} has no batched launch (affine weights quantizers only)")
+        plans, plan_outs = batched_plans(quantizer, x0, tensors, ring)
+        xs, ys = None, None
 
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+        def step(i):
+            plans[i % ring]()
+    else:
+        xs = [x0] + [x0.clone() for _ in range(ring - 1)]
+        ys = [None] * ring
+        streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
 
-    def step(i):
-        if streams is None:
-            ys[i % ring] = quantizer(xs[i % ring])
-        else:
-            with torch.cuda.stream(streams[i % len(streams)]):
+        def step(i):
+            if streams is None:
                 ys[i % ring] = quantizer(xs[i % ring])
+            else:
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    ys[i % ring] = quantizer(xs[i % ring])
+    if args.batched:
+        streams = None
+
+    def dev_sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     # ---- fixed-duration pre-warm (declared; outside the timed region) --------------------------
     p0, n_pre = time.perf_counter(), 0
-    while n_pre < ring or time.perf_counter() - p0 < args.prewarm_seconds:
+    while n_pre < ring or time.perf_counter() - p0 < (0.05 if dry else args.prewarm_seconds):
         step(n_pre)
         n_pre += 1
         if n_pre % 256 == 0:
-            torch.cuda.synchronize()          # keep the launch queue bounded
-    torch.cuda.synchronize()
+            dev_sync()                        # keep the launch queue bounded
+    dev_sync()
     prewarm_s = time.perf_counter() - p0
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    kernel_variant = native.last_launch()
+    dev_sync()
+    kernel_variant = "aten cpu operator (dry run)" if dry else native.last_launch()
 
     graph = None
     if args.graph:
@@ -169,11 +240,16 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region ---------------------------------------------------------------------
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev_first = torch.cuda.Event(enable_timing=True)   # behind the FIRST launch: ev0 -> ev_first carries the host's launch latency
-    steady = graph is None and streams is None and args.steps >= 2
+    steady = graph is None and streams is None and args.steps >= 2 and not dry
+    if not dry:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_first = torch.cuda.Event(enable_timing=True)   # behind the FIRST launch: ev0 -> ev_first carries the host's launch latency
 
     def run_all(_):
+        if dry:
+            for i in range(args.steps):
+                step(i)
+            return None
         ev0.record()
         if graph is not None:
             graph.replay()
@@ -189,7 +265,7 @@ def main():
         return ev1                                 # the region's closing synchronize polls this event first
 
     wall = bench_dist.timed_region(run_all, 1, device, dist)
-    dev_ms = ev0.elapsed_time(ev1)            # events on the stream the kernels were launched on
+    dev_ms = wall * 1e3 if dry else ev0.elapsed_time(ev1)      # events on the stream the kernels were launched on
     wall, dev_ms = bench_dist.max_over_ranks([wall, dev_ms], dist, control_plane, device)
 
     value = elems * args.steps * world / wall
@@ -197,14 +273,16 @@ def main():
     if steady:
         # launches 2..K, from the end of launch 1 to the end of launch K: the period without the idle stream's start-up (the
         # host's first call + launch latency, ~5-8 us once per region -- 1.5 % of a 20-step region, 0.03 % of a 1000-step one)
-        steady_ms = bench_dist.max_over_ranks([ev_first.elapsed_time(ev1)], dist, control_plane, device)[0]
-        launch_us = steady_ms * 1e3 / (args.steps - 1)
+        own_steady_us = ev_first.elapsed_time(ev1) * 1e3 / (args.steps - 1)
+        launch_us = bench_dist.max_over_ranks([own_steady_us], dist, control_plane, device)[0]
     else:
-        launch_us = launch_us_all
+        own_steady_us = launch_us = launch_us_all
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+    wall_us = wall * 1e6 / args.steps
+    achieved_wall = alg_bytes / (wall_us * 1e-6) / 1e9
 
     result = {
-        "metric": metric_label(args.config, wl),
+        "metric": metric_label(args.config, wl, args.batched),
         "value": value,
         "unit": "elems/s",
         "n_gpus": world,
@@ -216,26 +294,41 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (portable splitmix64 generator, mct_quantizers_amd/workloads.py)",
-        "config": {"workload": wl.name, "shape": list(wl.shape), "quantizer": wl.quantizer,
+        "config": {"workload": wl.name + (f", {tensors} tensors in one batched launch" if args.batched else ""),
+                   "shape": list(wl.shape), "quantizer": wl.quantizer, "tensors_per_step": tensors,
                    "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
                    "launch": "hipGraph" if graph is not None else "eager", "streams": args.streams,
-                   "binding": "compiled" if native.fast() is not None else "ctypes",
+                   "binding": "none (dry run)" if dry else ("compiled" if native.fast() is not None else "ctypes"),
                    "prewarm_s": round(prewarm_s, 3), "prewarm_steps": n_pre,
                    "parallelism": f"replicated x{world} (weak, no collective)",
-                   "control_plane": control_plane},
-        "achieved_gbs": achieved,
+                   "control_plane": control_plane, "ranks_seen": ranks_seen},
+        "achieved_gbs": achieved_wall,                       # same clock as value / ms_per_step (host wall)
+        "achieved_gbs_steady": achieved,                     # = roofline.achieved (event period of launches 2..K)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                     "frac_wall": achieved_wall / HBM_PEAK_GBS,
+                     "frac_events_whole_region": alg_bytes / (launch_us_all * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "kernel": kernel_variant, "kernel_us": launch_us,
                      "kernel_us_is": ("average launch PERIOD inside the timed region, launches 2..K (event behind launch 1 -> event "
-                                      "behind launch K): kernel duration + the ~1.4 us bubble between back-to-back launches"
+                                      "behind launch K): kernel duration + the ~1.4 us bubble between back-to-back launches; "
+                                      "frac_wall = the same bytes over ms_per_step (host wall clock incl. the first launch's latency "
+                                      "and the closing synchronize)"
                                       if steady else "average launch PERIOD over the timed region (one event pair around K launches)"),
                      "kernel_us_incl_first_launch_latency": launch_us_all,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    if dry:
+        result["dry_run"] = "CPU dry run of the entry path (launcher, gloo process group, barriers, JSON): NOT a measurement"
+        result["roofline"] = None
+    if dist is not None:
+        # every rank's own steady period (the headline uses the slowest)
+        t = torch.tensor([own_steady_us], dtype=torch.float64, device=device if control_plane == "nccl" else "cpu")
+        got = [torch.zeros_like(t) for _ in range(ranks_seen)]
+        dist.all_gather(got, t)
+        result["per_rank_kernel_us"] = [float(v[0]) for v in got]
 
     # ---- per-launch evidence pass (outside the timed region) ---------------------------------------------
-    if args.evidence_launches > 0 and graph is None and streams is None:
+    if args.evidence_launches > 0 and graph is None and streams is None and not dry:
         try:
             periods = per_launch_periods(step, max(50, args.evidence_launches))[1:]     # first period: event after idle
             periods.sort()
@@ -251,25 +344,38 @@ def main():
             result["roofline"]["per_launch"] = {"error": repr(e)[:200]}
 
     # ---- measured HBM traffic per launch (rocprofv3 PMC passes committed under profiles/) ----------------
-    try:
-        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(args.config if args.config != "cfg3" else f"cfg3_n{args.batch}")
-        if rec is None:
-            result["roofline"]["traffic_source"] = "no PMC record for this configuration in profiles/pmc_traffic.json"
-        elif rec.get("variant") != kernel_variant:
-            result["roofline"]["traffic_source"] = (f"stale: profiles/pmc_traffic.json was taken on {rec.get('variant')!r}, "
-                                                    f"this run launched {kernel_variant!r}")
-        else:
-            result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = (f"profiles/pmc_traffic.json: {rec['variant']} at git {rec.get('git_head', '?')} "
-                                                    f"(FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
-    except OSError:
-        result["roofline"]["traffic_source"] = "profiles/pmc_traffic.json missing"
+    if not dry:
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+                key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
+                if args.batched:
+                    key = f"{key}_batched{tensors}"
+                rec = json.load(f).get(key)
+            if rec is None:
+                result["roofline"]["traffic_source"] = f"no PMC record {key!r} in profiles/pmc_traffic.json"
+            elif rec.get("variant") != kernel_variant:
+                result["roofline"]["traffic_source"] = (f"stale: profiles/pmc_traffic.json was taken on {rec.get('variant')!r}, "
+                                                        f"this run launched {kernel_variant!r}")
+            else:
+                result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = (f"profiles/pmc_traffic.json: {rec['variant']} at git {rec.get('git_head', '?')} "
+                                                        f"(FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
+        except OSError:
+            result["roofline"]["traffic_source"] = "profiles/pmc_traffic.json missing"
+
+    # ---- the last timed step's output, kept for the parity check before anything overwrites the ring ----------
+    last_slot = (args.steps - 1) % ring
+    if dry:
+        y_last = ys[last_slot]
+    elif args.batched:
+        y_last = plan_outs[last_slot]       # persistent outputs; later passes rewrite them with the same values
+    else:
+        y_last = ys[last_slot]
 
     # Extra (outside the judged region): the same K independent steps issued round-robin on two HIP streams,
     # which overlaps one kernel's tail with the next one's ramp.  Whole-job rate only; per-kernel durations
     # overlap, so this is not a roofline figure.
-    if args.extras and args.streams == 1 and graph is None:
+    if args.extras and args.streams == 1 and graph is None and not args.batched:
         try:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
             for st in s2:
@@ -290,7 +396,7 @@ def main():
     # Extras at N = 1 (outside the judged region): warm-cache rate (one buffer pair, working set inside the
     # Infinity Cache) and what the REFERENCE would execute on this GPU for the same call -- ATen's own HIP
     # fake-quant operator (only defined for the affine configurations).
-    if args.extras and world == 1 and graph is None and args.streams == 1:
+    if args.extras and world == 1 and graph is None and args.streams == 1 and not args.batched:
         try:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             wsteps = min(args.steps, 300)
@@ -333,20 +439,56 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["extras_error"] = repr(e)[:200]
 
+    # ---- default run at N = 1: the headline tensor 16 times in ONE batched launch (outside the judged region) -------
+    if (not dry and world == 1 and args.config == "cfg2" and not args.batched and not args.no_batched_extra
+            and graph is None and streams is None and hasattr(quantizer, "batch_item") and native.fast() is not None):
+        try:
+            T = 16
+            bplans, bouts = batched_plans(quantizer, x0, T, 2)
+            for i in range(6):
+                bplans[i % 2]()
+            bsteps = max(20, min(args.steps, 100))
+            b_us, b_us_all = event_timed(lambda i: bplans[i % 2](), bsteps)
+            bb = alg_bytes * T
+            same = all(torch.equal(y, bouts[(bsteps - 1) % 2][0]) for y in bouts[(bsteps - 1) % 2][1:])
+            result["batched_16x4096"] = {
+                "what": "the headline tensor 16 times (distinct buffers, 2 GiB in + 2 GiB out per launch) in ONE batched "
+                        "launch: the launch a wrapped model issues per forward (pytorch/batching.py, "
+                        "mctq_fq_batch_run); outside the judged region, same event protocol",
+                "kernel": native.last_launch(), "launches": bsteps, "kernel_us": b_us, "kernel_us_per_tensor": b_us / T,
+                "kernel_us_incl_first_launch_latency": b_us_all, "algorithmic_bytes_per_launch": bb,
+                "achieved_gbs": bb / b_us / 1e3, "frac": bb / b_us / 1e3 / HBM_PEAK_GBS,
+                "frac_of_measured_copy": bb / b_us / 1e3 / HBM_COPY_GBS,
+                "all_16_outputs_equal": bool(same),
+                "equal_to_single_launch_output": bool(torch.equal(bouts[(bsteps - 1) % 2][0], y_last))}
+            del bplans, bouts
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            result["batched_16x4096"] = {"error": repr(e)[:300]}
+
     # ---- N > 1 (or --gather under torchrun): config 5 sharded by dim 0 + ONE all-gather -----------------
-    if dist is not None and control_plane == "nccl" and (args.gather or world > 1):
+    if dist is not None and (control_plane == "nccl" or dry) and (args.gather or world > 1):
         with bench_dist.Watchdog(120.0, rank, lambda: json.dumps(result)):
             try:
-                result["sharded_cfg5"] = bench_dist.sharded_cfg5_leg(dist, rank, world, device)
+                kw = dict(rows=64, cols=128, reps=3, gather_reps=2) if dry else {}
+                leg = bench_dist.sharded_cfg5_leg(dist, rank, world, device, **kw)
+                result["sharded_cfg5"] = leg
+                result["sharded_cfg5_compute_elems_per_s"] = leg["compute_elems_per_s"]
+                result["sharded_cfg5_compute_plus_allgather_elems_per_s"] = leg["compute_plus_allgather_elems_per_s"]
+                result["sharded_cfg5_allgather_gbs_per_link"] = leg["allgather_gbs_per_link"]
             except Exception as e:  # noqa: BLE001  (extras only)
                 result["sharded_cfg5"] = {"error": repr(e)[:300]}
 
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not dry:
         from oracle import torch_cpu
         f = torch_cpu.prepare(wl.quantizer, wl.kwargs)
         x_cpu = torch.from_numpy(x_np)
         y_cpu = f(x_cpu)                                   # warm-up + parity reference
-        same = bool(torch.equal(quantizer(xs[0]).cpu(), y_cpu))
+        if args.batched:
+            same = all(bool(torch.equal(y.cpu(), y_cpu)) for y in y_last[:2]) and \
+                all(bool(torch.equal(y, y_last[0])) for y in y_last[2:])
+        else:
+            same = bool(torch.equal(y_last.cpu(), y_cpu))  # the output of the LAST timed step
         # ATen's CPU kernel stops scaling (and degrades) well before all hardware threads of a big host:
         # probe a few thread counts briefly and report the best one.
         ncpu = os.cpu_count() or 1
@@ -368,14 +510,15 @@ def main():
             el = time.perf_counter() - c0
             if el >= args.cpu_seconds or n >= 2000:
                 break
-        result["cpu_baseline"] = {"value": elems * n / el, "unit": "elems/s", "cores": best, "kind": "port",
-                                  "sample": f"{n} calls on the same {wl.name} tensor of the ATen CPU operator the "
+        result["cpu_baseline"] = {"value": wl.numel * n / el, "unit": "elems/s", "cores": best, "kind": "port",
+                                  "sample": f"{n} calls on one {wl.name} tensor of the ATen CPU operator the "
                                             f"reference calls, parameters from the oracle restatement "
                                             f"(oracle/torch_cpu.py), {el:.1f} s at the best of "
                                             f"{sorted(probe)} threads on a {ncpu}-thread host",
                                   "ms_per_call": el * 1e3 / n,
                                   "ms_per_call_by_threads": {str(k): round(v * 1e3, 3) for k, v in probe.items()},
-                                  "gpu_output_bit_equal": same}
+                                  "gpu_output_bit_equal": same,
+                                  "gpu_output_checked": "output of the last timed step"}
         if not same:
             result["parity_error"] = "GPU output differs from the CPU oracle"
 

@@ -15,6 +15,28 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(script: str, n: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher: start ``python -m torch.distributed.run`` (one rank per GPU) on
+    the same script and arguments as a CHILD process and return its exit status.  Called before anything has touched
+    the GPU (a process that has initialised HIP must not be replaced, and is not: the parent only waits).  The child's
+    stdout / stderr are inherited, so rank 0's JSON line is this process's output."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] no RANK in the environment: launching " + " ".join(cmd[1:8]) + " ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def init_process_group(backend: str, device: torch.device, force_gloo: bool = False):
     """Returns (dist module, control_plane).  ``backend`` "nccl" is probed with one all-reduce (RCCL creates its
     communicators lazily: fail here, not mid-run) and replaced by gloo for the CONTROL plane (barrier,
@@ -101,23 +123,28 @@ def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: in
         y = sq(xs[i % 3])
     t_comp = timed_region(lambda i: sq(xs[i % 3]), reps, device, dist) / reps
     y = sq(xs[0])
+    buffers = sq.gather_buffers(y) if world > 1 else None      # the 256 MiB result lives outside the timed gather
     full = None
     for _ in range(min(3, gather_reps)):
-        full = sq.all_gather(y)
+        full = sq.all_gather(y, buffers)
     box = {}
 
     def gather(i):
-        box["full"] = sq.all_gather(y)
+        box["full"] = sq.all_gather(y, buffers)
     t_gather = timed_region(gather, gather_reps, device, dist) / gather_reps
     full = box.get("full", full)
     recv = (rows - (stop - start)) * cols * 4
     ok = full is not None and tuple(full.shape) == (rows, cols) and bool(torch.equal(full[start:stop], y))
+    recv_gbs = recv / t_gather / 1e9 if t_gather > 0 else None
     return {
         "workload": f"cfg5 WeightsPOT per-channel(axis0) 4b {rows}x{cols}, dim-0 shards",
-        "scaling": "strong", "rows_per_rank": stop - start,
+        "scaling": "strong", "rows_per_rank": stop - start, "ranks": world,
         "compute_ms": t_comp * 1e3, "compute_elems_per_s": rows * cols / t_comp,
         "allgather_ms": t_gather * 1e3, "allgather_recv_bytes_per_rank": recv,
-        "allgather_recv_gbs_per_rank": recv / t_gather / 1e9 if t_gather > 0 else None,
+        "allgather_recv_gbs_per_rank": recv_gbs,
+        # xGMI is point to point: a rank receives from its world - 1 peers over world - 1 links at once
+        "allgather_gbs_per_link": recv_gbs / (world - 1) if recv_gbs is not None and world > 1 else None,
+        "allgather_output": "pre-allocated outside the timed region",
         "compute_plus_allgather_elems_per_s": rows * cols / (t_comp + t_gather),
         "gathered_rows_match_local": ok,
     }

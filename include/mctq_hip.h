@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 4
+#define MCTQ_ABI_VERSION 5
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
@@ -122,14 +122,16 @@ int mctq_fq_per_tensor_tqp(const void* x, void* y, int64_t n, int32_t dtype,
                            void* stream);
 
 /*
- * A LIST of affine fake-quantizations in one call -- one launch per group of up to 32 tensors of one storage
+ * A LIST of affine fake-quantizations in one call -- one launch per group of up to 48 tensors of one storage
  * type.  PytorchQuantizationWrapper.forward re-quantizes each wrapped layer's weights on every forward
  * (pytorch/quantize_wrapper.py:228-240); a model has tens of such layers, and each separate launch pays its own
  * host cost and ~2 us of ramp/drain on the GPU.  `items` is a HOST array (it is consumed before the call returns:
- * the descriptors travel in the kernel arguments, so the call is legal under hipGraph capture); every pointer
+ * the descriptors and the block -> tensor map travel in the kernel arguments, so the call is legal under hipGraph
+ * capture); every pointer
  * inside an item is a DEVICE pointer with the meaning it has in mctq_fq_per_channel.  Per-tensor quantization is
  * outer = channels = 1, inner = n with 1-element device scales / zero_points and flags = MCTQ_FQ_ITEM_PER_TENSOR.  Tensors the batched kernel cannot
- * take (x or y not 16-byte aligned, >= 2^31 elements, float64) are launched one by one on the same stream.
+ * take (x or y not 16-byte aligned, >= 2^31 elements, float64, per-channel rows shorter than 32 elements) are
+ * launched one by one on the same stream, after the batched launches.
  * All items are validated before anything is launched.
  */
 typedef struct mctq_fq_item {
@@ -148,6 +150,21 @@ typedef struct mctq_fq_item {
 #define MCTQ_FQ_ITEM_PER_TENSOR 1
 
 int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream);
+
+/*
+ * The same list as ONE launch per storage type, whatever its length (a whole model's weights): the descriptors are
+ * packed on the host into a table whose DEVICE copy the kernel reads by scalar loads.
+ *   mctq_fq_batch_pack  writes the table for `items` into host_table (capacity bytes) and returns its size in bytes;
+ *                       with host_table == NULL or a capacity that is too small it writes nothing and returns the size
+ *                       needed.  Negative: MCTQ_E_ARG.  Pure host code (no HIP call).
+ *   mctq_fq_batch_run   launches a packed table: host_table is the packed bytes (launch geometry, and the tensors
+ *                       that are launched one by one, are read from it), device_table a 16-byte aligned device copy
+ *                       of the same bytes, made and owned by the caller (the library never allocates or copies).
+ * The table holds the items' device pointers: pack again (and refresh the device copy) when one of them changes.
+ * Results are bit-identical to mctq_fq_batched and to the single-tensor entry points.
+ */
+int64_t mctq_fq_batch_pack(const mctq_fq_item* items, int32_t n_items, void* host_table, int64_t capacity);
+int mctq_fq_batch_run(const void* host_table, const void* device_table, void* stream);
 
 /*
  * Integer-code output of the affine quantizers: codes[i] = clamp(rint(x[i] * (1/scale)) + zero_point, quant_min,

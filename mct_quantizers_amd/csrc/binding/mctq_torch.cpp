@@ -465,18 +465,46 @@ void lutplan_dealloc(PyObject* self) {
 PyTypeObject LutPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
 // ---- a whole list of weights, pre-packed: plan = BatchPlan(items) with items = sequence of
-//      (x, y, scales, zero_points | None, axis | None, quant_min, quant_max); plan() re-quantizes every x into ITS y
-//      (caller-owned, persistent output buffers) with one mctq_fq_batched call and returns None -- no allocation, no
-//      per-tensor Python.  The device pointers are re-read from the tensors on every call (a Parameter whose storage
-//      was swapped is followed); shapes, strides and dtypes are fixed at construction and re-checked.
+//      (x, y, scales, zero_points | None, axis | None, quant_min, quant_max[, watch]); plan() re-quantizes every x
+//      into ITS y (caller-owned, persistent output buffers) with ONE launch per storage type, whatever the number of
+//      tensors (mctq_fq_batch_pack / mctq_fq_batch_run: the descriptors live in a device table owned by the plan), and
+//      returns None -- no allocation, no per-tensor Python.
+//      Every call re-reads the tensors: the device pointers of x, y, scales and zero_points are followed (a Parameter
+//      whose storage was swapped; the table is re-packed and re-uploaded then -- one small synchronous copy, not legal
+//      under stream capture); a change of sizes, strides, dtype or device returns NotImplemented (the caller rebuilds
+//      the plan), as does a stale `watch`.
+//      watch = (dict, ((name, object, version), ...)): dict[name] must still BE `object` and, for version >= 0, that
+//      tensor's in-place version counter must still equal `version` -- how the plan notices that a quantizer's public
+//      parameters were replaced or edited in place since it was built.
+struct BatchWatch { PyObject* dict; PyObject* name; PyObject* obj; int64_t version; };
+
 struct BatchPlan {
   PyObject_HEAD
   vectorcallfunc vectorcall;
   std::vector<mctq_fq_item>* items;
   std::vector<PyObject*>* refs;          // 4 per item: x, y, scales, zero_points (or Py_None)
-  std::vector<int64_t>* numel;
+  std::vector<std::vector<int64_t>>* sizes;
+  std::vector<int64_t>* axes;            // -1: per tensor
+  std::vector<BatchWatch>* watch;
+  std::vector<uint8_t>* host_table;
+  at::Tensor* dev_table;
+  bool uploaded;
   c10::DeviceIndex device;
 };
+
+bool batchplan_upload(BatchPlan* p) {
+  const int64_t need = mctq_fq_batch_pack(p->items->data(), (int32_t)p->items->size(), nullptr, 0);
+  if (need < 0) { raise_rc((int)need, "mctq_fq_batch_pack"); return false; }
+  p->host_table->resize((size_t)need);
+  const int64_t got = mctq_fq_batch_pack(p->items->data(), (int32_t)p->items->size(), p->host_table->data(), need);
+  if (got != need) { raise_rc((int)got, "mctq_fq_batch_pack"); return false; }
+  if (!p->dev_table->defined() || p->dev_table->numel() < need)
+    *p->dev_table = at::Tensor(at::detail::empty_cuda({need}, c10::ScalarType::Byte, c10::Device(c10::kCUDA, p->device), std::nullopt));
+  const auto stream = c10::hip::getCurrentHIPStream(p->device);
+  c10::hip::memcpy_and_sync(p->dev_table->mutable_data_ptr(), p->host_table->data(), need, hipMemcpyHostToDevice, stream.stream());
+  p->uploaded = true;
+  return true;
+}
 
 PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, PyObject* kwnames) {
   HANDLE_TH_ERRORS
@@ -486,24 +514,55 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
     return nullptr;
   }
   if (torch::jit::tracer::isTracing()) return not_implemented();
+  for (const BatchWatch& w : *p->watch) {
+    PyObject* cur = PyDict_GetItemWithError(w.dict, w.name);          // borrowed
+    if (!cur) { if (PyErr_Occurred()) return nullptr; return not_implemented(); }
+    if (cur != w.obj) return not_implemented();
+    if (w.version >= 0 && (!THPVariable_Check(cur) || (int64_t)THPVariable_Unpack(cur)._version() != w.version))
+      return not_implemented();
+  }
   const size_t n = p->items->size();
+  bool dirty = !p->uploaded;
   for (size_t i = 0; i < n; ++i) {
     const at::Tensor& x = THPVariable_Unpack((*p->refs)[4 * i]);
     const at::Tensor& y = THPVariable_Unpack((*p->refs)[4 * i + 1]);
-    if (x.numel() != (*p->numel)[i] || y.numel() != (*p->numel)[i] || !x.is_cuda() || !y.is_cuda() ||
+    const at::Tensor& sc = THPVariable_Unpack((*p->refs)[4 * i + 2]);
+    mctq_fq_item& d = (*p->items)[i];
+    const std::vector<int64_t>& sz = (*p->sizes)[i];
+    if (x.sizes() != c10::IntArrayRef(sz) || y.sizes() != x.sizes() || !x.is_cuda() || !y.is_cuda() ||
         x.device().index() != p->device || y.device().index() != p->device ||
         !x.unsafeGetTensorImpl()->is_non_overlapping_and_dense() || x.strides() != y.strides() ||
-        dtype_code(x.scalar_type()) != (*p->items)[i].dtype || y.scalar_type() != x.scalar_type()) {
-      PyErr_Format(PyExc_RuntimeError, "BatchPlan: tensor %zu changed shape, layout, dtype or device since the plan was built", i);
-      return nullptr;
+        dtype_code(x.scalar_type()) != d.dtype || y.scalar_type() != x.scalar_type())
+      return not_implemented();
+    int64_t outer, c, inner;
+    const int64_t axis = (*p->axes)[i];
+    if (axis < 0) { outer = 1; c = 1; inner = x.numel(); }
+    else channel_view(x, axis, &outer, &c, &inner);
+    if (outer != d.outer || c != d.channels || inner != d.inner) return not_implemented();   // same sizes, other strides
+    const int64_t want = axis < 0 ? 1 : c;
+    if (sc.scalar_type() != c10::ScalarType::Float || !sc.is_contiguous() || sc.device() != x.device() || sc.numel() != want)
+      return not_implemented();
+    const void* zp = nullptr;
+    if ((*p->refs)[4 * i + 3] != Py_None) {
+      const at::Tensor& z = THPVariable_Unpack((*p->refs)[4 * i + 3]);
+      if (z.scalar_type() != c10::ScalarType::Int || !z.is_contiguous() || z.device() != x.device() || z.numel() != want)
+        return not_implemented();
+      zp = z.const_data_ptr();
     }
-    (*p->items)[i].x = x.const_data_ptr();
-    (*p->items)[i].y = y.mutable_data_ptr();
+    const void* xp = x.const_data_ptr();
+    void* yp = y.mutable_data_ptr();
+    const void* sp = sc.const_data_ptr();
+    if (xp != d.x || yp != d.y || sp != (const void*)d.scales || zp != (const void*)d.zero_points) {
+      d.x = xp; d.y = yp; d.scales = (const float*)sp; d.zero_points = (const int32_t*)zp;
+      dirty = true;
+    }
   }
   if (n > 0) {
     DeviceScope scope(p->device);
-    const int rc = mctq_fq_batched(p->items->data(), (int32_t)n, (void*)c10::hip::getCurrentHIPStream(p->device).stream());
-    if (rc) return raise_rc(rc, "mctq_fq_batched");
+    if (dirty && !batchplan_upload(p)) return nullptr;
+    const int rc = mctq_fq_batch_run(p->host_table->data(), p->dev_table->const_data_ptr(),
+                                     (void*)c10::hip::getCurrentHIPStream(p->device).stream());
+    if (rc) return raise_rc(rc, "mctq_fq_batch_run");
   }
   Py_RETURN_NONE;
   END_HANDLE_TH_ERRORS
@@ -512,8 +571,29 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
 void batchplan_dealloc(PyObject* self) {
   BatchPlan* p = (BatchPlan*)self;
   if (p->refs) for (PyObject* o : *p->refs) Py_XDECREF(o);
-  delete p->items; delete p->refs; delete p->numel;
+  if (p->watch) for (BatchWatch& w : *p->watch) { Py_XDECREF(w.dict); Py_XDECREF(w.name); Py_XDECREF(w.obj); }
+  delete p->items; delete p->refs; delete p->sizes; delete p->axes; delete p->watch; delete p->host_table; delete p->dev_table;
   Py_TYPE(self)->tp_free(self);
+}
+
+// watch = (dict, ((name, object, version), ...)); returns an error text or nullptr
+const char* batchplan_add_watch(BatchPlan* p, PyObject* w) {
+  if (w == Py_None) return nullptr;
+  if (!PyTuple_Check(w) || PyTuple_GET_SIZE(w) != 2 || !PyDict_Check(PyTuple_GET_ITEM(w, 0)) || !PyTuple_Check(PyTuple_GET_ITEM(w, 1)))
+    return "watch: (dict, ((name, object, version), ...))";
+  PyObject* dict = PyTuple_GET_ITEM(w, 0);
+  PyObject* ents = PyTuple_GET_ITEM(w, 1);
+  for (Py_ssize_t j = 0; j < PyTuple_GET_SIZE(ents); ++j) {
+    PyObject* e = PyTuple_GET_ITEM(ents, j);
+    if (!PyTuple_Check(e) || PyTuple_GET_SIZE(e) != 3 || !PyUnicode_Check(PyTuple_GET_ITEM(e, 0)) || !PyLong_Check(PyTuple_GET_ITEM(e, 2)))
+      return "watch entry: (name, object, version)";
+    BatchWatch bw;
+    bw.dict = dict; bw.name = PyTuple_GET_ITEM(e, 0); bw.obj = PyTuple_GET_ITEM(e, 1);
+    bw.version = PyLong_AsLongLong(PyTuple_GET_ITEM(e, 2));
+    Py_INCREF(bw.dict); Py_INCREF(bw.name); Py_INCREF(bw.obj);
+    p->watch->push_back(bw);
+  }
+  return nullptr;
 }
 
 PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
@@ -524,13 +604,18 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   BatchPlan* p = (BatchPlan*)type->tp_alloc(type, 0);
   if (!p) { Py_DECREF(seq); return nullptr; }
   p->vectorcall = batchplan_vectorcall;
-  p->items = new std::vector<mctq_fq_item>(); p->refs = new std::vector<PyObject*>(); p->numel = new std::vector<int64_t>();
+  p->items = new std::vector<mctq_fq_item>(); p->refs = new std::vector<PyObject*>();
+  p->sizes = new std::vector<std::vector<int64_t>>(); p->axes = new std::vector<int64_t>();
+  p->watch = new std::vector<BatchWatch>(); p->host_table = new std::vector<uint8_t>(); p->dev_table = new at::Tensor();
+  p->uploaded = false;
   p->device = -1;
   const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
   const char* err = nullptr;
   for (Py_ssize_t i = 0; i < n && !err; ++i) {
     PyObject* it = PySequence_Fast_GET_ITEM(seq, i);
-    if (!PyTuple_Check(it) || PyTuple_GET_SIZE(it) != 7) { err = "item: (x, y, scales, zero_points, axis, quant_min, quant_max)"; break; }
+    if (!PyTuple_Check(it) || (PyTuple_GET_SIZE(it) != 7 && PyTuple_GET_SIZE(it) != 8)) {
+      err = "item: (x, y, scales, zero_points, axis, quant_min, quant_max[, watch])"; break;
+    }
     int dt, dty;
     const at::Tensor* xp = eligible(PyTuple_GET_ITEM(it, 0), &dt);
     const at::Tensor* yp = eligible(PyTuple_GET_ITEM(it, 1), &dty);
@@ -564,8 +649,10 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
     d.quant_min = (int32_t)qmin; d.quant_max = (int32_t)qmax; d.dtype = dt;
     d.flags = axis_o == Py_None ? MCTQ_FQ_ITEM_PER_TENSOR : 0;
     p->items->push_back(d);
-    p->numel->push_back(xp->numel());
+    p->sizes->push_back(xp->sizes().vec());
+    p->axes->push_back(axis_o == Py_None ? -1 : axis);
     for (int k = 0; k < 4; ++k) { PyObject* o = PyTuple_GET_ITEM(it, k); Py_INCREF(o); p->refs->push_back(o); }
+    if (PyTuple_GET_SIZE(it) == 8) err = batchplan_add_watch(p, PyTuple_GET_ITEM(it, 7));
   }
   Py_DECREF(seq);
   if (err) { Py_DECREF(p); PyErr_Format(PyExc_TypeError, "BatchPlan: %s", err); return nullptr; }

@@ -2,18 +2,29 @@
 //
 // A LIST of affine fake-quantizations in one launch.  The reference re-quantizes every wrapped layer's weights
 // on every forward (pytorch/quantize_wrapper.py:228-240: one quantizer call per weight attribute), i.e. tens of
-// launches per model forward, each paying its own launch cost and ~2 us of ramp/drain (profiles/r02).  Here the
-// descriptors of up to kMaxBatch tensors travel in the kernel arguments (no device-side table, no memcpy: legal
-// under hipGraph capture) and one grid covers all of them; block -> (tensor, tile) by a scan of the
-// wave-uniform tile offsets.
+// launches per model forward, each paying its own launch cost and ~2 us of ramp/drain (profiles/r02).  Here one grid
+// covers all of them.
 //
-// Per tile (256 * U lane-vectors of one tensor, never crossing tensors):
+// Block -> (tensor, tile) in O(1): the grid is cut into CHUNKS of 2^shift blocks, every tensor starts on a chunk
+// boundary (its last chunk may hold a few idle blocks), and a byte / half-word per chunk names the tensor.  A block
+// therefore reads ONE map word and ONE 64-byte descriptor by scalar loads before it can issue its data loads
+// (round 2 scanned up to 32 descriptors per block: 0.6 us on every block's critical path, 17 % of the launch at 32
+// tensors -- profiles/r03/batched_shape_probe_before.log).
+//
+// Two sources for the descriptors, one kernel body:
+//   KernargSrc  descriptors + chunk map travel in the kernel arguments (<= 4 KiB: 48 tensors, 960 chunks): no device
+//               table, no memcpy, legal under hipGraph capture -- mctq_fq_batched().
+//   TableSrc    a caller-owned device copy of a table packed on the host by mctq_fq_batch_pack(): any number of
+//               tensors in ONE launch (a whole model's weights) -- mctq_fq_batch_run().
+//
+// Per tile (256 * U lane-vectors of one tensor, contiguous, never crossing tensors):
 //   - the tile lies inside ONE (outer, channel) row  -> the row's scale / zero point arrive by scalar loads and
 //     sit in SGPRs, exactly as rows_kernel does (Linear / conv weights quantized along axis 0, per-tensor items);
 //   - the tile covers exactly TWO rows (rows longer than a tile that do not divide into tiles): both rows' parameters in
 //     SGPRs, a lane-vector selects by its position relative to the boundary;
-//   - otherwise every lane-vector finds its row with one 32-bit division and reads its parameters from the
-//     (L1/L2-resident) tables; vectors that straddle rows go element by element.
+//   - otherwise (rows shorter than a tile) every lane-vector finds its row with one float-reciprocal division
+//     (div_small) and reads its parameters from the (L1/L2-resident) tables; vectors that straddle rows go element by
+//     element.
 // Arithmetic: AffineOp (mctq_kernels.hpp), the same expression as every other affine entry point.
 #include "mctq_kernels.hpp"
 
@@ -21,104 +32,139 @@ using namespace mctq;
 
 namespace mctq {
 
-constexpr int kMaxBatch = 32;
+constexpr int kMaxBatch = 48;            // descriptors per kernel-argument launch
+constexpr int kMaxChunksK = 960;         // chunk-map bytes in the kernel arguments
+constexpr uint32_t kMaxChunksT = 16384;  // chunk-map entries of a packed table (2 bytes each)
+constexpr int kBatchU = 4;
 
-struct BatchItem {
+struct __attribute__((aligned(16))) BatchItem {   // 64 bytes
   const void* x;
   void* y;
   const float* scales;
   const int32_t* zps;
-  uint32_t n;            // elements, < 2^31
+  uint32_t n;            // elements, < 2^31 - tile
   uint32_t inner;
   uint32_t channels;
-  uint32_t tile_begin;   // first tile (= block) of this tensor in the launch
+  uint32_t tile_begin;   // first block of this tensor in the launch (a multiple of the chunk size)
+  uint32_t tiles;        // blocks that have work; the rest of the last chunk is idle
+  uint32_t reserved;
   float lo, hi;
 };
+static_assert(sizeof(BatchItem) == 64, "descriptor layout");
 
-struct BatchArgs {
+struct KernargSrc {
   BatchItem it[kMaxBatch];
-  int n_items;
+  uint32_t map[kMaxChunksK / 4];         // one byte per chunk
+  uint32_t shift;
+  __device__ __forceinline__ uint32_t lookup(uint32_t chunk) const { return (map[chunk >> 2] >> ((chunk & 3u) * 8u)) & 0xffu; }
+  __device__ __forceinline__ const BatchItem& item(uint32_t i) const { return it[i]; }
+};
+static_assert(sizeof(KernargSrc) <= 4096, "kernel arguments");
+
+struct TableSrc {
+  const BatchItem* __restrict__ it;      // device
+  const uint32_t* __restrict__ map;      // device, one half-word per chunk
+  uint32_t shift;
+  __device__ __forceinline__ uint32_t lookup(uint32_t chunk) const { return (map[chunk >> 1] >> ((chunk & 1u) * 16u)) & 0xffffu; }
+  __device__ __forceinline__ const BatchItem& item(uint32_t i) const { return it[i]; }
 };
 
-template <class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void batched_kernel(const BatchArgs a) {
+// The descriptor's pointers arrive through scalar loads, so the compiler cannot infer their address space (it would
+// emit flat_load / flat_store and a vector load + readfirstlane for the row parameters): say it.  x / y are global
+// memory; the parameter tables are not written by this kernel, so uniform reads of them go through the scalar cache.
+#define MCTQ_GLOBAL __attribute__((address_space(1)))
+#define MCTQ_CONST __attribute__((address_space(4)))
+
+template <class TI, class TO, int NT>
+struct GIO {
   typedef IO<TI, TO> io;
+  __device__ __forceinline__ static typename io::VI load(const TI MCTQ_GLOBAL* p) {
+    const typename io::VI MCTQ_GLOBAL* q = reinterpret_cast<const typename io::VI MCTQ_GLOBAL*>(p);
+    if (NT != 0) return __builtin_nontemporal_load(q);
+    return *q;
+  }
+  __device__ __forceinline__ static void store(TO MCTQ_GLOBAL* p, typename io::VO v) {
+    typename io::VO MCTQ_GLOBAL* q = reinterpret_cast<typename io::VO MCTQ_GLOBAL*>(p);
+    if (NT == 1) __builtin_nontemporal_store(v, q);
+    else *q = v;
+  }
+};
+
+struct BatchParams {
+  const float MCTQ_CONST* s_uniform;     // same tables, two views: wave-uniform reads (scalar loads) ...
+  const int32_t MCTQ_CONST* z_uniform;
+  const float MCTQ_GLOBAL* s_lane;       // ... and per-lane reads
+  const int32_t MCTQ_GLOBAL* z_lane;
+  __device__ __forceinline__ AffineOp::Param uniform(uint32_t c) const {
+    return AffineOp::make(s_uniform[c], z_uniform ? z_uniform[c] : 0);
+  }
+  __device__ __forceinline__ AffineOp::Param lane(uint32_t c) const {
+    return AffineOp::make(s_lane[c], z_lane ? z_lane[c] : 0);
+  }
+};
+
+template <bool FULL, class TI, class TO, int U, int NT>
+__device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t e0, const uint32_t count) {
+  typedef IO<TI, TO> io;
+  typedef GIO<TI, TO, NT> gio;
   constexpr uint32_t N = io::N;
-  constexpr uint32_t TILE = kThreads * U * N;
-  int i = 0;
-  for (int j = 1; j < a.n_items; ++j)                       // wave-uniform scan over <= 32 kernel-argument words
-    if (blockIdx.x >= a.it[j].tile_begin) i = j;
-  const BatchItem& it = a.it[i];
-  const TI* __restrict__ x = static_cast<const TI*>(it.x);
-  TO* __restrict__ y = static_cast<TO*>(it.y);
-  const uint32_t n = it.n, inner = it.inner, channels = it.channels;
-  const uint32_t e0 = (blockIdx.x - it.tile_begin) * TILE;
-  const uint32_t count = n - e0 < TILE ? n - e0 : TILE;
+  const TI MCTQ_GLOBAL* __restrict__ x = (const TI MCTQ_GLOBAL*)it.x;
+  TO MCTQ_GLOBAL* __restrict__ y = (TO MCTQ_GLOBAL*)it.y;
+  const uint32_t inner = it.inner, channels = it.channels;
+  BatchParams prm;
+  prm.s_uniform = (const float MCTQ_CONST*)it.scales; prm.z_uniform = (const int32_t MCTQ_CONST*)it.zps;
+  prm.s_lane = (const float MCTQ_GLOBAL*)it.scales; prm.z_lane = (const int32_t MCTQ_GLOBAL*)it.zps;
   AffineOp op;
-  op.scales = it.scales; op.zps = it.zps; op.lo = it.lo; op.hi = it.hi;
+  op.scales = nullptr; op.zps = nullptr; op.lo = it.lo; op.hi = it.hi;
   const NoBook book;
 
   // data loads first; the row search / parameter fetch below runs under their latency
   typename io::VI v[U];
-  const bool full = count == TILE;                          // wave-uniform
-  if (full) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(x + e0 + (u * kThreads + threadIdx.x) * N);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t off = (u * kThreads + threadIdx.x) * N;
-      if (off + N <= count) v[u] = io::template load<NT>(x + e0 + off);
-    }
+  for (int u = 0; u < U; ++u) {
+    const uint32_t off = (u * kThreads + threadIdx.x) * N;
+    if (FULL || off + N <= count) v[u] = gio::load(x + e0 + off);
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  const uint32_t row0 = e0 / inner;                         // uniform
-  const uint32_t row_last = (e0 + count - 1) / inner;
-  if (row0 == row_last) {
+  uint32_t row0 = 0, rem0 = e0;
+  if (channels > 1) {                                        // uniform; per-tensor items have one row
+    row0 = e0 / inner;
+    rem0 = e0 - row0 * inner;
+  }
+  const uint32_t c0 = row0 < channels ? row0 : row0 % channels;     // outer == 1 (weights along axis 0): no modulo
+
+  if (channels == 1 || rem0 + count <= inner) {
     // ---- one row: parameters in SGPRs ----
-    const uint32_t c = channels > 1 ? row0 % channels : 0;
-    const AffineOp::Param p = op.fetch(c);
-    if (full) {
+    const AffineOp::Param p = prm.uniform(c0);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {
+      const uint32_t off = (u * kThreads + threadIdx.x) * N;
+      if (FULL || off + N <= count) {
         float in[N], out[N];
         io::unpack(v[u], in);
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
-        io::template store<NT>(y + e0 + (u * kThreads + threadIdx.x) * N, io::pack(out));
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t off = (u * kThreads + threadIdx.x) * N;
-        if (off + N <= count) {
-          float in[N], out[N];
-          io::unpack(v[u], in);
-#pragma unroll
-          for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
-          io::template store<NT>(y + e0 + off, io::pack(out));
-        } else {
-          for (uint32_t j = 0; j < N && off + j < count; ++j)
-            y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], p, book);
-        }
+        gio::store(y + e0 + off, io::pack(out));
+      } else {
+        for (uint32_t j = 0; j < N && off + j < count; ++j)
+          y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], p, book);
       }
     }
     return;
   }
 
-  if (row_last == row0 + 1) {
-    // ---- exactly two rows (rows at least a tile long, e.g. 11008-wide Linear weights): both parameter sets in SGPRs,
+  if (rem0 + count <= 2 * inner) {
+    // ---- exactly two rows (rows at least half a tile long): both parameter sets in SGPRs,
     //      a lane-vector picks by its position relative to the row boundary -- no per-lane division or table read ----
-    const uint32_t c0 = channels > 1 ? row0 % channels : 0;
-    const uint32_t c1 = channels > 1 ? (c0 + 1 == channels ? 0 : c0 + 1) : 0;
-    const AffineOp::Param p0 = op.fetch(c0), p1 = op.fetch(c1);
-    const uint32_t bnd = (row0 + 1) * inner - e0;             // elements of the tile that belong to row0 (0 < bnd < count)
+    const uint32_t c1 = c0 + 1 == channels ? 0 : c0 + 1;
+    const AffineOp::Param p0 = prm.uniform(c0), p1 = prm.uniform(c1);
+    const uint32_t bnd = inner - rem0;                       // elements of the tile that belong to row0 (0 < bnd < count)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t off = (u * kThreads + threadIdx.x) * N;
-      if (off >= count) continue;
-      if (off + N <= count) {
+      if (!FULL && off >= count) continue;
+      if (FULL || off + N <= count) {
         float in[N], out[N];
         io::unpack(v[u], in);
         if (off + N <= bnd || off >= bnd) {
@@ -131,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void batched_kernel(const BatchArgs a) {
 #pragma unroll
           for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], off + j < bnd ? p0 : p1, book);
         }
-        io::template store<NT>(y + e0 + off, io::pack(out));
+        gio::store(y + e0 + off, io::pack(out));
       } else {
         for (uint32_t j = 0; j < N && off + j < count; ++j)
           y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], off + j < bnd ? p0 : p1, book);
@@ -140,28 +186,35 @@ __global__ __launch_bounds__(kThreads) void batched_kernel(const BatchArgs a) {
     return;
   }
 
-  // ---- several rows in the tile: per lane-vector parameters ----
-  // Pass 1 finds every vector's row and issues its table reads (U independent loads in flight, not U dependent
-  // round trips to L2); pass 2 inverts the scales and applies.
+  // ---- several rows in the tile (inner < tile / 2): per lane-vector parameters ----
+  // Pass 1 finds every vector's row (positions inside the tile are < 2^24: one float multiply + two integer
+  // corrections) and issues its table reads (U independent loads in flight); pass 2 inverts the scales and applies.
+  const float r_inner = 1.0f / (float)inner;
+  const uint32_t nrows = (rem0 + count - 1) / inner + 1;      // uniform
+  const bool wraps = c0 + nrows > channels;                   // uniform: some row of the tile starts a new outer slice
+  const bool small_c = (uint64_t)channels + nrows < (1u << 24);
+  const float r_channels = 1.0f / (float)channels;
   uint32_t cc[U], rr[U];
   float sv[U];
   int32_t zv[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
-    const uint32_t pos = e0 + (off < count ? off : 0);
-    const uint32_t row = pos / inner;
-    rr[u] = pos - row * inner;
-    cc[u] = channels > 1 ? row % channels : 0;
-    sv[u] = op.scales[cc[u]];
-    zv[u] = op.zps ? op.zps[cc[u]] : 0;
+    const uint32_t pos = rem0 + ((FULL || off < count) ? off : 0);
+    const uint32_t lrow = div_small(pos, inner, r_inner);
+    rr[u] = pos - lrow * inner;
+    uint32_t c = c0 + lrow;
+    if (wraps) c = small_c ? c - div_small(c, channels, r_channels) * channels : c % channels;
+    cc[u] = c;
+    sv[u] = prm.s_lane[c];
+    zv[u] = prm.z_lane ? prm.z_lane[c] : 0;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
-    if (off >= count) continue;
+    if (!FULL && off >= count) continue;
     uint32_t rem = rr[u], c = cc[u];
-    if (off + N <= count) {
+    if (FULL || off + N <= count) {
       float in[N], out[N];
       io::unpack(v[u], in);
       if (rem + N <= inner) {                               // the vector lies in one row
@@ -171,42 +224,87 @@ __global__ __launch_bounds__(kThreads) void batched_kernel(const BatchArgs a) {
       } else {
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-          out[j] = op.apply(in[j], op.fetch(c), book);
+          out[j] = op.apply(in[j], prm.lane(c), book);
           if (++rem == inner) { rem = 0; if (++c == channels) c = 0; }
         }
       }
-      io::template store<NT>(y + e0 + off, io::pack(out));
+      gio::store(y + e0 + off, io::pack(out));
     } else {
       for (uint32_t j = 0; j < N && off + j < count; ++j) {
-        y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], op.fetch(c), book);
+        y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], prm.lane(c), book);
         if (++rem == inner) { rem = 0; if (++c == channels) c = 0; }
       }
     }
   }
 }
 
-template <class TI, class TO>
-static int launch_batch(const BatchArgs& a, uint32_t tiles, int64_t out_bytes, hipStream_t st) {
-  constexpr int U = 4;
-  MCTQ_WITH_MODE(nt_mode(out_bytes) == 0 ? 1 : nt_mode(out_bytes), false, {
-    hipLaunchKernelGGL((batched_kernel<TI, TO, U, NT>), dim3(tiles), dim3(kThreads), 0, st, a);
-    note<AffineOp, TI, TO>("batched_kernel", U, NT);
-  });
-  return check_launch("batched launch");
+template <class TI, class TO, int U, int NT, class Src>
+__device__ __forceinline__ void batched_block(const Src& src) {
+  constexpr uint32_t TILE = kThreads * U * IO<TI, TO>::N;
+  const uint32_t i = src.lookup(blockIdx.x >> src.shift);    // scalar loads: one map word, then one descriptor
+  // the whole 64-byte descriptor in ONE scalar load (left to itself the compiler fetches tile_begin / tiles first
+  // and the pointers behind the idle-block test: one more dependent round trip in front of the data loads)
+  typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+  union { u32x16 w; BatchItem it; } d;
+  d.w = *reinterpret_cast<const u32x16*>(&src.item(i));
+  asm volatile("" : "+s"(d.w));
+  const BatchItem& it = d.it;
+  const uint32_t t = blockIdx.x - it.tile_begin;
+  if (t >= it.tiles) return;                                 // idle block at the end of the tensor's last chunk
+  const uint32_t e0 = t * TILE;
+  const uint32_t left = it.n - e0;
+  if (left >= TILE) batched_tile<true, TI, TO, U, NT>(it, e0, TILE);      // wave-uniform: straight-line code
+  else batched_tile<false, TI, TO, U, NT>(it, e0, left);
+}
+
+template <class TI, class TO, int U, int NT>
+__global__ __launch_bounds__(kThreads) void batched_kernel(const KernargSrc src) {
+  batched_block<TI, TO, U, NT>(src);
+}
+
+// Three scalar arguments (not a struct): with -amdgpu-kernarg-preload-count they arrive in SGPRs at wave start, so the
+// map word can be requested in the block's first instructions instead of behind a kernel-argument load.
+template <class TI, class TO, int U, int NT>
+__global__ __launch_bounds__(kThreads) void batched_table_kernel(const BatchItem* __restrict__ it,
+                                                                 const uint32_t* __restrict__ map, uint32_t shift) {
+  TableSrc src;
+  src.it = it; src.map = map; src.shift = shift;
+  batched_block<TI, TO, U, NT>(src);
 }
 
 template <class TI, class TO>
-static uint32_t batch_tile_elems() { return kThreads * 4 * IO<TI, TO>::N; }
+static constexpr uint32_t batch_tile_elems() { return kThreads * kBatchU * IO<TI, TO>::N; }
+static uint32_t tile_elems_of(int dtype) {
+  return dtype == MCTQ_DT_F32 ? batch_tile_elems<float, float>() : batch_tile_elems<_Float16, _Float16>();
+}
 
-}  // namespace mctq
+template <class TI, class TO>
+static int launch_batch(const KernargSrc& src, uint32_t grid, int64_t out_bytes, hipStream_t st) {
+  MCTQ_WITH_MODE(nt_mode(out_bytes) == 0 ? 1 : nt_mode(out_bytes), false, {
+    hipLaunchKernelGGL((batched_kernel<TI, TO, kBatchU, NT>), dim3(grid), dim3(kThreads), 0, st, src);
+    note<AffineOp, TI, TO>("batched_kernel", kBatchU, NT);
+  });
+  return check_launch("batched launch");
+}
+template <class TI, class TO>
+static int launch_batch(const TableSrc& src, uint32_t grid, int64_t out_bytes, hipStream_t st) {
+  MCTQ_WITH_MODE(nt_mode(out_bytes) == 0 ? 1 : nt_mode(out_bytes), false, {
+    hipLaunchKernelGGL((batched_table_kernel<TI, TO, kBatchU, NT>), dim3(grid), dim3(kThreads), 0, st, src.it, src.map, src.shift);
+    note<AffineOp, TI, TO>("batched_kernel<table>", kBatchU, NT);
+  });
+  return check_launch("batched launch");
+}
+template <class Src>
+static int launch_batch_dt(int dt, const Src& src, uint32_t grid, int64_t out_bytes, hipStream_t st) {
+  if (dt == MCTQ_DT_F32) return launch_batch<float, float>(src, grid, out_bytes, st);
+  if (dt == MCTQ_DT_F16) return launch_batch<_Float16, _Float16>(src, grid, out_bytes, st);
+  return launch_batch<__bf16, __bf16>(src, grid, out_bytes, st);
+}
 
-extern "C" {
-
-int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream) {
+// ---- host: which tensors one grid can take, and how the grid is cut ---------------------------------------
+static int validate_items(const mctq_fq_item* items, int32_t n_items) {
   if (n_items < 0) return fail_arg("n_items < 0");
   if (n_items > 0 && !items) return fail_arg("items is NULL");
-  hipStream_t st = (hipStream_t)stream;
-  // validate everything before the first launch: a bad descriptor must not leave the list half done
   for (int32_t k = 0; k < n_items; ++k) {
     const mctq_fq_item& d = items[k];
     if (d.outer < 0 || d.channels < 0 || d.inner < 0) return fail_arg("negative extent");
@@ -217,62 +315,215 @@ int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream) {
     if (d.dtype == MCTQ_DT_F64 && (d.flags & MCTQ_FQ_ITEM_PER_TENSOR) && !d.zero_points)
       return fail_arg("a float64 per-tensor item needs a zero_points pointer");
   }
+  return 0;
+}
+
+// One grid takes: float32 / float16 / bfloat16 tensors with 16-byte aligned x and y, fewer than 2^31 elements, and
+// rows of at least 32 elements (or one parameter set for the whole tensor).  Channel-last layouts (inner < 32) keep
+// their own kernels (lastaxis / window), float64 its own path: launched one by one on the same stream.
+static bool batchable(const mctq_fq_item& d) {
+  if (d.dtype == MCTQ_DT_F64) return false;
+  const int64_t n = d.outer * d.channels * d.inner;
+  const bool aligned = (((uintptr_t)d.x | (uintptr_t)d.y) & 15u) == 0;
+  if (!aligned || n >= (1ll << 31) - (int64_t)tile_elems_of(d.dtype)) return false;
+  if (d.channels > 0x7fffffffLL || d.inner > 0x7fffffffLL) return false;
+  return d.outer * d.channels == 1 || d.inner >= 32;
+}
+
+static int launch_single(const mctq_fq_item& d, void* stream) {
+  const int64_t n = d.outer * d.channels * d.inner;
+  if (n == 0) return 0;
+  if ((d.flags & MCTQ_FQ_ITEM_PER_TENSOR) && d.zero_points)
+    return mctq_fq_per_tensor_tqp(d.x, d.y, n, d.dtype, d.scales, d.zero_points, d.quant_min, d.quant_max, stream);
+  if ((d.flags & MCTQ_FQ_ITEM_PER_TENSOR) && d.dtype == MCTQ_DT_F64)
+    return fail_arg("a float64 per-tensor item needs a zero_points pointer");
+  return mctq_fq_per_channel(d.x, d.y, d.outer, d.channels, d.inner, d.dtype, d.scales, d.zero_points, d.quant_min,
+                             d.quant_max, stream);
+}
+
+static void fill_item(BatchItem& b, const mctq_fq_item& d, uint32_t tiles) {
+  const int64_t n = d.outer * d.channels * d.inner;
+  b.x = d.x; b.y = d.y; b.scales = d.scales; b.zps = d.zero_points;
+  b.n = (uint32_t)n;
+  const bool one_row = d.outer * d.channels == 1;
+  b.inner = one_row ? (uint32_t)n : (uint32_t)d.inner;
+  b.channels = one_row ? 1u : (uint32_t)d.channels;
+  b.tile_begin = 0; b.tiles = tiles; b.reserved = 0;
+  b.lo = (float)d.quant_min; b.hi = (float)d.quant_max;
+}
+
+// Smallest chunk shift with sum over tensors of ceil(tiles / 2^shift) <= max_chunks.
+static uint32_t chunk_shift(const uint32_t* tiles, int n, uint32_t max_chunks) {
+  for (uint32_t s = 0;; ++s) {
+    uint64_t chunks = 0;
+    for (int k = 0; k < n; ++k) chunks += ((uint64_t)tiles[k] + (1u << s) - 1) >> s;
+    if (chunks <= max_chunks) return s;
+  }
+}
+
+// ---- packed table (mctq_fq_batch_pack / mctq_fq_batch_run) -------------------------------------------------
+constexpr uint32_t kTableMagic = 0x4d435451u;   // "MCTQ"
+struct TableGroup { uint32_t dtype, items_off, map_off, n_items, grid, shift; int64_t out_bytes; };
+struct TableHeader {
+  uint32_t magic, version, total_bytes, n_groups, n_singles, singles_off, pad0, pad1;
+  TableGroup g[3];
+};
+static_assert(sizeof(TableHeader) == 128, "table header layout");
+
+}  // namespace mctq
+
+extern "C" {
+
+int mctq_fq_batched(const mctq_fq_item* items, int32_t n_items, void* stream) {
+  // validate everything before the first launch: a bad descriptor must not leave the list half done
+  if (int rc = validate_items(items, n_items)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  bool singles = false;
   for (int dt = MCTQ_DT_F32; dt <= MCTQ_DT_BF16; ++dt) {
-    BatchArgs a;
-    a.n_items = 0;
-    uint32_t tiles = 0;
-    int64_t out_bytes = 0;
-    const uint32_t tile_e = dt == MCTQ_DT_F32 ? batch_tile_elems<float, float>() : batch_tile_elems<_Float16, _Float16>();
-    const size_t esz = dt == MCTQ_DT_F32 ? 4 : 2;
-    auto flush = [&]() -> int {
-      if (a.n_items == 0) return 0;
-      int rc;
-      if (dt == MCTQ_DT_F32) rc = launch_batch<float, float>(a, tiles, out_bytes, st);
-      else if (dt == MCTQ_DT_F16) rc = launch_batch<_Float16, _Float16>(a, tiles, out_bytes, st);
-      else rc = launch_batch<__bf16, __bf16>(a, tiles, out_bytes, st);
-      a.n_items = 0; tiles = 0; out_bytes = 0;
-      return rc;
-    };
+    const uint32_t tile_e = tile_elems_of(dt);
+    const int64_t esz = dt == MCTQ_DT_F32 ? 4 : 2;
+    int32_t k = 0;
+    while (k < n_items) {
+      // next group: up to kMaxBatch batchable tensors of this storage type whose chunk map fits the kernel arguments
+      KernargSrc a;
+      uint32_t tiles[kMaxBatch];
+      int m = 0;
+      int64_t out_bytes = 0;
+      uint64_t total_tiles = 0;
+      for (; k < n_items && m < kMaxBatch; ++k) {
+        const mctq_fq_item& d = items[k];
+        if (d.dtype != dt) { if (d.dtype == MCTQ_DT_F64 && dt == MCTQ_DT_F32) singles = true; continue; }
+        const int64_t n = d.outer * d.channels * d.inner;
+        if (n == 0) continue;
+        if (!batchable(d)) { singles = true; continue; }
+        const uint32_t t = (uint32_t)((n + tile_e - 1) / tile_e);
+        if (total_tiles + t + ((uint64_t)kMaxBatch << 21) > 0x7fffffffull) break;    // grid limit (incl. chunk padding)
+        fill_item(a.it[m], d, t);
+        tiles[m++] = t;
+        total_tiles += t;
+        out_bytes += n * esz;
+      }
+      if (m == 0) continue;
+      a.shift = chunk_shift(tiles, m, kMaxChunksK);
+      memset(a.map, 0, sizeof(a.map));
+      uint32_t chunk = 0;
+      uint8_t* map = reinterpret_cast<uint8_t*>(a.map);
+      for (int j = 0; j < m; ++j) {
+        a.it[j].tile_begin = chunk << a.shift;
+        const uint32_t c = (tiles[j] + (1u << a.shift) - 1) >> a.shift;
+        memset(map + chunk, j, c);
+        chunk += c;
+      }
+      if (int rc = launch_batch_dt(dt, a, chunk << a.shift, out_bytes, st)) return rc;
+    }
+  }
+  if (singles)
+    for (int32_t k = 0; k < n_items; ++k)                     // what one grid cannot take: one launch each, same stream
+      if (!batchable(items[k]))
+        if (int rc = launch_single(items[k], stream)) return rc;
+  return 0;
+}
+
+int64_t mctq_fq_batch_pack(const mctq_fq_item* items, int32_t n_items, void* host_table, int64_t capacity) {
+  if (int rc = validate_items(items, n_items)) return rc;
+  // sizes first
+  uint32_t count[3] = {0, 0, 0}, n_singles = 0;
+  for (int32_t k = 0; k < n_items; ++k) {
+    const mctq_fq_item& d = items[k];
+    if (d.outer * d.channels * d.inner == 0) continue;
+    if (batchable(d)) ++count[d.dtype - MCTQ_DT_F32]; else ++n_singles;
+  }
+  for (int g = 0; g < 3; ++g)
+    if (count[g] > 0xffffu) return fail_arg("more than 65535 tensors of one storage type");
+  uint32_t shift[3] = {0, 0, 0}, chunks[3] = {0, 0, 0};
+  uint32_t* tl = n_items ? (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n_items) : nullptr;
+  if (n_items && !tl) return fail_arg("out of host memory");
+  for (int g = 0; g < 3; ++g) {
+    if (!count[g]) continue;
+    const uint32_t tile_e = tile_elems_of(MCTQ_DT_F32 + g);
+    int m = 0;
+    uint64_t total = 0;
     for (int32_t k = 0; k < n_items; ++k) {
       const mctq_fq_item& d = items[k];
-      if (d.dtype != dt) continue;
       const int64_t n = d.outer * d.channels * d.inner;
-      if (n == 0) continue;
-      const bool aligned = (((uintptr_t)d.x | (uintptr_t)d.y) & 15u) == 0;
-      if (!aligned || n >= (1ll << 31) - (int64_t)tile_e || d.channels > 0x7fffffffLL || d.inner > 0x7fffffffLL) {
-        // not batchable (unaligned view, huge tensor): the single-tensor entry point, same stream
-        if (int rc = mctq_fq_per_channel(d.x, d.y, d.outer, d.channels, d.inner, d.dtype, d.scales, d.zero_points,
-                                         d.quant_min, d.quant_max, stream)) return rc;
-        continue;
-      }
-      const uint32_t t = (uint32_t)((n + tile_e - 1) / tile_e);
-      if (a.n_items == kMaxBatch || (uint64_t)tiles + t > 0x7fffffffu) {
-        if (int rc = flush()) return rc;
-      }
-      BatchItem& b = a.it[a.n_items++];
-      b.x = d.x; b.y = d.y; b.scales = d.scales; b.zps = d.zero_points;
-      b.n = (uint32_t)n; b.inner = (uint32_t)d.inner; b.channels = (uint32_t)d.channels;
-      b.tile_begin = tiles;
-      b.lo = (float)d.quant_min; b.hi = (float)d.quant_max;
-      tiles += t;
-      out_bytes += n * (int64_t)esz;
+      if (d.dtype != MCTQ_DT_F32 + g || n == 0 || !batchable(d)) continue;
+      tl[m] = (uint32_t)((n + tile_e - 1) / tile_e);
+      total += tl[m++];
     }
-    if (int rc = flush()) return rc;
+    shift[g] = chunk_shift(tl, m, kMaxChunksT);
+    for (int j = 0; j < m; ++j) chunks[g] += (tl[j] + (1u << shift[g]) - 1) >> shift[g];
+    if (total + ((uint64_t)m << shift[g]) > 0x7fffffffull) { free(tl); return fail_arg("too many tiles for one launch"); }
   }
-  for (int32_t k = 0; k < n_items; ++k) {                   // float64 tensors: one launch each
-    const mctq_fq_item& d = items[k];
-    if (d.dtype != MCTQ_DT_F64 || d.outer * d.channels * d.inner == 0) continue;
-    int rc;
-    if ((d.flags & MCTQ_FQ_ITEM_PER_TENSOR) && d.zero_points)
-      rc = mctq_fq_per_tensor_tqp(d.x, d.y, d.outer * d.channels * d.inner, d.dtype, d.scales, d.zero_points, d.quant_min,
-                                  d.quant_max, stream);
-    else if (d.flags & MCTQ_FQ_ITEM_PER_TENSOR)
-      return fail_arg("a float64 per-tensor item needs a zero_points pointer");
-    else
-      rc = mctq_fq_per_channel(d.x, d.y, d.outer, d.channels, d.inner, d.dtype, d.scales, d.zero_points, d.quant_min,
-                               d.quant_max, stream);
-    if (rc) return rc;
+  auto align16 = [](uint64_t v) { return (v + 15u) & ~(uint64_t)15u; };
+  uint64_t off = sizeof(TableHeader);
+  uint64_t items_off[3], map_off[3];
+  for (int g = 0; g < 3; ++g) {
+    items_off[g] = off; off += (uint64_t)count[g] * sizeof(BatchItem);
+    map_off[g] = off; off = align16(off + (uint64_t)chunks[g] * 2u + 2u);
   }
+  const uint64_t singles_off = off;
+  off = align16(off + (uint64_t)n_singles * sizeof(mctq_fq_item));
+  if (off > 0x7fffffffull) { free(tl); return fail_arg("table too large"); }
+  if (!host_table || capacity < (int64_t)off) { free(tl); return (int64_t)off; }     // size query
+
+  uint8_t* base = static_cast<uint8_t*>(host_table);
+  memset(base, 0, (size_t)off);
+  TableHeader* h = reinterpret_cast<TableHeader*>(base);
+  h->magic = kTableMagic; h->version = MCTQ_ABI_VERSION; h->total_bytes = (uint32_t)off;
+  h->n_singles = n_singles; h->singles_off = (uint32_t)singles_off;
+  for (int g = 0; g < 3; ++g) {
+    if (!count[g]) continue;
+    TableGroup& tg = h->g[h->n_groups++];
+    tg.dtype = MCTQ_DT_F32 + g; tg.items_off = (uint32_t)items_off[g]; tg.map_off = (uint32_t)map_off[g];
+    tg.n_items = count[g]; tg.shift = shift[g]; tg.out_bytes = 0;
+    const uint32_t tile_e = tile_elems_of(tg.dtype);
+    BatchItem* bi = reinterpret_cast<BatchItem*>(base + items_off[g]);
+    uint16_t* map = reinterpret_cast<uint16_t*>(base + map_off[g]);
+    uint32_t chunk = 0;
+    int m = 0;
+    for (int32_t k = 0; k < n_items; ++k) {
+      const mctq_fq_item& d = items[k];
+      const int64_t n = d.outer * d.channels * d.inner;
+      if (d.dtype != (int32_t)tg.dtype || n == 0 || !batchable(d)) continue;
+      const uint32_t t = (uint32_t)((n + tile_e - 1) / tile_e);
+      fill_item(bi[m], d, t);
+      bi[m].tile_begin = chunk << tg.shift;
+      const uint32_t c = (t + (1u << tg.shift) - 1) >> tg.shift;
+      for (uint32_t j = 0; j < c; ++j) map[chunk + j] = (uint16_t)m;
+      chunk += c;
+      tg.out_bytes += n * (tg.dtype == MCTQ_DT_F32 ? 4 : 2);
+      ++m;
+    }
+    tg.grid = chunk << tg.shift;
+  }
+  mctq_fq_item* sg = reinterpret_cast<mctq_fq_item*>(base + singles_off);
+  uint32_t s = 0;
+  for (int32_t k = 0; k < n_items; ++k)
+    if (items[k].outer * items[k].channels * items[k].inner != 0 && !batchable(items[k])) sg[s++] = items[k];
+  free(tl);
+  return (int64_t)off;
+}
+
+int mctq_fq_batch_run(const void* host_table, const void* device_table, void* stream) {
+  if (!host_table) return fail_arg("host_table is NULL");
+  const uint8_t* base = static_cast<const uint8_t*>(host_table);
+  const TableHeader* h = reinterpret_cast<const TableHeader*>(base);
+  if (h->magic != kTableMagic || h->version != (uint32_t)MCTQ_ABI_VERSION || h->n_groups > 3)
+    return fail_arg("not a table packed by this library version (mctq_fq_batch_pack)");
+  if (h->n_groups && (!device_table || ((uintptr_t)device_table & 15u))) return fail_arg("device_table is NULL or not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t* dev = static_cast<const uint8_t*>(device_table);
+  for (uint32_t g = 0; g < h->n_groups; ++g) {
+    const TableGroup& tg = h->g[g];
+    TableSrc src;
+    src.it = reinterpret_cast<const BatchItem*>(dev + tg.items_off);
+    src.map = reinterpret_cast<const uint32_t*>(dev + tg.map_off);
+    src.shift = tg.shift;
+    if (int rc = launch_batch_dt((int)tg.dtype, src, tg.grid, tg.out_bytes, st)) return rc;
+  }
+  const mctq_fq_item* sg = reinterpret_cast<const mctq_fq_item*>(base + h->singles_off);
+  for (uint32_t s = 0; s < h->n_singles; ++s)
+    if (int rc = launch_single(sg[s], stream)) return rc;
   return 0;
 }
 

@@ -24,8 +24,11 @@ BINDING_SRC = os.path.join(CSRC, "binding", "mctq_torch.cpp")
 BINDING_OUT = os.path.join(PKG, "lib", "_mctq_torch.so")
 
 # -ffp-contract=off / no fast-math: the kernels must reproduce IEEE float32 results bit for bit.
+# -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave start (gfx940+); kernels
+# that take a struct first are unaffected.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def needs_build() -> bool:

@@ -14,7 +14,7 @@ import ctypes
 import os
 import threading
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
 CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
 FQ_ITEM_PER_TENSOR = 1
@@ -64,6 +64,8 @@ SIGNATURES = {
     "mctq_fq_per_tensor_tqp": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int32, _c_f32p, _c_i32p,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mctq_fq_batched": (ctypes.c_int, [ctypes.POINTER(FqItem), ctypes.c_int32, ctypes.c_void_p]),
+    "mctq_fq_batch_pack": (ctypes.c_int64, [ctypes.POINTER(FqItem), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64]),
+    "mctq_fq_batch_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mctq_lut_per_tensor_f64": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_float,
                                                _c_f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_void_p]),

@@ -14,10 +14,14 @@ Outputs are bit-identical to the per-layer calls (same AffineOp arithmetic; test
 and rewrites those tensors in place.  The values are the same; what changes is object identity: the quantized weight a
 wrapper installs is the same tensor object every forward (the reference returns a fresh one), so do not hold on to a
 previous forward's quantized weights across forwards in that mode.  The plan is built at the first forward from the
-wrappers and quantizer parameters found then; in-place updates of the WEIGHTS are followed (that is the point), but
-after replacing a quantizer's ``scales`` / ``zero_points`` or adding / removing wrappers call ``handle.refresh()``.
-A wrapper uses its persistent tensor only in the forward whose pre-hook has just filled it (generation counter):
-calling a sub-module directly, past the hook, falls back to that wrapper's own quantizer call.  54 ResNet-50 weights: 70 us -> host ~4 us + ~35 us
+wrappers and quantizer parameters found then; in-place updates of the WEIGHTS are followed (that is the point), and so
+are replaced or edited quantizer parameters, ``model.half()`` / ``.to(device)`` and re-pointed storages: the plan
+re-checks its tensors and the quantizers' public attributes on every call and is rebuilt when something changed.
+Only adding / removing wrappers needs ``handle.refresh()``.  The launch is ONE grid per storage type whatever the
+number of weights (mctq_fq_batch_pack / mctq_fq_batch_run: the descriptors live in a small device table).
+A wrapper uses the tensor prepared for it only inside the model forward whose pre-hook has just filled it (generation
+counter, closed again by a forward hook): calling a sub-module directly, past the hook, falls back to that wrapper's
+own quantizer call -- in both modes.  54 ResNet-50 weights: 70 us -> host ~4 us + ~35 us
 of GPU time (profiles/r02/requant_model_weights_batched.log).
 
 Only the affine weights quantizers (symmetric / power-of-two / uniform, per tensor or per channel) take part;
@@ -41,19 +45,41 @@ class BatchedWeightQuantization:
     def __init__(self, model: nn.Module, reuse_buffers: bool = False):
         self.model = model
         self.reuse_buffers = reuse_buffers
-        self._plan = None                 # (BatchPlan, generation cell, tensor count) in reuse_buffers mode
+        self._plan = None                 # (BatchPlan, tensor count) in reuse_buffers mode
+        # [generation, open]: a wrapper takes its prepared tensor once per generation and only while the model's
+        # forward that prepared it is running (a direct call of a sub-module later must not serve it)
+        self._cell = [0, False]
         self._hook = model.register_forward_pre_hook(self._before_forward)
+        self._post = model.register_forward_hook(self._after_forward, always_call=True)
+
+    def __getstate__(self):
+        # torch.save(model) / copy.deepcopy(model) reach the handle through the hooks: the pre-packed launch (device
+        # table, raw pointers) stays behind and is rebuilt at the copy's first forward
+        state = dict(self.__dict__)
+        state["_plan"] = None
+        state["_cell"] = [0, False]
+        return state
 
     def _entries(self) -> List[Tuple[PytorchQuantizationWrapper, str, torch.Tensor, object]]:
         out = []
         for m in self.model.modules():
-            if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization:
+            if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization and m.is_str_attr:
                 for name, weight, quantizer in m.get_weights_vars():
                     if (hasattr(quantizer, "batch_item") and not quantizer.enable_reuse
                             and not quantizer.__dict__.get("_versioned_reuse")
                             and not (quantizer._use_custom_impl and torch.jit.is_tracing())):
                         out.append((m, name, weight, quantizer))
         return out
+
+    @staticmethod
+    def _watch(quantizer):
+        """What the plan checks on every call (in C): the quantizer's public parameters are still the objects, at the
+        in-place versions, its launch state was derived from (the reference reads them on every call)."""
+        d = quantizer.__dict__
+        names = ("scales", "zero_points", "per_channel", "channel_axis", "min_quantized_domain", "max_quantized_domain")
+        if not all(k in d for k in names):
+            return None
+        return (d, tuple((k, d[k], d[k]._version if isinstance(d[k], torch.Tensor) else -1) for k in names))
 
     def _build_plan(self, entries):
         fast = ops._fast_mod()
@@ -63,25 +89,27 @@ class BatchedWeightQuantization:
         for wrapper, name, weight, quantizer in entries:
             weight.requires_grad = False            # the side effect of the reference's weights quantizers
             x, scales, zps, axis, qmin, qmax = quantizer.batch_item(weight)
+            if quantizer.__dict__.get("_zp_out_of_range"):
+                return None                         # the per-layer call raises ATen's message
             if zps is None and axis is None and weight.dtype == torch.float64:
                 zps = torch.zeros(1, dtype=torch.int32, device=weight.device)
             if not ops._is_dense(x.detach()):
                 return None
             y = torch.empty_like(x.detach())
-            items.append((x, y, scales, zps, axis, qmin, qmax))
+            items.append((x, y, scales, zps, axis, qmin, qmax, self._watch(quantizer)))
             per_wrapper.setdefault(wrapper, {})[name] = y
         try:
             plan = fast.BatchPlan(items)
         except TypeError:
             return None                   # something the pre-packed launch cannot take: per-forward batching instead
-        cell = [0]                        # generation: bumped once per forward, after the launch
         for wrapper, outs in per_wrapper.items():
-            wrapper.__dict__["_prequantized_plan"] = (cell, outs)
+            wrapper.__dict__["_prequantized_plan"] = (self._cell, outs)
             wrapper.__dict__.pop("_prequantized_seen", None)
-        return plan, cell, len(entries)
+        return plan, len(entries)
 
     def refresh(self):
-        """Rebuild the pre-packed plan at the next forward (after changing quantizer parameters or the model)."""
+        """Rebuild the pre-packed plan at the next forward.  Not needed after changing quantizer parameters or moving /
+        casting the model (the plan notices and is rebuilt); needed after adding or removing wrappers."""
         self._drop_plan()
 
     def _drop_plan(self):
@@ -94,15 +122,20 @@ class BatchedWeightQuantization:
     def quantize_now(self) -> int:
         """Quantize every participating weight in one batched launch and hand the results to the wrappers.
         Returns the number of tensors quantized."""
+        cell = self._cell
         if self.reuse_buffers and not torch.jit.is_tracing():
-            plan = self._plan
-            if plan is None:
-                entries = self._entries()
-                plan = self._plan = self._build_plan(entries) if entries else None
-            if plan is not None and plan[0]() is None:          # ONE C call: pointers re-read, one launch per 32 tensors
-                plan[1][0] += 1
-                return plan[2]
-            self._drop_plan()
+            for _ in range(2):                                       # a stale plan is rebuilt once, then given up
+                plan = self._plan
+                if plan is None:
+                    entries = self._entries()
+                    plan = self._plan = self._build_plan(entries) if entries else None
+                if plan is None:
+                    break
+                if plan[0]() is None:                                # ONE C call: tensors re-checked, one launch
+                    cell[0] += 1
+                    cell[1] = True
+                    return plan[1]
+                self._drop_plan()                                    # NotImplemented: shapes / dtypes / parameters changed
         entries = self._entries()
         if not entries:
             return 0
@@ -111,20 +144,27 @@ class BatchedWeightQuantization:
             weight.requires_grad = False            # the side effect of the reference's weights quantizers
             items.append(quantizer.batch_item(weight))
         outs = ops.fq_batched(items)
+        per_wrapper = {}
         for (wrapper, name, _, _), y in zip(entries, outs):
-            wrapper.__dict__.setdefault("_prequantized", {})[name] = y
+            per_wrapper.setdefault(wrapper, {})[name] = y
+        for wrapper, ready in per_wrapper.items():
+            wrapper.__dict__["_prequantized_plan"] = (cell, ready)
+        cell[0] += 1
+        cell[1] = True
         return len(entries)
 
     def _before_forward(self, module, args):
         self.quantize_now()
         return None
 
+    def _after_forward(self, module, args, output):
+        self._cell[1] = False             # whatever a wrapper did not pick up in this forward is void
+        return None
+
     def remove(self):
         self._hook.remove()
+        self._post.remove()
         self._drop_plan()
-        for m in self.model.modules():
-            if isinstance(m, PytorchQuantizationWrapper):
-                m.__dict__.pop("_prequantized", None)
 
 
 def batch_weight_quantization(model: nn.Module, reuse_buffers: bool = False) -> BatchedWeightQuantization:

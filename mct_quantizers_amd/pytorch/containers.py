@@ -149,17 +149,24 @@ class PytorchQuantizationWrapper(nn.Module):
     def get_weights_vars(self) -> List[Tuple[str, Any, BaseInferableQuantizer]]:
         return self._weights_vars
 
+    def __getstate__(self):
+        # tensors a batched launch prepared for one forward (pytorch/batching.py) are not part of the module's state
+        state = self.__dict__.copy()
+        state.pop("_prequantized_plan", None)
+        state.pop("_prequantized_seen", None)
+        return state
+
     def forward(self, *args: List[Any], **kwargs: Dict[str, Any]) -> Union[torch.Tensor, List[torch.Tensor]]:
         if self._weights_vars:
             # tensors a batched launch has already prepared for THIS forward (pytorch/batching.py); used once
             d = self.__dict__
             # (torch.compile traces the plain per-layer calls: none of this bookkeeping belongs in a graph)
-            ready = None if _is_compiling() else d.pop("_prequantized", None)
-            if ready is None and not _is_compiling():
-                # reuse_buffers mode: (generation cell, {name: persistent tensor}); valid once per generation, i.e.
-                # only for the forward whose pre-hook has just re-quantized into those tensors
+            ready = None
+            if not _is_compiling():
+                # (generation cell [generation, open], {name: tensor}); valid once per generation and only while the
+                # model forward whose pre-hook prepared the tensors is still running
                 plan = d.get("_prequantized_plan")
-                if plan is not None and plan[0][0] != d.get("_prequantized_seen"):
+                if plan is not None and plan[0][1] and plan[0][0] != d.get("_prequantized_seen"):
                     d["_prequantized_seen"] = plan[0][0]
                     ready = plan[1]
             fresh = {}

@@ -68,15 +68,24 @@ class ShardedWeightsQuantizer:
             return torch.empty_like(w_local)
         return self.quantizer(w_local)
 
-    def all_gather(self, y_local: torch.Tensor) -> torch.Tensor:
-        """Concatenate every rank's row block along dim 0 (one collective; every rank gets the full tensor)."""
+    def gather_buffers(self, y_local: torch.Tensor):
+        """(out, pad): the full-size result tensor and, when this rank's block is shorter than the common block size,
+        a staging tensor of the common size -- allocate once, pass to ``all_gather`` every time."""
+        tail = tuple(y_local.shape[1:])
+        out = torch.empty((self.rows_per_rank * self.world,) + tail, dtype=y_local.dtype, device=y_local.device)
+        pad = None
+        if y_local.shape[0] != self.rows_per_rank:
+            pad = torch.zeros((self.rows_per_rank,) + tail, dtype=y_local.dtype, device=y_local.device)
+        return out, pad
+
+    def all_gather(self, y_local: torch.Tensor, buffers=None) -> torch.Tensor:
+        """Concatenate every rank's row block along dim 0 (one collective; every rank gets the full tensor).
+        ``buffers``: the pair from ``gather_buffers`` (no allocation inside the call); default: allocate."""
         if self.world == 1:
             return y_local
-        tail = tuple(y_local.shape[1:])
+        out, pad = buffers if buffers is not None else self.gather_buffers(y_local)
         if y_local.shape[0] != self.rows_per_rank:      # short last block: pad to the common size
-            pad = torch.zeros((self.rows_per_rank,) + tail, dtype=y_local.dtype, device=y_local.device)
             pad[: y_local.shape[0]] = y_local
             y_local = pad
-        full = torch.empty((self.rows_per_rank * self.world,) + tail, dtype=y_local.dtype, device=y_local.device)
-        dist.all_gather_into_tensor(full, y_local.contiguous(), group=self.group)
-        return full[: self.full_rows]
+        dist.all_gather_into_tensor(out, y_local.contiguous(), group=self.group)
+        return out[: self.full_rows]

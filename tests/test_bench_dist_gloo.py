@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 KEYS = {"workload", "scaling", "rows_per_rank", "compute_ms", "compute_elems_per_s", "allgather_ms",
         "allgather_recv_bytes_per_rank", "allgather_recv_gbs_per_rank", "compute_plus_allgather_elems_per_s",
-        "gathered_rows_match_local"}
+        "gathered_rows_match_local", "ranks", "allgather_gbs_per_link", "allgather_output"}
 
 
 def _free_port():
@@ -73,3 +73,33 @@ def test_watchdog_exits_nonzero():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=60)
     assert r.returncode == 4 and "MAIN-LINE" in r.stdout
+
+
+def test_plain_python_bench_gpus_2_launches_itself_and_emits_the_multi_rank_line():
+    """`python bench.py --gpus 2` with no RANK in the environment (how the driver launched BENCH in round 2) must start
+    torch.distributed.run on itself as a child process and relay rank 0's JSON line and the exit status.  Here on CPU
+    (--device cpu: the dry run of the same entry path over gloo -- launcher, process group, barriers, max-over-ranks,
+    the sharded config-5 leg, the JSON)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--device", "cpu"],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["value"] > 0
+    assert out["config"]["ranks_seen"] == 2 and out["config"]["control_plane"] == "gloo" and "dry_run" in out
+    assert len(out["per_rank_kernel_us"]) == 2
+    leg = out["sharded_cfg5"]
+    assert leg["gathered_rows_match_local"] is True and leg["ranks"] == 2
+    for key in ("sharded_cfg5_compute_elems_per_s", "sharded_cfg5_compute_plus_allgather_elems_per_s",
+                "sharded_cfg5_allgather_gbs_per_link"):
+        assert out[key] and out[key] > 0
+    # a failing child is not reported as success
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--device", "cpu", "--config", "nope"],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
