@@ -91,6 +91,10 @@ def parse():
                     help="after the judged region also measure: two-stream overlap, warm-cache rate, ATen's HIP operator")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue independent steps round-robin on this many HIP streams (default 1: the judged protocol)")
+    ap.add_argument("--stream-depth", type=int, default=0,
+                    help="config 3: batches per replay of the activation stream (pytorch/graphs.py: CapturedStream; one fused "
+                         "batched launch per D batches).  0 = automatic (on for --batch <= 16, D = the largest divisor of "
+                         "--steps that is <= 32 and <= steps / 2), -1 = off (one eager call per batch)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: dry run of the entry path over gloo (tests); not a measurement")
     return ap.parse_args()
@@ -186,11 +190,27 @@ def main():
     wl = workloads.make_workload(args.config, x_np)
     quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
     tensors = max(1, args.batched)
+    per_launch = 1                               # steps served by one launch (activation stream: D batches per replay)
+    stream_on = (args.config == "cfg3" and not args.batched and not dry and not args.graph and args.streams == 1
+                 and (args.stream_depth > 0 or (args.stream_depth == 0 and args.batch <= 16)) and native.fast() is not None)
+    if stream_on:
+        cap = args.stream_depth if args.stream_depth > 0 else min(32, max(1, args.steps // 2))
+        per_launch = max(d for d in range(1, cap + 1) if args.steps % d == 0)
+        stream_on = per_launch > 1
     elems = wl.numel * tensors
-    alg_bytes = elems * wl.bytes_per_elem
-    ring = args.ring or max(2, -(-(512 << 20) // alg_bytes) + 1)
+    alg_bytes = elems * wl.bytes_per_elem        # per STEP
+    ring = args.ring or max(2, -(-(512 << 20) // (alg_bytes * per_launch)) + 1)
     x0 = torch.from_numpy(x_np).to(device)
-    if args.batched:
+    streams = None
+    if stream_on:
+        from mct_quantizers_amd.pytorch.graphs import capture_stream
+        holder = mq.PytorchActivationQuantizationHolder(quantizer).to(device)
+        act_streams = [capture_stream(holder, x0, depth=per_launch) for _ in range(ring)]
+        xs, ys = None, None
+
+        def step(i):                             # one LAUNCH: per_launch batches
+            act_streams[i % ring].run()
+    elif args.batched:
         if not hasattr(quantizer, "batch_item"):
             raise SystemExit(f"--batched: {wl.quantizer} has no batched launch (affine weights quantizers only)")
         plans, plan_outs = batched_plans(quantizer, x0, tensors, ring)
@@ -209,8 +229,8 @@ def main():
             else:
                 with torch.cuda.stream(streams[i % len(streams)]):
                     ys[i % ring] = quantizer(xs[i % ring])
-    if args.batched:
-        streams = None
+    n_launch = args.steps // per_launch
+    launch_bytes = alg_bytes * per_launch
 
     def dev_sync():
         if not dry:
@@ -226,7 +246,7 @@ def main():
     dev_sync()
     prewarm_s = time.perf_counter() - p0
 
-    for i in range(args.warmup):
+    for i in range(-(-args.warmup // per_launch)):
         step(i)
     dev_sync()
     kernel_variant = "aten cpu operator (dry run)" if dry else native.last_launch()
@@ -235,26 +255,26 @@ def main():
     if args.graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for i in range(args.steps):
+            for i in range(n_launch):
                 step(i)
         torch.cuda.synchronize()
 
     # ---- timed region ---------------------------------------------------------------------
-    steady = graph is None and streams is None and args.steps >= 2 and not dry
+    steady = graph is None and streams is None and n_launch >= 2 and not dry
     if not dry:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev_first = torch.cuda.Event(enable_timing=True)   # behind the FIRST launch: ev0 -> ev_first carries the host's launch latency
 
     def run_all(_):
         if dry:
-            for i in range(args.steps):
+            for i in range(n_launch):
                 step(i)
             return None
         ev0.record()
         if graph is not None:
             graph.replay()
         else:
-            for i in range(args.steps):
+            for i in range(n_launch):
                 step(i)
                 if i == 0 and steady:
                     ev_first.record()
@@ -269,15 +289,15 @@ def main():
     wall, dev_ms = bench_dist.max_over_ranks([wall, dev_ms], dist, control_plane, device)
 
     value = elems * args.steps * world / wall
-    launch_us_all = dev_ms * 1e3 / args.steps
+    launch_us_all = dev_ms * 1e3 / n_launch
     if steady:
         # launches 2..K, from the end of launch 1 to the end of launch K: the period without the idle stream's start-up (the
         # host's first call + launch latency, ~5-8 us once per region -- 1.5 % of a 20-step region, 0.03 % of a 1000-step one)
-        own_steady_us = ev_first.elapsed_time(ev1) * 1e3 / (args.steps - 1)
+        own_steady_us = ev_first.elapsed_time(ev1) * 1e3 / (n_launch - 1)
         launch_us = bench_dist.max_over_ranks([own_steady_us], dist, control_plane, device)[0]
     else:
         own_steady_us = launch_us = launch_us_all
-    achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+    achieved = launch_bytes / (launch_us * 1e-6) / 1e9
     wall_us = wall * 1e6 / args.steps
     achieved_wall = alg_bytes / (wall_us * 1e-6) / 1e9
 
@@ -297,7 +317,11 @@ def main():
         "config": {"workload": wl.name + (f", {tensors} tensors in one batched launch" if args.batched else ""),
                    "shape": list(wl.shape), "quantizer": wl.quantizer, "tensors_per_step": tensors,
                    "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
-                   "launch": "hipGraph" if graph is not None else "eager", "streams": args.streams,
+                   "launch": ("hipGraph" if graph is not None else
+                              f"activation stream: {per_launch} batches per fused batched launch (pytorch/graphs.py "
+                              f"CapturedStream, mode {act_streams[0].mode}); a batch's result is ready when its group's "
+                              f"launch completes" if stream_on else "eager"),
+                   "steps_per_launch": per_launch, "streams": args.streams,
                    "binding": "none (dry run)" if dry else ("compiled" if native.fast() is not None else "ctypes"),
                    "prewarm_s": round(prewarm_s, 3), "prewarm_steps": n_pre,
                    "parallelism": f"replicated x{world} (weak, no collective)",
@@ -307,7 +331,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                      "frac_wall": achieved_wall / HBM_PEAK_GBS,
-                     "frac_events_whole_region": alg_bytes / (launch_us_all * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "frac_events_whole_region": launch_bytes / (launch_us_all * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "kernel": kernel_variant, "kernel_us": launch_us,
                      "kernel_us_is": ("average launch PERIOD inside the timed region, launches 2..K (event behind launch 1 -> event "
                                       "behind launch K): kernel duration + the ~1.4 us bubble between back-to-back launches; "
@@ -315,7 +339,7 @@ def main():
                                       "and the closing synchronize)"
                                       if steady else "average launch PERIOD over the timed region (one event pair around K launches)"),
                      "kernel_us_incl_first_launch_latency": launch_us_all,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "algorithmic_bytes_per_launch": launch_bytes},
     }
     if dry:
         result["dry_run"] = "CPU dry run of the entry path (launcher, gloo process group, barriers, JSON): NOT a measurement"
@@ -337,7 +361,7 @@ def main():
             result["roofline"]["per_launch"] = {
                 "launches": n, "median_us": med, "mean_us": sum(periods) / n,
                 "p10_us": periods[n // 10], "p90_us": periods[(n * 9) // 10],
-                "achieved_gbs_at_median": alg_bytes / med / 1e3, "frac_at_median": alg_bytes / med / 1e3 / HBM_PEAK_GBS,
+                "achieved_gbs_at_median": launch_bytes / med / 1e3, "frac_at_median": launch_bytes / med / 1e3 / HBM_PEAK_GBS,
                 "note": "one HIP event between every two launches (the marker itself adds to the period); "
                         "outside the timed region"}
         except Exception as e:  # noqa: BLE001
@@ -350,6 +374,8 @@ def main():
                 key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
                 if args.batched:
                     key = f"{key}_batched{tensors}"
+                if stream_on:
+                    key = f"{key}_stream{per_launch}"
                 rec = json.load(f).get(key)
             if rec is None:
                 result["roofline"]["traffic_source"] = f"no PMC record {key!r} in profiles/pmc_traffic.json"
@@ -364,9 +390,11 @@ def main():
             result["roofline"]["traffic_source"] = "profiles/pmc_traffic.json missing"
 
     # ---- the last timed step's output, kept for the parity check before anything overwrites the ring ----------
-    last_slot = (args.steps - 1) % ring
+    last_slot = (n_launch - 1) % ring
     if dry:
         y_last = ys[last_slot]
+    elif stream_on:
+        y_last = act_streams[last_slot].outputs       # persistent outputs of the last timed replay
     elif args.batched:
         y_last = plan_outs[last_slot]       # persistent outputs; later passes rewrite them with the same values
     else:
@@ -375,7 +403,7 @@ def main():
     # Extra (outside the judged region): the same K independent steps issued round-robin on two HIP streams,
     # which overlaps one kernel's tail with the next one's ramp.  Whole-job rate only; per-kernel durations
     # overlap, so this is not a roofline figure.
-    if args.extras and args.streams == 1 and graph is None and not args.batched:
+    if args.extras and args.streams == 1 and graph is None and not args.batched and not stream_on:
         try:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
             for st in s2:
@@ -396,7 +424,7 @@ def main():
     # Extras at N = 1 (outside the judged region): warm-cache rate (one buffer pair, working set inside the
     # Infinity Cache) and what the REFERENCE would execute on this GPU for the same call -- ATen's own HIP
     # fake-quant operator (only defined for the affine configurations).
-    if args.extras and world == 1 and graph is None and args.streams == 1 and not args.batched:
+    if args.extras and world == 1 and graph is None and args.streams == 1 and not args.batched and not stream_on:
         try:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             wsteps = min(args.steps, 300)
@@ -484,7 +512,7 @@ def main():
         f = torch_cpu.prepare(wl.quantizer, wl.kwargs)
         x_cpu = torch.from_numpy(x_np)
         y_cpu = f(x_cpu)                                   # warm-up + parity reference
-        if args.batched:
+        if args.batched or stream_on:
             same = all(bool(torch.equal(y.cpu(), y_cpu)) for y in y_last[:2]) and \
                 all(bool(torch.equal(y, y_last[0])) for y in y_last[2:])
         else:

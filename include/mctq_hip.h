@@ -130,7 +130,7 @@ int mctq_fq_per_tensor_tqp(const void* x, void* y, int64_t n, int32_t dtype,
  * capture); every pointer
  * inside an item is a DEVICE pointer with the meaning it has in mctq_fq_per_channel.  Per-tensor quantization is
  * outer = channels = 1, inner = n with 1-element device scales / zero_points and flags = MCTQ_FQ_ITEM_PER_TENSOR.  Tensors the batched kernel cannot
- * take (x or y not 16-byte aligned, >= 2^31 elements, float64, per-channel rows shorter than 32 elements) are
+ * take (x or y not 16-byte aligned, >= 2^31 elements, float64, more than 2^20 elements in rows shorter than 32) are
  * launched one by one on the same stream, after the batched launches.
  * All items are validated before anything is launched.
  */

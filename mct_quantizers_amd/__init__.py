@@ -25,6 +25,9 @@ def __getattr__(name):
     if name == "capture_forward":                    # the whole forward replayed from one hipGraph
         from mct_quantizers_amd.pytorch.graphs import capture_forward
         return capture_forward
+    if name == "capture_stream":                     # a fixed-shape activation stream replayed from one hipGraph
+        from mct_quantizers_amd.pytorch.graphs import capture_stream
+        return capture_stream
     if name == "batch_weight_quantization":          # all wrapped weights of a model in ONE launch per forward
         from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
         return batch_weight_quantization

@@ -319,15 +319,17 @@ static int validate_items(const mctq_fq_item* items, int32_t n_items) {
 }
 
 // One grid takes: float32 / float16 / bfloat16 tensors with 16-byte aligned x and y, fewer than 2^31 elements, and
-// rows of at least 32 elements (or one parameter set for the whole tensor).  Channel-last layouts (inner < 32) keep
-// their own kernels (lastaxis / window), float64 its own path: launched one by one on the same stream.
+// rows of at least 32 elements (or one parameter set for the whole tensor) -- or any rows when the tensor is small
+// (<= 2^20 elements: depthwise 3x3 weights, [C, 1, 3, 3], are tiny and many; one more launch each would cost more
+// than the element-by-element path of their row-straddling vectors).  LARGE channel-last layouts keep their own
+// kernels (lastaxis / window), float64 its own path: launched one by one on the same stream.
 static bool batchable(const mctq_fq_item& d) {
   if (d.dtype == MCTQ_DT_F64) return false;
   const int64_t n = d.outer * d.channels * d.inner;
   const bool aligned = (((uintptr_t)d.x | (uintptr_t)d.y) & 15u) == 0;
   if (!aligned || n >= (1ll << 31) - (int64_t)tile_elems_of(d.dtype)) return false;
   if (d.channels > 0x7fffffffLL || d.inner > 0x7fffffffLL) return false;
-  return d.outer * d.channels == 1 || d.inner >= 32;
+  return d.outer * d.channels == 1 || d.inner >= 32 || n <= (1ll << 20);
 }
 
 static int launch_single(const mctq_fq_item& d, void* stream) {

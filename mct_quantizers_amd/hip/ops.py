@@ -664,6 +664,80 @@ for _name in ("lut_per_tensor", "lut_per_channel"):          # the LUT chain's r
     _lib_def.impl(_name, (lambda x, *a: torch.empty(x.shape, dtype=torch.float32, device=x.device)), "Meta")
 
 
+# ---- autograd: what ATen's operators do at the reference's call sites -----------------------------------------
+# torch.fake_quantize_per_{tensor,channel}_affine carry a straight-through backward: the incoming gradient where the
+# clamp index q = nearbyint(x * (1.0f / scale)) + zero_point lies inside [quant_min, quant_max], zero elsewhere
+# (ATen's *_cachemask kernels record that mask in the forward; here it is recomputed from x in the rare backward, with
+# plain torch ops -- this is an inference library, the reference switches gradients off before it calls them:
+# weights_symmetric_inferable_quantizer.py:138,146, activation_symmetric_inferable_quantizer.py:112).
+# The scale / zero-point tensors get no gradient (nor do they in ATen's tensor-qparams and per-channel operators).
+# The LUT chain ends in argmin + gather (quantizer_utils.py:131-137): its result does not depend on x differentiably.
+
+def _ste_mask(x, inv_scale, zero_point, qmin: int, qmax: int):
+    q = torch.round(x.detach().float() * inv_scale) + zero_point          # round half to even, as nearbyint
+    return (q >= qmin) & (q <= qmax)
+
+
+def _f32_inverse(scale):
+    s = scale if isinstance(scale, torch.Tensor) else torch.tensor(float(scale), dtype=torch.float64)
+    return torch.tensor(1.0, dtype=torch.float32, device=s.device) / s.detach().to(torch.float32)    # float32 1.0f / scale
+
+
+def _ctx_per_tensor(ctx, inputs, output):
+    x, scale, zero_point, qmin, qmax = inputs
+    ctx.save_for_backward(x)
+    ctx.q = (scale, zero_point, qmin, qmax)
+
+
+def _bwd_per_tensor(ctx, grad):
+    (x,) = ctx.saved_tensors
+    scale, zero_point, qmin, qmax = ctx.q
+    mask = _ste_mask(x, _f32_inverse(scale).to(x.device), zero_point, qmin, qmax)
+    return grad * mask, None, None, None, None
+
+
+def _ctx_per_tensor_tqp(ctx, inputs, output):
+    x, scale, zero_point, qmin, qmax = inputs
+    ctx.save_for_backward(x, scale, zero_point)
+    ctx.q = (qmin, qmax)
+
+
+def _bwd_per_tensor_tqp(ctx, grad):
+    x, scale, zero_point = ctx.saved_tensors
+    qmin, qmax = ctx.q
+    mask = _ste_mask(x, _f32_inverse(scale.reshape(-1)[:1]), zero_point.reshape(-1)[:1].to(torch.float32), qmin, qmax)
+    return grad * mask, None, None, None, None
+
+
+def _ctx_per_channel(ctx, inputs, output):
+    x, scales, zero_points, axis, qmin, qmax = inputs
+    ctx.save_for_backward(x, scales, zero_points)
+    ctx.q = (axis, qmin, qmax)
+
+
+def _bwd_per_channel(ctx, grad):
+    x, scales, zero_points = ctx.saved_tensors
+    axis, qmin, qmax = ctx.q
+    shape = [1] * x.dim()
+    shape[axis] = -1
+    mask = _ste_mask(x, _f32_inverse(scales).reshape(shape), zero_points.to(torch.float32).reshape(shape), qmin, qmax)
+    return grad * mask, None, None, None, None, None
+
+
+def _ctx_nondiff(ctx, inputs, output):
+    ctx.mark_non_differentiable(output)
+
+
+torch.library.register_autograd(f"{_LIBNAME}::fq_per_tensor", _bwd_per_tensor, setup_context=_ctx_per_tensor, lib=_lib_def)
+torch.library.register_autograd(f"{_LIBNAME}::fq_per_tensor_tqp", _bwd_per_tensor_tqp, setup_context=_ctx_per_tensor_tqp,
+                                lib=_lib_def)
+torch.library.register_autograd(f"{_LIBNAME}::fq_per_channel", _bwd_per_channel, setup_context=_ctx_per_channel, lib=_lib_def)
+torch.library.register_autograd(f"{_LIBNAME}::lut_per_tensor", lambda ctx, grad: (None,) * 8, setup_context=_ctx_nondiff,
+                                lib=_lib_def)
+torch.library.register_autograd(f"{_LIBNAME}::lut_per_channel", lambda ctx, grad: (None,) * 8, setup_context=_ctx_nondiff,
+                                lib=_lib_def)
+
+
 def _is_real(x) -> bool:
     return type(x) is torch.Tensor or type(x) is torch.nn.Parameter
 

@@ -220,6 +220,13 @@ class PytorchActivationQuantizationHolder(torch.nn.Module):
             return super().__call__(inputs, *args, **kwargs)
         return self.forward(inputs)
 
+    def capture_stream(self, example: torch.Tensor, depth: int = 16, mode: str = "auto"):
+        """Extension (not in the reference): a fixed-shape stream of ``depth`` activation batches through this holder per
+        replay -- ONE batched launch for the affine quantizers, one hipGraph otherwise (``pytorch/graphs.py``:
+        ``CapturedStream``); falls back to eager calls for anything that does not fit the captured shape."""
+        from mct_quantizers_amd.pytorch.graphs import capture_stream
+        return capture_stream(self, example, depth, mode=mode)
+
     def convert_to_inferable_quantizers(self):
         conv = getattr(self.activation_holder_quantizer, 'convert2inferable', None)
         if callable(conv):  # pragma: no cover

@@ -14,11 +14,12 @@ exactly as in eager mode.  Shapes, dtypes and the module structure are frozen at
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Callable, List, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 
+from mct_quantizers_amd.hip import ops
 from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
 
 
@@ -69,3 +70,118 @@ def capture_forward(model: nn.Module, *example_inputs: torch.Tensor, batch_weigh
     """Capture ``model(*example_inputs)`` (inference, no grad) into one hipGraph and return the replaying callable.
     ``batch_weights``: re-quantize all wrapped weights in one launch inside the graph (``pytorch/batching.py``)."""
     return CapturedForward(model, example_inputs, batch_weights, warmup)
+
+
+class CapturedStream:
+    """A fixed-shape STREAM of activation batches through one quantizer / holder, ``depth`` batches per replay.
+
+    Small activations are launch-bound: an eager ``holder(x)`` costs ~4-5 us of host time for ~1-2 us of GPU work
+    (BASELINE config 3 at N = 1 / 8; reference call site pytorch/activation_quantization_holder.py:43-53).  The stream owns
+    ``depth`` static input tensors; the producer writes batch i into ``stream.inputs[i]`` (or hands ``depth`` tensors to
+    ``stream(batches)``, which copies them in), ``stream.run()`` quantizes all of them, and ``stream.outputs[i]`` holds
+    batch i's result until the next replay.  Two ways to run the ``depth`` calls, same bits as the eager calls either way:
+
+      fused   (affine activation quantizers: symmetric / power-of-two / uniform)  ONE launch of the batched kernel over
+              all ``depth`` batches (``BatchPlan`` -> mctq_fq_batch_run, per-tensor items): no hipGraph at all, one host
+              call and one ramp / drain per ``depth`` batches -- config 3 at N = 1: 5.2 -> ~0.5 us per batch.
+      graph   (anything else: LUT quantizers, arbitrary callables)  one hipGraph of ``depth`` kernel nodes on one branch.
+              Measured (profiles/r03/stream_probe.log): a replay costs ~12 us of fixed overhead, so a ONE-node graph is
+              2-3x SLOWER than the eager call (14.5 vs 5.2 us) and pays only from depth >= 8 (2.2 us per batch at depth
+              16); parallel branches (``lanes`` > 1) made small batches slower, so the default is 1.
+
+    Anything that does not fit the captured shape / dtype / count falls back to eager calls."""
+
+    def __init__(self, fn: Callable[[torch.Tensor], torch.Tensor], example: torch.Tensor, depth: int = 16, lanes: int = 1,
+                 warmup: int = 2, mode: str = "auto"):
+        if not isinstance(example, torch.Tensor) or not example.is_cuda:
+            raise TypeError("capture_stream takes a GPU tensor as the example batch")
+        if depth < 1 or lanes < 1:
+            raise ValueError("depth and lanes must be >= 1")
+        if mode not in ("auto", "fused", "graph"):
+            raise ValueError("mode: auto | fused | graph")
+        self.fn = fn
+        self.depth, self.lanes = depth, min(lanes, depth)
+        self.inputs: List[torch.Tensor] = [example.detach().clone() for _ in range(depth)]
+        self.outputs: List[torch.Tensor] = [None] * depth
+        self.graph, self._plan = None, None
+        quantizer = getattr(fn, "activation_holder_quantizer", fn)
+        bypass = bool(getattr(fn, "quantization_bypass", False))
+        fusable = (mode != "graph" and not bypass and hasattr(quantizer, "batch_item") and hasattr(quantizer, "_plan_args")
+                   and ops._fast_mod() is not None and ops._is_dense(example))
+        if mode == "fused" and not fusable:
+            raise TypeError("fused streams need an affine activation quantizer (or its holder) and the compiled binding")
+        if fusable:
+            self.mode = "fused"
+            self.outputs = [torch.empty_like(x) for x in self.inputs]
+            items = []
+            for x, y in zip(self.inputs, self.outputs):
+                xi, scale, zp, axis, qmin, qmax = quantizer.batch_item(x)
+                watch = (quantizer.__dict__, tuple((k, quantizer.__dict__[k], -1) for k in quantizer._plan_attrs))
+                items.append((xi, y, scale, zp, axis, qmin, qmax, watch))
+            self._plan = ops._fast_mod().BatchPlan(items)
+            self._plan()
+            return
+        self.mode = "graph"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):                 # allocator, lazy library state, launch plans
+                for x in self.inputs:
+                    fn(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            root = torch.cuda.current_stream()
+            branches = [torch.cuda.Stream() for _ in range(self.lanes)] if self.lanes > 1 else [root]
+            for b in branches:
+                if b is not root:
+                    b.wait_stream(root)                     # fork
+            for i, x in enumerate(self.inputs):
+                with torch.cuda.stream(branches[i % len(branches)]):
+                    self.outputs[i] = fn(x)
+            for b in branches:
+                if b is not root:
+                    root.wait_stream(b)                     # join
+
+    def run(self) -> List[torch.Tensor]:
+        """Quantize whatever ``inputs`` hold now into ``outputs`` (valid until the next replay)."""
+        if self._plan is not None:
+            if self._plan() is NotImplemented:              # the quantizer's parameters changed: eager calls from now on
+                self._plan = None
+                self.mode = "eager"
+                return self.run()
+        elif self.graph is not None:
+            self.graph.replay()
+        else:
+            with torch.no_grad():
+                self.outputs = [self.fn(x) for x in self.inputs]
+        return self.outputs
+
+    def fits(self, batches: Sequence[torch.Tensor]) -> bool:
+        if len(batches) != self.depth:
+            return False
+        ref = self.inputs[0]
+        return all(isinstance(b, torch.Tensor) and b.shape == ref.shape and b.dtype == ref.dtype
+                   and b.device == ref.device and not b.requires_grad for b in batches)
+
+    def __call__(self, batches: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """``depth`` batches of the captured shape: copy in (skipped for tensors that ARE the static inputs), replay.
+        Anything else -- another shape, dtype, device or count, tensors that require grad -- runs the eager calls."""
+        if not self.fits(batches):
+            return [self.fn(b) for b in batches]
+        for dst, src in zip(self.inputs, batches):
+            if src is not dst:
+                dst.copy_(src)
+        return self.run()
+
+    def release(self):
+        self.graph, self._plan = None, None
+        self.mode = "eager"
+
+
+def capture_stream(quantizer_or_holder: Callable[[torch.Tensor], torch.Tensor], example: torch.Tensor, depth: int = 16,
+                   lanes: int = 1, mode: str = "auto") -> CapturedStream:
+    """``depth`` calls of an activation quantizer (or a holder module) on ``example``-shaped batches per replay: one fused
+    batched launch for the affine quantizers, one hipGraph otherwise; see ``CapturedStream``."""
+    return CapturedStream(quantizer_or_holder, example, depth, lanes, mode=mode)

@@ -56,6 +56,20 @@ class _PerTensorPlanMixin:
         self.__dict__["_plan"] = plan
         return plan
 
+    def batch_item(self, inputs: torch.Tensor):
+        """(x, scale[1], zero_point[1], None, qmin, qmax) for ``ops.fq_batched`` / ``BatchPlan``: this quantizer's call
+        on ``inputs`` as one entry of a batched launch (a stream of activation batches quantized together).  The
+        1-element device tensors hold float32(scale) -- the value the per-tensor launch narrows the Python double to --
+        and are rebuilt whenever the public attributes change."""
+        scale, zp, qmin, qmax = self._plan_args()
+        key = (scale, zp, inputs.device)
+        hit = self.__dict__.get("_batch_params")
+        if hit is None or hit[0] != key:
+            hit = (key, torch.tensor([scale], dtype=torch.float64).to(torch.float32).to(inputs.device),
+                   torch.tensor([zp], dtype=torch.int32, device=inputs.device))
+            self.__dict__["_batch_params"] = hit
+        return inputs, hit[1], hit[2], None, qmin, qmax
+
 
 _MAX_BITS = 24      # the clamp bounds travel as float32: exact for |q| < 2^24
 
@@ -103,7 +117,7 @@ class BasePyTorchInferableQuantizer(BaseInferableQuantizer):
     #    the private launch state (host copies of scalars, decision tables) is rebuilt on load.
     def __getstate__(self):
         state = dict(self.__dict__)
-        for k in ("_plan", "_plan_key", "_versioned_key", "_versioned_pending"):   # binding handles, weak references
+        for k in ("_plan", "_plan_key", "_versioned_key", "_versioned_pending", "_batch_params"):   # binding handles, weak references
             state.pop(k, None)
         return state
 

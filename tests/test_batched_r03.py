@@ -49,7 +49,8 @@ def test_batch_pack_is_host_code_and_maps_every_block_to_its_tensor():
         inner = int(rng.choice([32, 64, 147, 512, 576, 1000, 4096, 4608, 11008]))
         specs.append((1, c, inner, native.DT_F32 if k % 3 else native.DT_BF16))
     specs += [(1, 1, 5000, native.DT_F16), (1, 1, 0, native.DT_F32),       # per tensor; empty
-              (1, 64, 3, native.DT_F32), (4, 8, 1, native.DT_F32),         # rows shorter than 32 elements: own kernels
+              (1, 1 << 19, 3, native.DT_F32), (1 << 18, 8, 1, native.DT_F32),   # LARGE tensors of short rows: own kernels
+              (1, 64, 9, native.DT_F32), (4, 8, 1, native.DT_F32),         # small ones (depthwise weights) ride along
               (1, 16, 64, native.DT_F64)]                                  # float64: own path
     n = len(specs)
     arr = (native.FqItem * n)()
@@ -65,13 +66,13 @@ def test_batch_pack_is_host_code_and_maps_every_block_to_its_tensor():
     assert lib.mctq_fq_batch_pack(arr, n, buf, need) == need
     t = _parse_table(buf.raw)
     assert t["magic"] == 0x4d435451 and t["version"] == native.ABI_VERSION and t["total"] == need
-    assert t["n_singles"] == 4                                   # inner 3, inner 1, float64, the unaligned view
+    assert t["n_singles"] == 4                                   # the two large short-row tensors, float64, the unaligned view
     assert sorted(g["dtype"] for g in t["groups"]) == [native.DT_F32, native.DT_F16, native.DT_BF16]
     packed = 0
     for g in t["groups"]:
         tile = TILE32 if g["dtype"] == native.DT_F32 else TILE16
         want = [(k, s) for k, s in enumerate(specs) if s[3] == g["dtype"] and s[0] * s[1] * s[2] > 0
-                and (s[2] >= 32 or s[0] * s[1] == 1) and k != 17]
+                and (s[2] >= 32 or s[0] * s[1] == 1 or s[0] * s[1] * s[2] <= (1 << 20)) and k != 17]
         assert len(g["items"]) == len(want)
         work = 0
         for (k, (outer, c, inner, _)), it in zip(want, g["items"]):
@@ -145,7 +146,8 @@ def _cases(rng, count):
     shapes = [((64, 3, 7, 7), 0), ((64, 64, 1, 1), 0), ((64, 64, 3, 3), 0), ((256, 64, 1, 1), 0), ((128, 128, 3, 3), 0),
               ((512, 512, 3, 3), 0), ((96, 2048), 0), ((33, 4096), 0), ((17, 4608), 0), ((5, 11008), 0), ((3, 8192), 0),
               ((40, 1000), 0), ((4096, 32), 0), ((2, 48, 100), 1), ((3, 5, 640), 1), ((2, 3, 4100), 1), ((12, 1031), 0),
-              ((4099,), None), ((1,), None), ((70000,), None), ((16, 37), 1), ((10, 6, 5), 2), ((8, 2052), 0)]
+              ((4099,), None), ((1,), None), ((70000,), None), ((16, 37), 1), ((10, 6, 5), 2), ((8, 2052), 0),
+              ((512, 1, 3, 3), 0), ((3, 7, 5), 2), ((2, 1031, 3), 1), ((6, 4, 1), 1)]
     out = []
     for k in range(count):
         shape, axis = shapes[k % len(shapes)]

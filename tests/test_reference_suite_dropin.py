@@ -17,10 +17,11 @@ def test_reference_pytorch_suite_passes_against_this_package(tmp_path):
     env = dict(os.environ)
     env["PYTHONPATH"] = ""                                   # the real mct_quantizers must NOT be importable
     env["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = "1"           # its save/load tests predate torch's weights_only default
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_reference_tests.py"),
-                        "--ignore", os.path.join(REF, "test_pytorch_load_model.py")],   # imports onnx (not installed)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_reference_tests.py")],
                        cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
     tail = r.stdout[-1500:]
     assert r.returncode == 0, tail + r.stderr[-1500:]
     assert " passed" in tail and "failed" not in tail.splitlines()[-1], tail
-    assert "64 passed" in tail and "15 subtests passed" in tail, tail
+    # 64 cases + the 9 torch.save -> pytorch_load_quantized_model cases of test_pytorch_load_model.py:78-221 (its one
+    # ONNX-metadata case is deselected by name: out of scope, needs `onnx`)
+    assert "73 passed" in tail and "1 deselected" in tail and "15 subtests passed" in tail, tail

@@ -5,7 +5,7 @@
 #        FETCH_SIZE, WRITE_SIZE                      HBM-side traffic (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
 #        SQ stall split, TCC EA stall counters       who waits for what (cfg2 only)
 # Raw per-dispatch CSVs land in gpurun_out/pmc/<config>/; tools/pmc_summarize.py (run in the build container
-# afterwards) turns them into profiles/pmc_traffic.json + profiles/r02/*.csv, keyed by the kernel VARIANT that the
+# afterwards) turns them into profiles/pmc_traffic.json + profiles/r03/*.csv, keyed by the kernel VARIANT that the
 # very same bench run reports (mctq_last_launch) and the git head.
 mkdir -p gpurun_out/pmc; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 cd /tmp
@@ -14,16 +14,18 @@ run_cfg() {   # name, bench args...
   local name=$1; shift
   local out=$R/gpurun_out/pmc/$name; mkdir -p $out
   rm -rf /tmp/prof_$name
+  # the stats pass runs the judged command as it is (at N = 1 the default run also carries the batched_16x4096 object)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --no-cpu --evidence-launches 0 "$@" > $out/bench_stats.log 2>&1
   find /tmp/prof_$name -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
   for pass in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${name}_$pass
-    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
     f=$(find /tmp/pmc_${name}_$pass -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then head -1 $f > $out/$pass.csv; grep -E "mctq::" $f | tail -120 >> $out/$pass.csv; fi
   done
 }
 run_cfg cfg2
+run_cfg cfg2_batched16 --batched 16 --steps 60 --warmup 5
 run_cfg cfg3_n64 --config cfg3 --batch 64
 run_cfg cfg4 --config cfg4 --steps 300
 run_cfg cfg5 --config cfg5 --steps 300
@@ -38,9 +40,9 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_NC_READ_REQ_sum"; do
   i=$((i+1)); rm -rf /tmp/pmc_stall_$i
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_$i -- python3 $R/bench.py --no-cpu --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 > $out/bench_stall_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_$i -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 > $out/bench_stall_$i.log 2>&1
   f=$(find /tmp/pmc_stall_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq::" $f | tail -400 >> $out/stall_$i.csv; else echo "group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
 done
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
-for c in cfg2 cfg3_n64 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
+for c in cfg2 cfg2_batched16 cfg3_n64 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/pmc/<config>/ (written by tools/gpu_pmc_traffic.sh on the GPU box) into
-profiles/pmc_traffic.json and profiles/r02/: per config the kernel VARIANT (mctq_last_launch, taken from the JSON line
+profiles/pmc_traffic.json and profiles/r03/: per config the kernel VARIANT (mctq_last_launch, taken from the JSON line
 of the same profiled bench run), rocprof's kernel symbol, the average FETCH_SIZE / WRITE_SIZE per dispatch, the gfx950
 correction (FETCH_SIZE x 2 for wide coalesced reads, guide MI355X_MICROARCH.md "HBM"), and the git head they were
 taken at.  bench.py emits roofline.traffic only when its own variant string equals the recorded one."""
 import csv, json, os, shutil, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "pmc")
-DST = os.path.join(REPO, "profiles", "r02")
+DST = os.path.join(REPO, "profiles", os.environ.get("MCTQ_ROUND", "r03"))
 os.makedirs(DST, exist_ok=True)
 head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
 
@@ -40,7 +40,8 @@ for cfg in sorted(os.listdir(SRC)):
     assert kern == kern_w, (kern, kern_w)
     alg = line["roofline"]["algorithmic_bytes_per_launch"]
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0
-    stats = next(csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))))
+    stats = next((r for r in rows if r["Name"] == kern), rows[0])      # the judged kernel's row of the stats pass
     out[cfg] = {"variant": variant, "kernel": kern, "git_head": head,
                 "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
                 "correction": "gfx950: FETCH_SIZE reports 1/2 of wide (16 B/lane) streaming reads -> doubled (guide MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",

@@ -2,8 +2,11 @@
 """Drop-in check (build container only): run the REFERENCE's own PyTorch test-suite (/root/reference/tests/pytorch_tests,
 unmodified, read in place) with `mct_quantizers` resolving to THIS package (compat.install_reference_aliases).
 Nothing of the reference is copied: its test files are collected from where they lie.  The onnx_export_tests need
-onnxruntime-extensions / the metadata module (out of scope) and are skipped; test_pytorch_load_model's
-metadata cases likewise.  On a GPU box the same suite exercises the HIP kernels (the working device is 'cuda')."""
+onnxruntime-extensions / the metadata module (out of scope) and are skipped.  test_pytorch_load_model.py
+imports `onnx` and `mct_quantizers.pytorch.metadata` at module level for ONE of its cases (test_save_and_load_metadata,
+ONNX metadata_props plumbing): empty stand-in modules let the file import, that case is deselected by name, and the
+torch.save -> pytorch_load_quantized_model cases (:78-221, every quantizer inside a wrapper / holder) run.
+On a GPU box the same suite exercises the HIP kernels (the working device is 'cuda')."""
 import os
 import sys
 
@@ -30,6 +33,23 @@ compat.install_reference_aliases(force=False)
 import mct_quantizers  # noqa: E402,F401
 assert mct_quantizers.__name__ == "mct_quantizers_amd", "the real package is importable: refusing to shadow it"
 sys.path.insert(0, os.path.dirname(REF_TESTS))          # so that `tests.pytorch_tests...` imports resolve
+
+import importlib.util  # noqa: E402
+import types  # noqa: E402
+
+
+def _out_of_scope(*_a, **_k):
+    raise NotImplementedError("ONNX / metadata plumbing is out of this package's scope (SURVEY.md section 2, rows 8-9)")
+
+
+if importlib.util.find_spec("onnx") is None:             # not installed here; only the deselected metadata case uses it
+    sys.modules["onnx"] = types.ModuleType("onnx")
+meta = types.ModuleType("mct_quantizers.pytorch.metadata")
+for name in ("add_metadata", "add_onnx_metadata", "get_metadata", "get_onnx_metadata"):
+    setattr(meta, name, _out_of_scope)
+sys.modules.setdefault("mct_quantizers.pytorch.metadata", meta)
+sys.modules.setdefault("mct_quantizers_amd.pytorch.metadata", meta)
 args = [os.path.join(REF_TESTS, "pytorch_tests"), "-q", "-p", "no:cacheprovider", "--rootdir", "/tmp",
-        "--ignore", os.path.join(REF_TESTS, "pytorch_tests", "onnx_export_tests")] + sys.argv[1:]
+        "--ignore", os.path.join(REF_TESTS, "pytorch_tests", "onnx_export_tests"),
+        "-k", "not test_save_and_load_metadata"] + sys.argv[1:]
 sys.exit(pytest.main(args))
