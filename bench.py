@@ -93,7 +93,7 @@ def parse():
                     help="issue independent steps round-robin on this many HIP streams (default 1: the judged protocol)")
     ap.add_argument("--stream-depth", type=int, default=0,
                     help="config 3: batches per replay of the activation stream (pytorch/graphs.py: CapturedStream; one fused "
-                         "batched launch per D batches).  0 = automatic (on for --batch <= 16, D = the largest divisor of "
+                         "batched launch per D batches).  0 = automatic (on for --batch <= 64, D = the largest divisor of "
                          "--steps that is <= 32 and <= steps / 2), -1 = off (one eager call per batch)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: dry run of the entry path over gloo (tests); not a measurement")
@@ -192,7 +192,7 @@ def main():
     tensors = max(1, args.batched)
     per_launch = 1                               # steps served by one launch (activation stream: D batches per replay)
     stream_on = (args.config == "cfg3" and not args.batched and not dry and not args.graph and args.streams == 1
-                 and (args.stream_depth > 0 or (args.stream_depth == 0 and args.batch <= 16)) and native.fast() is not None)
+                 and (args.stream_depth > 0 or (args.stream_depth == 0 and args.batch <= 64)) and native.fast() is not None)
     if stream_on:
         cap = args.stream_depth if args.stream_depth > 0 else min(32, max(1, args.steps // 2))
         per_launch = max(d for d in range(1, cap + 1) if args.steps % d == 0)
@@ -377,6 +377,7 @@ def main():
                 if stream_on:
                     key = f"{key}_stream{per_launch}"
                 rec = json.load(f).get(key)
+            result["roofline"]["traffic_key"] = key
             if rec is None:
                 result["roofline"]["traffic_source"] = f"no PMC record {key!r} in profiles/pmc_traffic.json"
             elif rec.get("variant") != kernel_variant:

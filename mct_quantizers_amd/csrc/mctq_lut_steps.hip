@@ -4,6 +4,8 @@
 #include "mctq_kernels.hpp"
 #include "mctq_table_builder.h"
 
+#include <vector>
+
 using namespace mctq;
 
 // 2 P + 2 words, P a power of two, optionally followed by the cell index (header + cells): the sizes cannot collide
@@ -40,7 +42,7 @@ int mctq_lut_build_steps(const float* lut_host, int32_t n_lut, float mult, float
   if (const char* err = mctq_tb::build_steps(lut_host, n_lut, mult, clip_min, clip_max, steps_host, &P)) return fail_arg(err);
   int distinct = 1;                                     // distinct centres = finite-or-infinite thresholds + 1: recount
   {
-    float seen[4096]; int d = 0;
+    std::vector<float> seen(n_lut); int d = 0;
     for (int j = 0; j < n_lut; ++j) { bool dup = false; for (int k = 0; k < d; ++k) dup = dup || seen[k] == lut_host[j]; if (!dup) seen[d++] = lut_host[j]; }
     distinct = d;
   }

@@ -5,6 +5,8 @@
 // correctness argument are described at LutTableOp in mctq_kernels.hpp and in DESIGN.md.
 #pragma once
 #include <math.h>
+
+#include <vector>
 #include <stdint.h>
 #include <string.h>
 
@@ -139,7 +141,8 @@ inline const char* build_steps(const float* lut, int n_lut, float mult, float cl
   for (int j = 0; j < n_lut; ++j)
     if (!(lut[j] == floorf(lut[j])) || fabsf(lut[j]) > 1048576.0f) return "the threshold list needs an integer codebook within 2^20";
   // distinct centres, ascending (insertion sort: n <= 4096, construction time only)
-  float vs[4096];
+  std::vector<float> vs_store(4096);                      // heap: the builders keep nothing large on the stack
+  float* vs = vs_store.data();
   int D = 0;
   for (int j = 0; j < n_lut; ++j) {
     int pos = 0;
@@ -207,11 +210,17 @@ inline const char* build_steps(const float* lut, int n_lut, float mult, float cl
 inline int build_step_cells(float* steps, int P, int n_distinct, float clip_min, float clip_max) {
   const int G = steps_cells_for(P);
   if (!G) return 0;
+  // the list AND the index are staged in LDS by every block: past the 64 KiB a launch gets without opting in, keep the
+  // binary search over the list alone (P = 4096: 32 KiB)
+  if ((size_t)(2 * P + 2 + kCellHeader + G) * sizeof(float) > 64u * 1024u) return 0;
   const float gscale = (float)G / (clip_max - clip_min);
   const float* T = steps;
-  uint32_t first[8192], count[8192];
+  std::vector<uint32_t> first_store(G), count_store(G);
+  uint32_t* first = first_store.data();
+  uint32_t* count = count_store.data();
   for (int c = 0; c < G; ++c) first[c] = count[c] = 0;
-  int cells_of[4096];
+  std::vector<int> cells_store(n_distinct > 1 ? n_distinct : 1);
+  int* cells_of = cells_store.data();
   for (int k = 1; k < n_distinct; ++k) { cells_of[k] = steps_cell(T[k], clip_min, gscale, G); ++count[cells_of[k]]; }
   for (int k = 2; k < n_distinct; ++k) if (cells_of[k] < cells_of[k - 1]) return 0;    // (cannot happen: T is sorted)
   uint32_t run = 0, maxc = 0;

@@ -757,7 +757,14 @@ def _tracing() -> bool:
 _compiling = torch.compiler.is_compiling      # dynamo / export in progress: the graph must see torch.ops.mctq_amd.*
 
 
+def _wide(qmin, qmax) -> bool:
+    """Clamp domains beyond 2^24 do not fit the kernels' float32 bounds: ATen's operator (the reference's own call) runs."""
+    return max(abs(int(qmin)), abs(int(qmax))) > (1 << 24)
+
+
 def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
+    if _wide(qmin, qmax) and _is_real(x):
+        return torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)
     if _compiling():
         return torch.ops.mctq_amd.fq_per_tensor(x, scale, zero_point, qmin, qmax)
     f = _FAST if _FAST_READY else _fast_mod()
@@ -779,6 +786,8 @@ def fq_per_tensor(x, scale: float, zero_point: int, qmin: int, qmax: int):
 def fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
     """``torch.fake_quantize_per_tensor_affine(x, scale_tensor, zero_point_tensor, qmin, qmax)``: the parameters are
     1-element tensors (float32 / int32) that the kernel reads on the device."""
+    if _wide(qmin, qmax) and _is_real(x):
+        return torch.fake_quantize_per_tensor_affine(x, scale, zero_point, qmin, qmax)
     if _compiling():
         return torch.ops.mctq_amd.fq_per_tensor_tqp(x, scale, zero_point, qmin, qmax)
     f = _FAST if _FAST_READY else _fast_mod()
@@ -798,6 +807,8 @@ def fq_per_tensor_tqp(x, scale, zero_point, qmin: int, qmax: int):
 
 
 def fq_per_channel(x, scales, zero_points, axis: int, qmin: int, qmax: int, zero_zps: bool = False):
+    if _wide(qmin, qmax) and _is_real(x):
+        return torch.fake_quantize_per_channel_affine(x, scales, zero_points, axis, qmin, qmax)
     if _compiling():
         return torch.ops.mctq_amd.fq_per_channel(x, scales, zero_points, axis, qmin, qmax)
     f = _FAST if _FAST_READY else _fast_mod()
@@ -826,11 +837,13 @@ def fq_batched(items):
     model's weights are re-quantized together (see pytorch/batching.py)."""
     items = list(items)
     f = _FAST if _FAST_READY else _fast_mod()
+    if any(_wide(it[4], it[5]) for it in items):
+        f = None
     if f is not None:
         ys = f.fq_batched(items)
         if ys is not NotImplemented:
             return ys
-    if all(_is_real(it[0]) and it[0].is_cuda for it in items) and not _tracing():
+    if all(_is_real(it[0]) and it[0].is_cuda and not _wide(it[4], it[5]) for it in items) and not _tracing():
         return _hip_fq_batched(items)
     out = []
     for x, scales, zps, axis, qmin, qmax in items:            # CPU tensors, traced graphs ...: one by one

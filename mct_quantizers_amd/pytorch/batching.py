@@ -66,6 +66,7 @@ class BatchedWeightQuantization:
             if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization and m.is_str_attr:
                 for name, weight, quantizer in m.get_weights_vars():
                     if (hasattr(quantizer, "batch_item") and not quantizer.enable_reuse
+                            and int(getattr(quantizer, "num_bits", 0)) <= 24
                             and not quantizer.__dict__.get("_versioned_reuse")
                             and not (quantizer._use_custom_impl and torch.jit.is_tracing())):
                         out.append((m, name, weight, quantizer))

@@ -425,8 +425,16 @@ def test_launch_attributes_invalidate_the_plan_and_survive_pickling():
     w.zero_points[1] = 4
     assert torch.equal(w(t.clone()), torch.fake_quantize_per_channel_affine(t, w.scales, w.zero_points, 0, -128, 127))
     assert "_plan" not in pickle.loads(pickle.dumps(w)).__getstate__()
-    with pytest.raises(ValueError):
-        Q.WeightsSymmetricInferableQuantizer(25, [1.0], False)
+    # clamp domains beyond the kernels' float32 bounds (num_bits > 24) are accepted, as in the reference
+    # (base_symmetric_inferable_quantizer.py:53-60 hands int64 bounds to ATen), and run ATen's own operator
+    for nb in (25, 31):
+        wide = Q.WeightsSymmetricInferableQuantizer(nb, [1.0, 3.0], True, 0)
+        big = torch.randn(2, 5) * 1e6
+        assert torch.equal(wide(big.clone()), torch.fake_quantize_per_channel_affine(
+            big, wide.scales, wide.zero_points, 0, -2 ** (nb - 1), 2 ** (nb - 1) - 1))
+        au = Q.ActivationUniformInferableQuantizer(nb, [-1.0], [3.0])
+        assert torch.equal(au(big), torch.fake_quantize_per_tensor_affine(big, au.scale, au.zero_point, 0, 2 ** nb - 1))
+        assert au.__dict__["_plan"] is False and wide.__dict__["_plan"] is None
 
 
 def test_jit_trace_on_cpu_records_the_reference_nodes():

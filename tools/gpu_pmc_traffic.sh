@@ -27,6 +27,8 @@ run_cfg() {   # name, bench args...
 run_cfg cfg2
 run_cfg cfg2_batched16 --batched 16 --steps 60 --warmup 5
 run_cfg cfg3_n64 --config cfg3 --batch 64
+run_cfg cfg3_n64_eager --config cfg3 --batch 64 --stream-depth -1
+run_cfg cfg3_n8 --config cfg3 --batch 8
 run_cfg cfg4 --config cfg4 --steps 300
 run_cfg cfg5 --config cfg5 --steps 300
 # stall counters of the headline kernel: one pass per group (8 SQ slots, 4 TCC slots)
@@ -45,4 +47,4 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq::" $f | tail -400 >> $out/stall_$i.csv; else echo "group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
 done
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
-for c in cfg2 cfg2_batched16 cfg3_n64 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
+for c in cfg2 cfg2_batched16 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
