@@ -734,8 +734,10 @@ __device__ __forceinline__ void one_tile(const Op& op, float* smem, const TI* __
 // U independent loads in flight per lane.
 // ------------------------------------------------------------------------------------------
 template <class Op, class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void flat_kernel(Op op, typename Op::Param p,
-                                                        const TI* __restrict__ xs, TO* __restrict__ ys, int64_t n) {
+// (Scalar arguments first: with -amdgpu-kernarg-preload-count they arrive in SGPRs at wave start, so the data loads
+// are issued without waiting for a kernel-argument fetch; the op struct behind them is only needed once data lands.)
+__global__ __launch_bounds__(kThreads) void flat_kernel(const TI* __restrict__ xs, TO* __restrict__ ys, int64_t n,
+                                                        Op op, typename Op::Param p) {
   typedef IO<TI, TO> io;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int64_t nv = n / io::N;
@@ -770,8 +772,8 @@ __global__ __launch_bounds__(kThreads) void flat_scalar_kernel(Op op, typename O
 // in SGPRs for the whole block.
 // ------------------------------------------------------------------------------------------
 template <class Op, class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void rows_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
-                                                        uint32_t tiles_per_row, uint32_t innerv, uint32_t channels) {
+__global__ __launch_bounds__(kThreads) void rows_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,
+                                                        uint32_t tiles_per_row, uint32_t innerv, uint32_t channels, Op op) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t row = blockIdx.x, tile = 0;
   if (tiles_per_row != 1) {                                // uniform branch: skip the division for 1 tile/row
@@ -1152,7 +1154,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
         if (blocks == 0) blocks = 1;
         if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
         hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                           op, p, x, y, n);
+                           x, y, n, op, p);
         note<Op, TI, TO>("flat_kernel", U, NT);
       });
       return check_launch("flat launch");
@@ -1176,7 +1178,7 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
       if (blocks == 0) blocks = 1;
       if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
       launch_resolved<flat_kernel<Op, TI, TO, U, NT>>(dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                                                       op, p, x, y, n);
+                                                       x, y, n, op, p);
       note<Op, TI, TO>("flat_kernel", U, NT);
     });
     return check_launch("flat launch");
@@ -1214,7 +1216,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       if ((Op::kFixedU != 0 || !g_heavy_persistent) && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
-                             st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
+                             st, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels, op);
           note<Op, TI, TO>("rows_kernel", U, NT);
         });
         return check_launch("rows launch");
@@ -1245,7 +1247,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       if (rows * tiles <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_U_NT(best_u, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)(rows * tiles)), dim3(kThreads), book_bytes,
-                             st, op, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels);
+                             st, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels, op);
           note<Op, TI, TO>("rows_kernel", U, NT);
         });
         return check_launch("rows launch");

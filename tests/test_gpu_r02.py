@@ -423,8 +423,12 @@ def test_public_attribute_changes_take_effect(lib):
     for obj in (q, qs, qw, qt):
         clone = pickle.loads(pickle.dumps(obj))
         assert torch.equal(clone(w.clone()), obj(w.clone())) and torch.equal(copy.deepcopy(obj)(w.clone()), obj(w.clone()))
-    with pytest.raises(ValueError):
-        Q.ActivationSymmetricInferableQuantizer(30, [2.0], True)
+    # clamp domains beyond the kernels' float32 bounds are accepted, as in the reference, and run ATen's operator on the GPU
+    wide = Q.ActivationSymmetricInferableQuantizer(30, [2.0], True)
+    big = torch.randn(3, 64, device="cuda") * 1e5
+    assert torch.equal(wide(big), torch.fake_quantize_per_tensor_affine(big, wide.scales, 0, -2 ** 29, 2 ** 29 - 1))
+    ww = Q.WeightsSymmetricInferableQuantizer(28, [1.0, 2.0, 3.0], True, 0)
+    assert torch.equal(ww(big.clone()), torch.fake_quantize_per_channel_affine(big, ww.scales, ww.zero_points, 0, -2 ** 27, 2 ** 27 - 1))
 
 
 def test_parameters_on_another_device_raise_cleanly(lib):
