@@ -11,6 +11,7 @@ int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggrega
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_ql_variant = 0;
+int g_ql_band = 0;
 int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)
 
 int fail_arg(const char* msg) {
@@ -107,11 +108,16 @@ int mctq_set_tuning(const char* key, int32_t value) {
     return 0;
   }
   if (!strcmp(key, "ql_variant")) {
-    static const int ok[] = {0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 142, 144, 1212, 612, 66, 662, 12122, 2588, 2548, 2584, 2544, 2560};
+    static const int ok[] = {0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 142, 144, 1212, 612, 66, 662, 12122, 2588, 2548, 2584, 2544, 2560, 3448, 3486, 3846, 4442};
     bool found = false;
     for (int v : ok) found = found || v == value;
     if (!found) return fail_arg("ql_variant must be 0, <waves><row tiles> (41 ... 84) a tile (1212, 612, 66, 662, 12122) or a wide tile (2588, 2548, 2584, 2544, 2560)");
     g_ql_variant = value;
+    return 0;
+  }
+  if (!strcmp(key, "ql_band")) {
+    if (value < 0 || value > 4096) return fail_arg("ql_band must be 0 (automatic) or the number of tile rows per band");
+    g_ql_band = value;
     return 0;
   }
   return fail_arg("unknown tuning key");

@@ -19,6 +19,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kQlKBlock = 256;          // bytes of K per wave step: 4 lane groups x 64 B
 extern int g_ql_variant;                // tuning hook "ql_variant": 0 = automatic
+// what the calling thread launched last (mctq_last_launch): "qlinear_<kernel>_<tile>" with the code widths
+template <bool A_U8>
+static void note_ql(const char* shape, int u = 0) {
+  g_note.shape = shape; g_note.op = A_U8 ? "u8 x i8" : "i8 x i8"; g_note.unroll = u; g_note.nt = 0;
+  g_note.in_bytes = 1; g_note.out_bytes = 4;
+}
+extern int g_ql_band;                   // tuning hook "ql_band": tile rows per band of the tiled kernel, 0 = automatic
 
 // Output form: float32 values, or the next layer's activation codes (the fake-quant arithmetic of
 // mctq_fq_codes_per_tensor applied to the float32 value in registers: clamp(rint(v * inv) + zp, lo, hi)).
@@ -361,6 +368,7 @@ static int launch_qlinear_lds(const void* a, const int8_t* w, const float* w_sca
   else
     hipLaunchKernelGGL((qlinear_i8_lds_kernel<WAVES, MT, A_U8, false>), grid, dim3(WAVES * 64), 0, stream,
                        (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
+  note_ql<A_U8>(WAVES == 8 ? "qlinear_stream_lds_8waves" : "qlinear_stream_lds_4waves", MT);
   return check_launch("mctq_qlinear_i8 (LDS-staged activations)");
 }
 
@@ -376,6 +384,7 @@ static int launch_qlinear(const void* a, const int8_t* w, const float* w_scales,
   else
     hipLaunchKernelGGL((qlinear_i8_kernel<WAVES, MT, A_U8, false, W4>), grid, dim3(WAVES * 64), 0, stream,
                        (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, oq);
+  note_ql<A_U8>(W4 ? "qlinear_stream_w4" : WAVES == 8 ? "qlinear_stream_8waves" : "qlinear_stream_4waves", MT);
   return check_launch("mctq_qlinear_i8");
 }
 
@@ -405,17 +414,23 @@ template <int BM, int BN, int kTileBK, bool A_U8>
 __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
-    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, QlOut oq) {
+    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, int gm, QlOut oq) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int CPR = kTileBK / 16;
   constexpr int SA = BM * CPR, SB = BN * CPR;        // slots of the A and of the B image
   constexpr int LT = (SA + SB) / 256;                // copies per thread per tile
   __shared__ i32x4 lds[2][SA + SB];
 
+  // Blocks are dealt round-robin to the 8 XCDs, each with its own L2: an XCD takes CONSECUTIVE tiles, ordered in bands
+  // of gm tile rows (all gm row tiles of a column tile first), so what one XCD reads -- gm x BM activation rows and its
+  // share of the weight rows -- is as small as the host could make it and stays in that XCD's L2 (gm = 1: row-major).
   const int total = m_blocks * n_blocks;
   int id = blockIdx.x;
   if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
-  const int mb = id / n_blocks, nb = id - mb * n_blocks;
+  const int per_band = gm * n_blocks;
+  const int band = id / per_band, in_band = id - band * per_band;
+  const int band_rows = min(gm, m_blocks - band * gm);
+  const int mb = band * gm + in_band % band_rows, nb = in_band / band_rows;
   const int m0 = mb * BM, n0 = nb * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -509,8 +524,19 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
                        const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
                        const QlOut& oq, hipStream_t stream) {
   const int mbl = (int)((M + BM - 1) / BM), nbl = (int)((N + BN - 1) / BN);
+  // tile rows per band: an XCD's chunk of total / 8 consecutive tiles as a gm x (chunk / gm) rectangle with the least
+  // gm * BM + (chunk / gm) * BN, i.e. gm ~ sqrt(chunk * BN / BM)   (tuning key "ql_band" overrides)
+  int gm = g_ql_band;
+  if (gm <= 0) {
+    const double chunk = (double)mbl * nbl / 8.0;
+    gm = (int)(sqrt(chunk * BN / BM) + 0.5);
+  }
+  gm = gm < 1 ? 1 : gm > mbl ? mbl : gm;
   hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
-                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, oq);
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
+  static const char* const kName = BM == 128 && BN == 128 ? (BK == 128 ? "qlinear_tiled_128x128x128" : "qlinear_tiled_128x128x256")
+      : BM == 64 && BN == 128 ? "qlinear_tiled_64x128x128" : BK == 128 ? "qlinear_tiled_64x64x128" : "qlinear_tiled_64x64x256";
+  note_ql<A_U8>(kName, gm);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
 }
 
@@ -592,14 +618,15 @@ __device__ __forceinline__ void ql_second_half(i32x4 (&acc)[TM][TN], const i32x4
   }
 }
 
-template <int TM, int TN, bool A_U8>
-__global__ __launch_bounds__(256, 1) void qgemm_i8_wide_kernel(
+template <int TM, int TN, bool A_U8, int S = 4, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void qgemm_i8_wide_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
     int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, QlOut oq) {
-  constexpr int BM = 32 * TM, BN = 32 * TN, CPR = 4, S = 4;
+  constexpr int BM = 32 * TM, BN = 32 * TN, CPR = 4;                // S: LDS stages of the ring (S - 1 in flight)
   constexpr int SA = BM * CPR, SB = BN * CPR, SLOTS = SA + SB;      // 16-byte slots of one stage
   constexpr int LA = SA / 256, LB = SB / 256, LT = LA + LB;          // copies per thread per stage
+  static_assert(S >= 4 && (S - 2) * LT <= 63 && OCC * S * SLOTS * 16 <= 160 * 1024, "ring depth / blocks per CU");
   __shared__ i32x4 lds[S * SLOTS];
 
   const int total = m_blocks * n_blocks;
@@ -626,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void qgemm_i8_wide_kernel(
   const int8_t* pw = w + (int64_t)(n0 + crow) * K + 16 * cchunk;
   const int64_t jstride = 64 * K;
   auto copy_stage = [&](int slot, int kt) {
-    i32x4* dst = lds + (slot & (S - 1)) * SLOTS + wave * 64;
+    i32x4* dst = lds + (slot % S) * SLOTS + wave * 64;
     const int64_t k0 = (int64_t)kt * 64;
 #pragma unroll
     for (int j = 0; j < LA; ++j)
@@ -672,16 +699,14 @@ __global__ __launch_bounds__(256, 1) void qgemm_i8_wide_kernel(
     }
     ql_mfma_run<TM, TN, 0, H1>(acc, fa, fb);
     // stage kt+1 complete in LDS for every wave (own copies retired, then the barrier); stage kt+2 may still fly
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LT) : "memory");
-    copy_stage(kt + 3, min(kt + 3, kt_last));            // into the slot of kt-1, whose fragments were consumed a step ago
-    const uint32_t so = (uint32_t)((kt + 1) & (S - 1)) * kStageBytes;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 3) * LT) : "memory");
+    copy_stage(kt + S - 1, min(kt + S - 1, kt_last));    // into the slot of kt-1, whose fragments were consumed a step ago
+    const uint32_t so = (uint32_t)((kt + 1) % S) * kStageBytes;
     ql_second_half<TM, TN, kFragBytes, true, 0>(acc, fa, fb, na, nb_, a_byte + so, b_byte + so);
   };
 
-  copy_stage(0, 0);
-  copy_stage(1, 1);
-  copy_stage(2, 2);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LT) : "memory");
+  ql_static_for<0, S - 1>([&](auto i_) { copy_stage(decltype(i_)::value, min((int)decltype(i_)::value, kt_last)); });
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 2) * LT) : "memory");
   ql_frag_reads<TM, kFragBytes, 0, NR>(fa0, fb0, a_byte, b_byte);
   for (int kt = 0; kt < kt_n; kt += 2) {                // kt_n is even (host check)
     step(kt, fa0, fb0, fa1, fb1);
@@ -879,18 +904,22 @@ static int launch_pp(const void* a, const int8_t* w, const float* w_scales, cons
   const int mbl = (int)(M / 256), nbl = (int)(N / 256);
   hipLaunchKernelGGL((qgemm_i8_pp_kernel<A_U8>), dim3((unsigned)(mbl * nbl)), dim3(512), 0, stream,
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, oq);
+  note_ql<A_U8>("qlinear_pingpong_256x256");
   return check_launch("mctq_qlinear_i8 (ping-pong tiles)");
 }
 
-template <int TM, int TN, bool A_U8>
+template <int TM, int TN, bool A_U8, int S = 4, int OCC = 1>
 static int launch_wide(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
                        const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
                        const QlOut& oq, hipStream_t stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   if (M % BM != 0 || N % BN != 0 || K % 128 != 0 || K < 256) return fail_arg("wide tiled kernel needs whole tiles, K % 128 == 0 and K >= 256");
   const int mbl = (int)(M / BM), nbl = (int)(N / BN);
-  hipLaunchKernelGGL((qgemm_i8_wide_kernel<TM, TN, A_U8>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
+  hipLaunchKernelGGL((qgemm_i8_wide_kernel<TM, TN, A_U8, S, OCC>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, oq);
+  static const char* const kName = TM == 8 && TN == 8 ? "qlinear_wide_256x256" : TM == 4 && TN == 8 ? "qlinear_wide_128x256"
+      : TM == 8 ? "qlinear_wide_256x128" : "qlinear_wide_128x128";
+  note_ql<A_U8>(kName, S);
   return check_launch("mctq_qlinear_i8 (wide tiles)");
 }
 
@@ -941,6 +970,19 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
 #define MCTQ_QW(TM_, TN_)                                                                                         \
   (u8 ? launch_wide<TM_, TN_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)      \
       : launch_wide<TM_, TN_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+#define MCTQ_QWS(TM_, TN_, S_)                                                                                    \
+  (u8 ? launch_wide<TM_, TN_, true, S_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
+      : launch_wide<TM_, TN_, false, S_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+#define MCTQ_QWO(TM_, TN_, S_, OCC_)                                                                                 \
+  (u8 ? launch_wide<TM_, TN_, true, S_, OCC_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
+      : launch_wide<TM_, TN_, false, S_, OCC_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  if (g_ql_variant == 4442) return MCTQ_QWO(4, 4, 4, 2);     // 128 x 128 tiles, two blocks per CU
+  switch (g_ql_variant) {                            // deeper rings: 3<TM><TN><stages>
+    case 3448: return MCTQ_QWS(4, 4, 8);
+    case 3486: return MCTQ_QWS(4, 8, 6);
+    case 3846: return MCTQ_QWS(8, 4, 6);
+    default: break;
+  }
   switch (g_ql_variant) {
     case 2588: return MCTQ_QW(8, 8);
     case 2548: return MCTQ_QW(4, 8);
@@ -982,6 +1024,11 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
                 : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
     if (w48_rate > old_rate) return MCTQ_QW(4, 8);
   }
+  // One round of whole 128 x 128 tiles (1024 x 4096^2): the asm-pinned 4-stage kernel at one block per CU runs at the CU's
+  // operand intake (~40 GB/s of direct-to-LDS copies per CU: 1 MiB of operands per tile in 26 us, profiles/r03/
+  // qlinear_mid_probe.log) like the compiler-scheduled tiles below, but without their second wave of blocks: 30.7 vs 34.6 us.
+  if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0 && blocks(128, 128) >= cus && blocks(128, 128) < 2 * cus)
+    return MCTQ_QW(4, 4);
   {                                                  // tiled: the largest tile that still gives every CU two blocks
     if (blocks(128, 128) >= 2 * cus) return MCTQ_QG(128, 128, 128);
     if (blocks(64, 128) >= 2 * cus) return MCTQ_QG(64, 128, 128);
