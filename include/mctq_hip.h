@@ -239,6 +239,25 @@ int mctq_lut_per_tensor_f64(const double* x, float* y, int64_t n,
                             void* stream);
 
 /*
+ * float64 tensors through a sorted threshold list evaluated in DOUBLE (integer codebooks, centres and clip bounds
+ * within 2^20): the reference's chain runs quotient, clip and distances in double for a double tensor
+ * (quantizer_utils.py:126-134 under type promotion), so the staircase's thresholds are doubles.
+ *   mctq_lut_steps_f64_bytes  upper bound of the blob size for a codebook of n_lut entries
+ *   mctq_lut_build_steps_f64  host code: fills steps_host (double T[P], float Q[P], float q_nan, float P) and *p_out = P
+ *                             by bisecting the literal double scan; MCTQ_E_ARG when the codebook does not qualify
+ *   mctq_luts_per_tensor_f64 / _per_channel_f64   the launches; `steps` is a DEVICE copy of that blob.  Arguments as
+ *                             mctq_lut_per_tensor_f64 / mctq_lut_per_channel with dtype MCTQ_DT_F64; y is float32.
+ */
+int32_t mctq_lut_steps_f64_bytes(int32_t n_lut);
+int mctq_lut_build_steps_f64(const float* lut_host, int32_t n_lut, float mult, float clip_min, float clip_max,
+                             void* steps_host, int32_t* p_out);
+int mctq_luts_per_tensor_f64(const double* x, float* y, int64_t n, double thr_div, float thr_mul, const void* steps,
+                             int32_t P, float mult, float clip_min, float clip_max, void* stream);
+int mctq_luts_per_channel_f64(const double* x, float* y, int64_t outer, int64_t channels, int64_t inner,
+                              const float* thresholds, float eps, const void* steps, int32_t P, float mult,
+                              float clip_min, float clip_max, void* stream);
+
+/*
  * Decision-table form of the LUT quantizer (integer codebooks, clip range of at most 1023.5 units).
  *
  * The literal scan above costs ~4 VALU ops per codebook entry per element.  For an integer codebook the

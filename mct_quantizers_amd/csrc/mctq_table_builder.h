@@ -235,4 +235,90 @@ inline int build_step_cells(float* steps, int P, int n_distinct, float clip_min,
   return kCellHeader + G;
 }
 
+// ---- the same threshold list for float64 tensors: the reference's chain evaluates quotient, clip and distances in
+// double there (type promotion, quantizer_utils.py:126-134), so the staircase's steps sit at DOUBLE thresholds.
+// Same argument as above (integer centres: distances to non-neighbours differ by >= 1, fl(t - a) is monotone in t),
+// same construction with the literal scan and the bisection carried out in double.
+// Blob layout: double T[P] (T[0] unused), float Q[P], float q_nan, float P  ->  12 P + 8 bytes (P <= 4096: 48 KiB).
+inline double literal64(double t, const float* lut, int n) {
+  float best_c = lut[0];
+  double best_d = fabs(t - (double)lut[0]);
+  for (int j = 1; j < n; ++j) {
+    const double d = fabs(t - (double)lut[j]);
+    if (d < best_d) { best_d = d; best_c = lut[j]; }
+  }
+  return (double)best_c;
+}
+inline uint64_t d2ord(double f) { uint64_t u; memcpy(&u, &f, 8); return (u >> 63) ? ~u : (u | 0x8000000000000000ull); }
+inline double ord2d(uint64_t o) { uint64_t u = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o; double f; memcpy(&f, &u, 8); return f; }
+inline size_t steps64_bytes(int P) { return (size_t)P * 12u + 8u; }
+
+inline const char* build_steps64(const float* lut, int n_lut, float mult, float clip_min, float clip_max, void* blob,
+                                 int* p_out) {
+  if (!lut || !blob || !p_out) return "NULL pointer";
+  if (n_lut < 1 || n_lut > 4096) return "n_lut must be in [1, 4096]";
+  int e = 0;
+  if (!(mult > 0.0f) || frexpf(mult, &e) != 0.5f) return "mult must be a positive power of two";
+  if (!(clip_min < clip_max) || fabsf(clip_min) > 1048576.0f || fabsf(clip_max) > 1048576.0f) return "clip range unsupported";
+  for (int j = 0; j < n_lut; ++j)
+    if (!(lut[j] == floorf(lut[j])) || fabsf(lut[j]) > 1048576.0f) return "the threshold list needs an integer codebook within 2^20";
+  std::vector<float> vs(n_lut);
+  int D = 0;
+  for (int j = 0; j < n_lut; ++j) {
+    int pos = 0;
+    while (pos < D && vs[pos] < lut[j]) ++pos;
+    if (pos < D && vs[pos] == lut[j]) continue;
+    for (int k = D; k > pos; --k) vs[k] = vs[k - 1];
+    vs[pos] = lut[j];
+    ++D;
+  }
+  const int P = steps_pow2(D);
+  std::vector<double> T(P, INFINITY);
+  std::vector<float> Qv(P, vs[D - 1] / mult);
+  T[0] = -INFINITY;
+  for (int k = 0; k < D; ++k) Qv[k] = vs[k] / mult;
+  const double cmin = clip_min, cmax = clip_max;
+  const uint64_t olo = d2ord(cmin), ohi = d2ord(cmax);
+  for (int k = 1; k < D; ++k) {
+    if (literal64(cmin, lut, n_lut) >= (double)vs[k]) { T[k] = -INFINITY; continue; }
+    if (literal64(cmax, lut, n_lut) < (double)vs[k]) { T[k] = INFINITY; continue; }
+    uint64_t a = olo, b = ohi;
+    while (b - a > 1) {
+      const uint64_t m = a + (b - a) / 2;
+      if (literal64(ord2d(m), lut, n_lut) >= (double)vs[k]) b = m; else a = m;
+    }
+    T[k] = ord2d(b);
+  }
+  for (int k = 2; k < D; ++k)
+    if (T[k] < T[k - 1]) return "codebook decision is not a monotone staircase";
+  auto model = [&](double t) {
+    int idx = 0;
+    for (int sft = P >> 1; sft > 0; sft >>= 1) idx += (t >= T[idx + sft]) ? sft : 0;
+    return (double)(Qv[idx] * mult);
+  };
+  for (int k = 1; k < D; ++k) {
+    if (!(T[k] > -INFINITY && T[k] < INFINITY)) continue;
+    const uint64_t o = d2ord(T[k]);
+    for (int d = -2; d <= 2; ++d) {
+      const uint64_t oo = o + (uint64_t)(int64_t)d;
+      if (oo < olo || oo > ohi) continue;
+      const double t = ord2d(oo);
+      if (literal64(t, lut, n_lut) != model(t)) return "codebook decision is not a monotone staircase";
+    }
+  }
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  for (int r = 0; r < 4096; ++r) {
+    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+    const double t = cmin + (cmax - cmin) * ((double)(rng >> 11) * (1.0 / 9007199254740992.0));
+    if (literal64(t, lut, n_lut) != model(t)) return "codebook decision is not a monotone staircase";
+  }
+  uint8_t* out = static_cast<uint8_t*>(blob);
+  memcpy(out, T.data(), (size_t)P * 8u);
+  memcpy(out + (size_t)P * 8u, Qv.data(), (size_t)P * 4u);
+  const float tail[2] = {lut[0] / mult, (float)P};
+  memcpy(out + (size_t)P * 12u, tail, 8);
+  *p_out = P;
+  return nullptr;
+}
+
 }  // namespace mctq_tb

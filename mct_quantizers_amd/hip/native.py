@@ -108,6 +108,15 @@ SIGNATURES = {
     "mctq_lut_table_entries": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float]),
     "mctq_lut_build_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_void_p]),
+    "mctq_lut_steps_f64_bytes": (ctypes.c_int32, [ctypes.c_int32]),
+    "mctq_lut_build_steps_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "mctq_luts_per_tensor_f64": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_float,
+                                                ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_void_p]),
+    "mctq_luts_per_channel_f64": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                 _c_f32p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mctq_lut_steps_words": (ctypes.c_int32, [ctypes.c_int32]),
     "mctq_lut_build_steps": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
@@ -167,6 +176,25 @@ def load():
             handle.mctq_set_tuning(b"cached_store_max_mb", int(mb))
         _lib = handle
     return _lib
+
+
+def build_lut_steps_f64(lut_values, mult: float, clip_min: float, clip_max: float):
+    """Host-side DOUBLE threshold list for float64 tensors (numpy uint8 blob + P; include/mctq_hip.h:
+    mctq_lut_build_steps_f64), or None when the codebook does not qualify (the literal double scan is used then)."""
+    import numpy as np
+    lib = load()
+    lut = np.ascontiguousarray(np.asarray(lut_values, dtype=np.float32).reshape(-1))
+    if lut.size < 1 or lut.size > 4096:
+        return None
+    cap = lib.mctq_lut_steps_f64_bytes(lut.size)
+    if cap <= 0:
+        return None
+    blob = np.zeros(cap, dtype=np.uint8)
+    p = ctypes.c_int32(0)
+    rc = lib.mctq_lut_build_steps_f64(lut.ctypes.data, lut.size, mult, clip_min, clip_max, blob.ctypes.data, ctypes.byref(p))
+    if rc != 0:
+        return None
+    return blob[: p.value * 12 + 8].copy(), int(p.value)
 
 
 def build_lut_steps(lut_values, mult: float, clip_min: float, clip_max: float):

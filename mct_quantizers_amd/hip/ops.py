@@ -315,7 +315,14 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
     y = torch.empty_like(x, dtype=torch.float32)
     lut = _param_on(x, lut, "lut_values", torch.float32)
     with _maybe_on_device(x):
-        if dt == native.DT_F64:
+        s64 = _op_steps64(lut, mult, cmin, cmax) if dt == native.DT_F64 else None
+        if s64 is not None:
+            # float64 tensor, integer codebook: the threshold list evaluated in double (the divisor is the activation
+            # quantizer's double, or a weights quantizer's float32 sum widened -- the same number either way)
+            rc = _launch(lib.mctq_luts_per_tensor_f64, x.data_ptr(), y.data_ptr(), x.numel(),
+                         thr_div64 if thr_div64 is not None else thr_div, thr_mul, s64[0].data_ptr(), s64[1], mult, cmin,
+                         cmax, _stream(x))
+        elif dt == native.DT_F64:
             if thr_div64 is not None:
                 rc = _launch(lib.mctq_lut_per_tensor_f64, x.data_ptr(), y.data_ptr(), x.numel(), thr_div64, thr_mul,
                              lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
@@ -361,7 +368,11 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
     thresholds = _param_on(x, thresholds, "thresholds", torch.float32)
     lut = _param_on(x, lut, "lut_values", torch.float32)
     with _maybe_on_device(x):
-        if table is not None and dt != native.DT_F64:
+        s64 = _op_steps64(lut, mult, cmin, cmax) if dt == native.DT_F64 else None
+        if s64 is not None:
+            rc = _launch(lib.mctq_luts_per_channel_f64, x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(),
+                         eps, s64[0].data_ptr(), s64[1], mult, cmin, cmax, _stream(x))
+        elif table is not None and dt != native.DT_F64:
             table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
                                            eps, table.data_ptr(), table.shape[0] - 1, mult, cmin, cmax, _stream(x))
@@ -629,6 +640,29 @@ def _op_table(lut, mult, cmin, cmax):
     except TypeError:                                   # not weak-referenceable: do not cache
         pass
     return books
+
+
+_op_steps64_cache = {}
+
+
+def _op_steps64(lut, mult, cmin, cmax):
+    """(device blob, P) of the DOUBLE threshold list of a codebook tensor for float64 inputs, or None (literal double
+    scan).  Built once per codebook TENSOR OBJECT and version, like ``_op_table`` (one device -> host read at the first
+    float64 call: not inside hipGraph capture)."""
+    import weakref
+    key = (id(lut), mult, cmin, cmax)
+    hit = _op_steps64_cache.get(key)
+    if hit is not None and hit[0]() is lut and hit[1] == lut._version:
+        return hit[2]
+    if len(_op_steps64_cache) > 256:
+        _op_steps64_cache.clear()
+    built = native.build_lut_steps_f64(lut.detach().cpu().numpy(), mult, cmin, cmax)
+    val = None if built is None else (torch.from_numpy(built[0]).to(lut.device), built[1])
+    try:
+        _op_steps64_cache[key] = (weakref.ref(lut), lut._version, val)
+    except TypeError:
+        pass
+    return val
 
 
 def _op_hip_lut_per_tensor(x, lut, thr_div, thr_mul, mult, cmin, cmax, step_round=0):

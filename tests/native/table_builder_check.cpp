@@ -85,6 +85,33 @@ static int check_steps(const std::vector<float>& lut, float mult, float cmin, fl
   return bad != 0;
 }
 
+// the float64 threshold list against the literal double scan on a grid, at every threshold +-3 ulps and at midpoints
+static int check_steps64(const std::vector<float>& lut, float mult, float cmin, float cmax) {
+  std::vector<unsigned char> blob(mctq_tb::steps64_bytes(mctq_tb::steps_pow2((int)lut.size())));
+  int P = 0;
+  if (const char* err = mctq_tb::build_steps64(lut.data(), (int)lut.size(), mult, cmin, cmax, blob.data(), &P)) {
+    printf("build_steps64 failed: %s\n", err);
+    return 1;
+  }
+  std::vector<double> T(P); std::vector<float> Q(P);
+  memcpy(T.data(), blob.data(), (size_t)P * 8); memcpy(Q.data(), blob.data() + (size_t)P * 8, (size_t)P * 4);
+  auto model = [&](double t) { int idx = 0; for (int s = P >> 1; s > 0; s >>= 1) idx += (t >= T[idx + s]) ? s : 0; return (double)(Q[idx] * mult); };
+  long bad = 0;
+  for (int i = 0; i <= 400000; ++i) {
+    const double t = (double)cmin + ((double)cmax - (double)cmin) * i / 400000.0;
+    if (mctq_tb::literal64(t, lut.data(), (int)lut.size()) != model(t)) ++bad;
+  }
+  for (int k = 1; k < P; ++k) {
+    if (!(T[k] > -INFINITY && T[k] < INFINITY)) continue;
+    for (int d = -3; d <= 3; ++d) {
+      const double t = mctq_tb::ord2d(mctq_tb::d2ord(T[k]) + (uint64_t)(int64_t)d);
+      if (t >= cmin && t <= cmax && mctq_tb::literal64(t, lut.data(), (int)lut.size()) != model(t)) ++bad;
+    }
+  }
+  if (bad) printf("steps64: %ld mismatches\n", bad);
+  return bad != 0;
+}
+
 int main() {
   int rc = 0;
   for (uint32_t h = 0; h < 65536; ++h) {                    // binary16 round trip
@@ -115,6 +142,11 @@ int main() {
     std::vector<float> st(mctq_tb::steps_words_for(2)); int P = 0;
     if (!mctq_tb::build_steps(bad_lut, 2, 2048, -2048, 2047, st.data(), &P)) { printf("non-integer codebook accepted (steps)\n"); rc = 1; }
   }
+  rc |= check_steps64({-5, 5}, 128, -128, 127);
+  rc |= check_steps64({3, 3, -8}, 2048, -2048, 2047);
+  rc |= check_steps64({22, -53, 62, 0, -66, -21, 44, -40}, 128, -128, 127);
+  rc |= check_steps64(w16, 32768, -32768, 32767);
+  rc |= check_steps64(all, 128, -128, 127);
   printf(rc ? "FAILED\n" : "table builder ok\n");
   return rc;
 }
