@@ -314,3 +314,31 @@ def test_same_numel_reshape_is_not_served_by_a_stale_plan():
     x.resize_(8, 64)
     y.resize_(4, 128)
     assert plan() is NotImplemented
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,key", [
+    (["--config", "cfg2", "--batched", "2", "--steps", "6", "--warmup", "2"], "batched_kernel<table>"),
+    (["--config", "cfg3", "--batch", "2", "--steps", "12", "--warmup", "2"], "batched_kernel<table>"),
+    (["--config", "cfg3", "--batch", "2", "--steps", "6", "--warmup", "2", "--stream-depth", "-1"], "flat_kernel"),
+])
+def test_bench_lines_of_the_batched_and_stream_modes(args, key):
+    """bench.py's --batched and activation-stream modes as the driver would run them: one JSON line, the kernel named,
+    the roofline fields of every clock present, the last timed step's output equal to the CPU oracle."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, "bench.py", "--prewarm-seconds", "0.05", "--cpu-seconds", "0.5", "--evidence-launches", "50"] + args,
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    rf = d["roofline"]
+    assert key in rf["kernel"], rf["kernel"]
+    for k in ("achieved", "frac", "frac_wall", "frac_events_whole_region", "kernel_us", "algorithmic_bytes_per_launch"):
+        assert rf[k] > 0, k
+    assert d["cpu_baseline"]["gpu_output_bit_equal"] is True and d["value"] > 0
+    per_launch = d["config"]["steps_per_launch"]
+    assert rf["algorithmic_bytes_per_launch"] == d["config"]["per_gpu_elems"] * 8 * per_launch
