@@ -80,7 +80,11 @@ def sync(device: torch.device, spin_on=None):
 
 
 def timed_region(step: Callable[[int], None], steps: int, device: torch.device, dist=None) -> float:
-    """Wall time of exactly ``steps`` calls of ``step``, bracketed by barrier + device synchronize on both sides."""
+    """Wall time of exactly ``steps`` calls of ``step``, bracketed by barrier + device synchronize on both sides.
+    The clock stops when THIS rank's device has finished its steps; the closing barrier follows (every rank leaves the
+    region together) and the caller takes the MAX over ranks -- the slowest rank's time for its K steps is the job's
+    time, and the collective that implements the barrier (tens of microseconds of RCCL, as much as several steps of a
+    20-step region) is measurement plumbing, not part of the path."""
     if dist is not None:
         dist.barrier()
     sync(device)
@@ -89,9 +93,10 @@ def timed_region(step: Callable[[int], None], steps: int, device: torch.device, 
     for i in range(steps):
         last = step(i)
     sync(device, last if device.type == "cuda" and isinstance(last, torch.cuda.Event) else None)
+    elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    return time.perf_counter() - t0
+    return elapsed
 
 
 def max_over_ranks(values, dist, control: str, device: torch.device):

@@ -342,3 +342,46 @@ def test_bench_lines_of_the_batched_and_stream_modes(args, key):
     assert d["cpu_baseline"]["gpu_output_bit_equal"] is True and d["value"] > 0
     per_launch = d["config"]["steps_per_launch"]
     assert rf["algorithmic_bytes_per_launch"] == d["config"]["per_gpu_elems"] * 8 * per_launch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_batched_launch_random_shapes_axes_dtypes_against_oracle(seed):
+    """Seeded fuzz of the batched kernel's tile geometry: random ranks, extents (rows shorter than, equal to, longer than
+    and not a multiple of the tile / the lane vector; outer > 1 so that channel indices wrap inside a tile), channel axes,
+    storage types, zero points and bit widths; ~150 tensors per launch through the device table AND the kernel-argument
+    source, every output compared with the oracle bit for bit."""
+    from mct_quantizers_amd.hip import native, ops
+    native.load()
+    rng = np.random.default_rng(1000 + seed)
+    cases = []
+    for k in range(150):
+        rank = int(rng.integers(1, 5))
+        while True:
+            shape = tuple(int(rng.choice([1, 2, 3, 5, 7, 8, 16, 31, 64, 100, 147, 256, 1000, 1031, 2048, 4100, 4608]))
+                          for _ in range(rank))
+            if 0 < int(np.prod(shape)) <= 300000:
+                break
+        axis = None if rng.random() < 0.2 else int(rng.integers(0, rank))
+        dt = (torch.float32, torch.float32, torch.float16, torch.bfloat16)[int(rng.integers(0, 4))]
+        c = 1 if axis is None else shape[axis]
+        scale = rng.uniform(0.003, 0.2, size=c).astype(np.float32)
+        zps = rng.integers(-7, 8, size=c).astype(np.int32) if rng.random() < 0.5 else None
+        bits = int(rng.choice([2, 3, 4, 8]))
+        x = (rng.standard_normal(shape) * rng.uniform(0.2, 3.0)).astype(np.float32)
+        cases.append((x, dt, scale, zps, axis, -(2 ** (bits - 1)), 2 ** (bits - 1) - 1))
+    items = [(torch.from_numpy(x).to(dt).cuda(), torch.from_numpy(s).cuda(), None if z is None else torch.from_numpy(z).cuda(),
+              axis, lo, hi) for (x, dt, s, z, axis, lo, hi) in cases]
+    wants = [np.asarray(_want(c), dtype=np.float32) for c in cases]
+    # kernel-argument source (and the one-by-one launches for what one grid does not take)
+    for y, want, c in zip(ops.fq_batched(items), wants, cases):
+        got = y.float().cpu().numpy()
+        assert bits_equal(got, want), f"kernarg {c[0].shape} {c[1]} axis={c[4]}: {first_mismatch(got, want, c[0])}"
+    # device-table source
+    if native.fast() is not None:
+        outs = [torch.empty_like(it[0]) for it in items]
+        plan = native.fast().BatchPlan([(it[0], o) + tuple(it[1:]) for it, o in zip(items, outs)])
+        assert plan() is None
+        for y, want, c in zip(outs, wants, cases):
+            got = y.float().cpu().numpy()
+            assert bits_equal(got, want), f"table {c[0].shape} {c[1]} axis={c[4]}: {first_mismatch(got, want, c[0])}"
