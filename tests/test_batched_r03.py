@@ -329,6 +329,9 @@ def test_bench_lines_of_the_batched_and_stream_modes(args, key):
     import subprocess
     import sys
     from conftest import REPO
+    from mct_quantizers_amd.hip import native
+    if "table" in key and native.fast() is None:
+        pytest.skip("the table launch is driven by the compiled binding (MCTQ_BINDING=ctypes / MCTQ_ROCTX=1 switch it off)")
     r = subprocess.run([sys.executable, "bench.py", "--prewarm-seconds", "0.05", "--cpu-seconds", "0.5", "--evidence-launches", "50"] + args,
                        cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-1500:]
