@@ -167,6 +167,32 @@ int64_t mctq_fq_batch_pack(const mctq_fq_item* items, int32_t n_items, void* hos
 int mctq_fq_batch_run(const void* host_table, const void* device_table, void* stream);
 
 /*
+ * The same table-driven launch for LUT quantizers that have a decision table (mctq_lut_build_table): all LUT weights of a
+ * model per forward (weights_lut_symmetric_inferable_quantizer.py:114-122 is called once per wrapped layer,
+ * quantize_wrapper.py:228-240), or a group of LUT activation batches.  Per-channel items give `thresholds` (device
+ * float32[channels]) and `eps`; per-tensor items give thresholds = NULL and the host floats thr_div / thr_mul with the
+ * meaning they have in mctq_lutt_per_tensor (step_round likewise).  y is float32.  Items one grid cannot take (x not
+ * vector-aligned, >= 2^31 elements, more than 2^20 elements in rows shorter than 32) are launched one by one.
+ * Results are bit-identical to mctq_lutt_per_tensor / mctq_lutt_per_channel.
+ */
+typedef struct mctq_lut_item {
+  const void* x;
+  float* y;
+  int64_t outer, channels, inner;
+  const float* thresholds;       /* device float32[channels], or NULL: per tensor */
+  const float* table;            /* device decision table, (entries + 1) x 2 words */
+  int32_t entries;
+  float eps;
+  float thr_div, thr_mul;
+  float mult, clip_min, clip_max;
+  int32_t dtype;                 /* MCTQ_DT_F32 / F16 / BF16: storage type of x */
+  int32_t step_round;
+} mctq_lut_item;
+
+int64_t mctq_lutt_batch_pack(const mctq_lut_item* items, int32_t n_items, void* host_table, int64_t capacity);
+int mctq_lutt_batch_run(const void* host_table, const void* device_table, void* stream);
+
+/*
  * Integer-code output of the affine quantizers: codes[i] = clamp(rint(x[i] * (1/scale)) + zero_point, quant_min,
  * quant_max), stored as int8 (MCTQ_CODE_I8, domain within [-128, 127]) or uint8 (MCTQ_CODE_U8, within [0, 255]).
  * (codes - zero_point) * scale equals the fake-quantized value of mctq_fq_* bit for bit.  This is the

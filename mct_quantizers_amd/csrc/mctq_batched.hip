@@ -28,6 +28,8 @@
 // Arithmetic: AffineOp (mctq_kernels.hpp), the same expression as every other affine entry point.
 #include "mctq_kernels.hpp"
 
+#include <vector>
+
 using namespace mctq;
 
 namespace mctq {
@@ -57,7 +59,7 @@ struct KernargSrc {
   uint32_t map[kMaxChunksK / 4];         // one byte per chunk
   uint32_t shift;
   __device__ __forceinline__ uint32_t lookup(uint32_t chunk) const { return (map[chunk >> 2] >> ((chunk & 3u) * 8u)) & 0xffu; }
-  __device__ __forceinline__ const BatchItem& item(uint32_t i) const { return it[i]; }
+  __device__ __forceinline__ const void* head(uint32_t i) const { return &it[i]; }
 };
 static_assert(sizeof(KernargSrc) <= 4096, "kernel arguments");
 
@@ -66,7 +68,7 @@ struct TableSrc {
   const uint32_t* __restrict__ map;      // device, one half-word per chunk
   uint32_t shift;
   __device__ __forceinline__ uint32_t lookup(uint32_t chunk) const { return (map[chunk >> 1] >> ((chunk & 1u) * 16u)) & 0xffffu; }
-  __device__ __forceinline__ const BatchItem& item(uint32_t i) const { return it[i]; }
+  __device__ __forceinline__ const void* head(uint32_t i) const { return &it[i]; }
 };
 
 // The descriptor's pointers arrive through scalar loads, so the compiler cannot infer their address space (it would
@@ -90,35 +92,110 @@ struct GIO {
   }
 };
 
-struct BatchParams {
+// ---- what a tile does with its elements: a POLICY per operation ---------------------------------------------------
+// init() runs after the tile's data loads have been issued (it may stage a table in LDS and synchronise the block);
+// uniform(c) / lane(c) build channel c's parameter set from a wave-uniform / per-lane index; run<UNI, N>() quantizes N
+// elements that share one set (UNI: the set is wave-uniform); pick() selects between two sets.
+template <class TI_, class TO_>
+struct AffinePol {
+  typedef TI_ TI;
+  typedef TO_ TO;
+  typedef AffineOp::Param Param;
+  AffineOp op;
   const float MCTQ_CONST* s_uniform;     // same tables, two views: wave-uniform reads (scalar loads) ...
   const int32_t MCTQ_CONST* z_uniform;
   const float MCTQ_GLOBAL* s_lane;       // ... and per-lane reads
   const int32_t MCTQ_GLOBAL* z_lane;
-  __device__ __forceinline__ AffineOp::Param uniform(uint32_t c) const {
-    return AffineOp::make(s_uniform[c], z_uniform ? z_uniform[c] : 0);
+  __device__ __forceinline__ explicit AffinePol(const BatchItem& it) {
+    s_uniform = (const float MCTQ_CONST*)it.scales; z_uniform = (const int32_t MCTQ_CONST*)it.zps;
+    s_lane = (const float MCTQ_GLOBAL*)it.scales; z_lane = (const int32_t MCTQ_GLOBAL*)it.zps;
+    op.scales = nullptr; op.zps = nullptr; op.lo = it.lo; op.hi = it.hi;
   }
-  __device__ __forceinline__ AffineOp::Param lane(uint32_t c) const {
-    return AffineOp::make(s_lane[c], z_lane ? z_lane[c] : 0);
+  __device__ __forceinline__ void init(float*) {}
+  __device__ __forceinline__ Param uniform(uint32_t c) const { return AffineOp::make(s_uniform[c], z_uniform ? z_uniform[c] : 0); }
+  __device__ __forceinline__ Param lane(uint32_t c) const { return AffineOp::make(s_lane[c], z_lane ? z_lane[c] : 0); }
+  template <bool UNI, int N>
+  __device__ __forceinline__ void run(const float* in, float* out, const Param& p) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = op.apply(in[j], p, NoBook());
+  }
+  __device__ __forceinline__ static Param pick(bool first, const Param& a, const Param& b) {
+    Param p; p.s = first ? a.s : b.s; p.inv = first ? a.inv : b.inv; p.zf = first ? a.zf : b.zf; return p;
   }
 };
 
-template <bool FULL, class TI, class TO, int U, int NT>
-__device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t e0, const uint32_t count) {
+// LUT quantizers with a decision table (LutTableOp, mctq_kernels.hpp): 96-byte descriptor = the 64 bytes above
+// (scales -> thresholds or NULL, zps -> the decision table, lo / hi unused) + the codebook's constants.
+struct __attribute__((aligned(16))) LutBatchItem {
+  BatchItem b;
+  float mult, cmin, cmax;
+  float eps;             // per channel: divisor fl32(thresholds[c] + eps)
+  float thr_div, thr_mul;   // per tensor (b.scales == NULL)
+  int32_t entries, step_round;
+};
+static_assert(sizeof(LutBatchItem) == 96, "LUT descriptor layout");
+
+template <class TI_>
+struct LutPol {
+  typedef TI_ TI;
+  typedef float TO;
+  typedef LutCommon::Param Param;
+  LutTableOp op;
+  LutTableBook book;
+  const float MCTQ_CONST* t_uniform;
+  const float MCTQ_GLOBAL* t_lane;
+  const f32x2 MCTQ_GLOBAL* table;
+  float thr_div, thr_mul;
+  __device__ __forceinline__ explicit LutPol(const LutBatchItem& it) {
+    t_uniform = (const float MCTQ_CONST*)it.b.scales; t_lane = (const float MCTQ_GLOBAL*)it.b.scales;
+    table = (const f32x2 MCTQ_GLOBAL*)it.b.zps;
+    thr_div = it.thr_div; thr_mul = it.thr_mul;
+    op.thr = nullptr; op.eps = it.eps; op.mult = it.mult; op.inv_mult = 1.0f / it.mult; op.cmin = it.cmin; op.cmax = it.cmax;
+    op.step_round = it.step_round; op.table = nullptr; op.entries = it.entries;
+    op.koff = 0.5f - 2.0f * it.cmin; op.kmax = (float)(it.entries - 1);
+  }
+  __device__ __forceinline__ void init(float* smem) {      // every thread of the block: the table goes to LDS
+    f32x2* dst = reinterpret_cast<f32x2*>(smem);
+    for (int j = threadIdx.x; j <= op.entries; j += kThreads) dst[j] = table[j];
+    __syncthreads();
+    book.tab = dst; book.nan_q = dst[op.entries].x;
+  }
+  __device__ __forceinline__ Param uniform(uint32_t c) const {
+    if (!t_uniform) return LutCommon::make(thr_div, thr_mul, op.mult);
+    const float t = t_uniform[c];
+    return LutCommon::make(t + op.eps, t, op.mult);
+  }
+  __device__ __forceinline__ Param lane(uint32_t c) const {
+    if (!t_lane) return LutCommon::make(thr_div, thr_mul, op.mult);
+    const float t = t_lane[c];
+    return LutCommon::make(t + op.eps, t, op.mult);
+  }
+  template <bool UNI, int N>
+  __device__ __forceinline__ void run(const float* in, float* out, const Param& p) const {
+    if constexpr (UNI) {
+      const bool fast = __builtin_amdgcn_readfirstlane((int)LutCommon::can_fast(p)) != 0;   // wave-uniform
+      if (fast) { op.template tile<true, N>(in, out, p, book); return; }
+    }
+    op.template tile<false, N>(in, out, p, book);
+  }
+  __device__ __forceinline__ static Param pick(bool first, const Param& a, const Param& b) {
+    Param p; p.d = first ? a.d : b.d; p.t = first ? a.t : b.t; p.r = first ? a.r : b.r; p.ds = first ? a.ds : b.ds; return p;
+  }
+};
+
+template <bool FULL, class Pol, int U, int NT>
+__device__ __forceinline__ void batched_tile(const BatchItem& it, Pol& pol, float* smem, const uint32_t e0, const uint32_t count) {
+  typedef typename Pol::TI TI;
+  typedef typename Pol::TO TO;
+  typedef typename Pol::Param Param;
   typedef IO<TI, TO> io;
   typedef GIO<TI, TO, NT> gio;
   constexpr uint32_t N = io::N;
   const TI MCTQ_GLOBAL* __restrict__ x = (const TI MCTQ_GLOBAL*)it.x;
   TO MCTQ_GLOBAL* __restrict__ y = (TO MCTQ_GLOBAL*)it.y;
   const uint32_t inner = it.inner, channels = it.channels;
-  BatchParams prm;
-  prm.s_uniform = (const float MCTQ_CONST*)it.scales; prm.z_uniform = (const int32_t MCTQ_CONST*)it.zps;
-  prm.s_lane = (const float MCTQ_GLOBAL*)it.scales; prm.z_lane = (const int32_t MCTQ_GLOBAL*)it.zps;
-  AffineOp op;
-  op.scales = nullptr; op.zps = nullptr; op.lo = it.lo; op.hi = it.hi;
-  const NoBook book;
 
-  // data loads first; the row search / parameter fetch below runs under their latency
+  // data loads first; the table staging / row search / parameter fetch below run under their latency
   typename io::VI v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -126,6 +203,7 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
     if (FULL || off + N <= count) v[u] = gio::load(x + e0 + off);
   }
   __builtin_amdgcn_sched_barrier(0);
+  pol.init(smem);
 
   uint32_t row0 = 0, rem0 = e0;
   if (channels > 1) {                                        // uniform; per-tensor items have one row
@@ -136,19 +214,21 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
 
   if (channels == 1 || rem0 + count <= inner) {
     // ---- one row: parameters in SGPRs ----
-    const AffineOp::Param p = prm.uniform(c0);
+    const Param p = pol.uniform(c0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t off = (u * kThreads + threadIdx.x) * N;
       if (FULL || off + N <= count) {
         float in[N], out[N];
         io::unpack(v[u], in);
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
+        pol.template run<true, (int)N>(in, out, p);
         gio::store(y + e0 + off, io::pack(out));
       } else {
-        for (uint32_t j = 0; j < N && off + j < count; ++j)
-          y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], p, book);
+        for (uint32_t j = 0; j < N && off + j < count; ++j) {
+          float in1[1] = {(float)x[e0 + off + j]}, out1[1];
+          pol.template run<true, 1>(in1, out1, p);
+          y[e0 + off + j] = (TO)out1[0];
+        }
       }
     }
     return;
@@ -158,7 +238,7 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
     // ---- exactly two rows (rows at least half a tile long): both parameter sets in SGPRs,
     //      a lane-vector picks by its position relative to the row boundary -- no per-lane division or table read ----
     const uint32_t c1 = c0 + 1 == channels ? 0 : c0 + 1;
-    const AffineOp::Param p0 = prm.uniform(c0), p1 = prm.uniform(c1);
+    const Param p0 = pol.uniform(c0), p1 = pol.uniform(c1);
     const uint32_t bnd = inner - rem0;                       // elements of the tile that belong to row0 (0 < bnd < count)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -168,19 +248,18 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
         float in[N], out[N];
         io::unpack(v[u], in);
         if (off + N <= bnd || off >= bnd) {
-          const bool first = off + N <= bnd;
-          AffineOp::Param p;
-          p.s = first ? p0.s : p1.s; p.inv = first ? p0.inv : p1.inv; p.zf = first ? p0.zf : p1.zf;
-#pragma unroll
-          for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
+          pol.template run<false, (int)N>(in, out, Pol::pick(off + N <= bnd, p0, p1));
         } else {                                              // the vector straddles the boundary (inner % N != 0)
 #pragma unroll
-          for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], off + j < bnd ? p0 : p1, book);
+          for (uint32_t j = 0; j < N; ++j) pol.template run<false, 1>(in + j, out + j, off + j < bnd ? p0 : p1);
         }
         gio::store(y + e0 + off, io::pack(out));
       } else {
-        for (uint32_t j = 0; j < N && off + j < count; ++j)
-          y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], off + j < bnd ? p0 : p1, book);
+        for (uint32_t j = 0; j < N && off + j < count; ++j) {
+          float in1[1] = {(float)x[e0 + off + j]}, out1[1];
+          pol.template run<false, 1>(in1, out1, off + j < bnd ? p0 : p1);
+          y[e0 + off + j] = (TO)out1[0];
+        }
       }
     }
     return;
@@ -188,15 +267,14 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
 
   // ---- several rows in the tile (inner < tile / 2): per lane-vector parameters ----
   // Pass 1 finds every vector's row (positions inside the tile are < 2^24: one float multiply + two integer
-  // corrections) and issues its table reads (U independent loads in flight); pass 2 inverts the scales and applies.
+  // corrections) and builds its parameter set (table reads issued back to back); pass 2 applies.
   const float r_inner = 1.0f / (float)inner;
   const uint32_t nrows = (rem0 + count - 1) / inner + 1;      // uniform
   const bool wraps = c0 + nrows > channels;                   // uniform: some row of the tile starts a new outer slice
   const bool small_c = (uint64_t)channels + nrows < (1u << 24);
   const float r_channels = 1.0f / (float)channels;
   uint32_t cc[U], rr[U];
-  float sv[U];
-  int32_t zv[U];
+  Param pv[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
@@ -206,8 +284,7 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
     uint32_t c = c0 + lrow;
     if (wraps) c = small_c ? c - div_small(c, channels, r_channels) * channels : c % channels;
     cc[u] = c;
-    sv[u] = prm.s_lane[c];
-    zv[u] = prm.z_lane ? prm.z_lane[c] : 0;
+    pv[u] = pol.lane(c);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -218,43 +295,51 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, const uint32_t
       float in[N], out[N];
       io::unpack(v[u], in);
       if (rem + N <= inner) {                               // the vector lies in one row
-        const AffineOp::Param p = AffineOp::make(sv[u], zv[u]);
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], p, book);
+        pol.template run<false, (int)N>(in, out, pv[u]);
       } else {
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-          out[j] = op.apply(in[j], prm.lane(c), book);
+          pol.template run<false, 1>(in + j, out + j, pol.lane(c));
           if (++rem == inner) { rem = 0; if (++c == channels) c = 0; }
         }
       }
       gio::store(y + e0 + off, io::pack(out));
     } else {
       for (uint32_t j = 0; j < N && off + j < count; ++j) {
-        y[e0 + off + j] = (TO)op.apply((float)x[e0 + off + j], prm.lane(c), book);
+        float in1[1] = {(float)x[e0 + off + j]}, out1[1];
+        pol.template run<false, 1>(in1, out1, pol.lane(c));
+        y[e0 + off + j] = (TO)out1[0];
         if (++rem == inner) { rem = 0; if (++c == channels) c = 0; }
       }
     }
   }
 }
 
+// Block -> its descriptor: one map word, then the 64-byte head in ONE scalar load (left to itself the compiler fetches
+// tile_begin / tiles first and the pointers behind the idle-block test: one more dependent round trip in front of the
+// data loads).
+template <class Src>
+__device__ __forceinline__ bool batched_head(const Src& src, BatchItem& out, uint32_t& index) {
+  index = src.lookup(blockIdx.x >> src.shift);
+  typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+  union { u32x16 w; BatchItem it; } d;
+  d.w = *reinterpret_cast<const u32x16*>(src.head(index));
+  asm volatile("" : "+s"(d.w));
+  out = d.it;
+  return blockIdx.x - out.tile_begin < out.tiles;            // false: idle block at the end of the tensor's last chunk
+}
+
 template <class TI, class TO, int U, int NT, class Src>
 __device__ __forceinline__ void batched_block(const Src& src) {
   constexpr uint32_t TILE = kThreads * U * IO<TI, TO>::N;
-  const uint32_t i = src.lookup(blockIdx.x >> src.shift);    // scalar loads: one map word, then one descriptor
-  // the whole 64-byte descriptor in ONE scalar load (left to itself the compiler fetches tile_begin / tiles first
-  // and the pointers behind the idle-block test: one more dependent round trip in front of the data loads)
-  typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-  union { u32x16 w; BatchItem it; } d;
-  d.w = *reinterpret_cast<const u32x16*>(&src.item(i));
-  asm volatile("" : "+s"(d.w));
-  const BatchItem& it = d.it;
-  const uint32_t t = blockIdx.x - it.tile_begin;
-  if (t >= it.tiles) return;                                 // idle block at the end of the tensor's last chunk
-  const uint32_t e0 = t * TILE;
+  BatchItem it;
+  uint32_t index;
+  if (!batched_head(src, it, index)) return;
+  const uint32_t e0 = (blockIdx.x - it.tile_begin) * TILE;
   const uint32_t left = it.n - e0;
-  if (left >= TILE) batched_tile<true, TI, TO, U, NT>(it, e0, TILE);      // wave-uniform: straight-line code
-  else batched_tile<false, TI, TO, U, NT>(it, e0, left);
+  AffinePol<TI, TO> pol(it);
+  if (left >= TILE) batched_tile<true, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, TILE);   // wave-uniform: straight-line code
+  else batched_tile<false, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, left);
 }
 
 template <class TI, class TO, int U, int NT>
@@ -270,6 +355,42 @@ __global__ __launch_bounds__(kThreads) void batched_table_kernel(const BatchItem
   TableSrc src;
   src.it = it; src.map = map; src.shift = shift;
   batched_block<TI, TO, U, NT>(src);
+}
+
+// The same grid for LUT quantizers with a decision table: all LUT weights of a model, or a group of LUT activation
+// batches, in one launch.  Output float32 (the reference's chain promotes), table staged in dynamic LDS per block.
+struct LutTableSrc {
+  const LutBatchItem* __restrict__ it;
+  const uint32_t* __restrict__ map;
+  uint32_t shift;
+  __device__ __forceinline__ uint32_t lookup(uint32_t chunk) const { return (map[chunk >> 1] >> ((chunk & 1u) * 16u)) & 0xffffu; }
+  __device__ __forceinline__ const void* head(uint32_t i) const { return &it[i].b; }
+};
+
+template <class TI, int U, int NT>
+__global__ __launch_bounds__(kThreads) void batched_lut_table_kernel(const LutBatchItem* __restrict__ items,
+                                                                     const uint32_t* __restrict__ map, uint32_t shift) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr uint32_t TILE = kThreads * U * IO<TI, float>::N;
+  LutTableSrc src;
+  src.it = items; src.map = map; src.shift = shift;
+  BatchItem it;
+  uint32_t index;
+  if (!batched_head(src, it, index)) return;
+  LutBatchItem full;
+  full.b = it;
+  {                                                          // the codebook constants: 32 more bytes, off the critical path
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    union { u32x8 w; float f[8]; int32_t i[8]; } t;
+    t.w = *reinterpret_cast<const u32x8*>(reinterpret_cast<const uint8_t*>(&items[index]) + sizeof(BatchItem));
+    full.mult = t.f[0]; full.cmin = t.f[1]; full.cmax = t.f[2]; full.eps = t.f[3]; full.thr_div = t.f[4]; full.thr_mul = t.f[5];
+    full.entries = t.i[6]; full.step_round = t.i[7];
+  }
+  const uint32_t e0 = (blockIdx.x - it.tile_begin) * TILE;
+  const uint32_t left = it.n - e0;
+  LutPol<TI> pol(full);
+  if (left >= TILE) batched_tile<true, LutPol<TI>, U, NT>(it, pol, smem, e0, TILE);
+  else batched_tile<false, LutPol<TI>, U, NT>(it, pol, smem, e0, left);
 }
 
 template <class TI, class TO>
@@ -299,6 +420,15 @@ static int launch_batch_dt(int dt, const Src& src, uint32_t grid, int64_t out_by
   if (dt == MCTQ_DT_F32) return launch_batch<float, float>(src, grid, out_bytes, st);
   if (dt == MCTQ_DT_F16) return launch_batch<_Float16, _Float16>(src, grid, out_bytes, st);
   return launch_batch<__bf16, __bf16>(src, grid, out_bytes, st);
+}
+
+template <class TI>
+static int launch_lut_batch(const LutTableSrc& src, uint32_t grid, size_t lds, int64_t out_bytes, hipStream_t st) {
+  MCTQ_WITH_MODE(nt_mode(out_bytes) == 0 ? 1 : nt_mode(out_bytes), false, {
+    hipLaunchKernelGGL((batched_lut_table_kernel<TI, kBatchU, NT>), dim3(grid), dim3(kThreads), lds, st, src.it, src.map, src.shift);
+    note<LutTableOp, TI, float>("batched_lut_kernel<table>", kBatchU, NT);
+  });
+  return check_launch("batched LUT launch");
 }
 
 // ---- host: which tensors one grid can take, and how the grid is cut ---------------------------------------
@@ -526,6 +656,168 @@ int mctq_fq_batch_run(const void* host_table, const void* device_table, void* st
   const mctq_fq_item* sg = reinterpret_cast<const mctq_fq_item*>(base + h->singles_off);
   for (uint32_t s = 0; s < h->n_singles; ++s)
     if (int rc = launch_single(sg[s], stream)) return rc;
+  return 0;
+}
+
+// ---- LUT quantizers with a decision table: the same table-driven grid -------------------------------------------
+namespace {
+
+int validate_lut_items(const mctq_lut_item* items, int32_t n_items) {
+  if (n_items < 0) return fail_arg("n_items < 0");
+  if (n_items > 0 && !items) return fail_arg("items is NULL");
+  for (int32_t k = 0; k < n_items; ++k) {
+    const mctq_lut_item& d = items[k];
+    if (d.outer < 0 || d.channels < 0 || d.inner < 0) return fail_arg("negative extent");
+    if (d.outer * d.channels * d.inner > 0 && (!d.x || !d.y || !d.table)) return fail_arg("NULL pointer");
+    if (d.dtype != MCTQ_DT_F32 && d.dtype != MCTQ_DT_F16 && d.dtype != MCTQ_DT_BF16) return fail_arg("unknown dtype");
+    if (d.step_round != 0 && d.step_round != MCTQ_DT_F16 && d.step_round != MCTQ_DT_BF16) return fail_arg("bad step_round");
+    if (d.step_round != 0 && d.thresholds) return fail_arg("step_round is a per-tensor option");
+    if (check_pow2(d.mult)) return MCTQ_E_ARG;
+    if (d.entries != table_entries(d.clip_min, d.clip_max)) return fail_arg("entries does not match the clip range");
+  }
+  return 0;
+}
+
+uint32_t lut_tile_elems(int dtype) {      // 256 lanes x 4 vectors x N, N = 16 B / 4 B (the float32 output decides)
+  (void)dtype;
+  return kThreads * kBatchU * 4;
+}
+
+bool lut_batchable(const mctq_lut_item& d) {
+  const int64_t n = d.outer * d.channels * d.inner;
+  const uintptr_t xa = d.dtype == MCTQ_DT_F32 ? 15u : 7u;    // a lane-vector: 4 elements in, 4 float32 out
+  if (((uintptr_t)d.x & xa) || ((uintptr_t)d.y & 15u)) return false;
+  if (n >= (1ll << 31) - (int64_t)lut_tile_elems(d.dtype) || d.channels > 0x7fffffffLL || d.inner > 0x7fffffffLL) return false;
+  return !d.thresholds || d.outer * d.channels == 1 || d.inner >= 32 || n <= (1ll << 20);
+}
+
+int launch_lut_single(const mctq_lut_item& d, void* stream) {
+  const int64_t n = d.outer * d.channels * d.inner;
+  if (n == 0) return 0;
+  if (!d.thresholds)
+    return mctq_lutt_per_tensor(d.x, d.y, n, d.dtype, d.step_round, d.thr_div, d.thr_mul, d.table, d.entries, d.mult,
+                                d.clip_min, d.clip_max, stream);
+  return mctq_lutt_per_channel(d.x, d.y, d.outer, d.channels, d.inner, d.dtype, d.thresholds, d.eps, d.table, d.entries,
+                               d.mult, d.clip_min, d.clip_max, stream);
+}
+
+constexpr uint32_t kLutTableMagic = 0x4d43544cu;   // "MCTL"
+struct LutTableGroup { uint32_t dtype, items_off, map_off, n_items, grid, shift, lds_bytes, pad; int64_t out_bytes; };
+struct LutTableHeader {
+  uint32_t magic, version, total_bytes, n_groups, n_singles, singles_off, pad0, pad1;
+  LutTableGroup g[3];
+};
+static_assert(sizeof(LutTableHeader) == 32 + 3 * 40, "LUT table header layout");
+
+}  // namespace
+
+int64_t mctq_lutt_batch_pack(const mctq_lut_item* items, int32_t n_items, void* host_table, int64_t capacity) {
+  if (int rc = validate_lut_items(items, n_items)) return rc;
+  uint32_t count[3] = {0, 0, 0}, n_singles = 0, shift[3] = {0, 0, 0}, chunks[3] = {0, 0, 0};
+  for (int32_t k = 0; k < n_items; ++k) {
+    const mctq_lut_item& d = items[k];
+    if (d.outer * d.channels * d.inner == 0) continue;
+    if (lut_batchable(d)) ++count[d.dtype - MCTQ_DT_F32]; else ++n_singles;
+  }
+  for (int g = 0; g < 3; ++g)
+    if (count[g] > 0xffffu) return fail_arg("more than 65535 tensors of one storage type");
+  std::vector<uint32_t> tl((size_t)(n_items > 0 ? n_items : 1));
+  for (int g = 0; g < 3; ++g) {
+    if (!count[g]) continue;
+    const uint32_t tile_e = lut_tile_elems(MCTQ_DT_F32 + g);
+    int m = 0;
+    uint64_t total = 0;
+    for (int32_t k = 0; k < n_items; ++k) {
+      const mctq_lut_item& d = items[k];
+      const int64_t n = d.outer * d.channels * d.inner;
+      if (d.dtype != MCTQ_DT_F32 + g || n == 0 || !lut_batchable(d)) continue;
+      tl[m] = (uint32_t)((n + tile_e - 1) / tile_e);
+      total += tl[m++];
+    }
+    shift[g] = chunk_shift(tl.data(), m, kMaxChunksT);
+    for (int j = 0; j < m; ++j) chunks[g] += (tl[j] + (1u << shift[g]) - 1) >> shift[g];
+    if (total + ((uint64_t)m << shift[g]) > 0x7fffffffull) return fail_arg("too many tiles for one launch");
+  }
+  auto align16 = [](uint64_t v) { return (v + 15u) & ~(uint64_t)15u; };
+  uint64_t off = align16(sizeof(LutTableHeader));
+  uint64_t items_off[3], map_off[3];
+  for (int g = 0; g < 3; ++g) {
+    items_off[g] = off; off += (uint64_t)count[g] * sizeof(LutBatchItem);
+    map_off[g] = off; off = align16(off + (uint64_t)chunks[g] * 2u + 2u);
+  }
+  const uint64_t singles_off = off;
+  off = align16(off + (uint64_t)n_singles * sizeof(mctq_lut_item));
+  if (off > 0x7fffffffull) return fail_arg("table too large");
+  if (!host_table || capacity < (int64_t)off) return (int64_t)off;     // size query
+
+  uint8_t* base = static_cast<uint8_t*>(host_table);
+  memset(base, 0, (size_t)off);
+  LutTableHeader* h = reinterpret_cast<LutTableHeader*>(base);
+  h->magic = kLutTableMagic; h->version = MCTQ_ABI_VERSION; h->total_bytes = (uint32_t)off;
+  h->n_singles = n_singles; h->singles_off = (uint32_t)singles_off;
+  for (int g = 0; g < 3; ++g) {
+    if (!count[g]) continue;
+    LutTableGroup& tg = h->g[h->n_groups++];
+    tg.dtype = MCTQ_DT_F32 + g; tg.items_off = (uint32_t)items_off[g]; tg.map_off = (uint32_t)map_off[g];
+    tg.n_items = count[g]; tg.shift = shift[g]; tg.out_bytes = 0; tg.lds_bytes = 0;
+    const uint32_t tile_e = lut_tile_elems(tg.dtype);
+    LutBatchItem* bi = reinterpret_cast<LutBatchItem*>(base + items_off[g]);
+    uint16_t* map = reinterpret_cast<uint16_t*>(base + map_off[g]);
+    uint32_t chunk = 0;
+    int m = 0;
+    for (int32_t k = 0; k < n_items; ++k) {
+      const mctq_lut_item& d = items[k];
+      const int64_t n = d.outer * d.channels * d.inner;
+      if (d.dtype != (int32_t)tg.dtype || n == 0 || !lut_batchable(d)) continue;
+      const uint32_t t = (uint32_t)((n + tile_e - 1) / tile_e);
+      LutBatchItem& b = bi[m];
+      const bool one_row = !d.thresholds || d.outer * d.channels == 1;
+      b.b.x = d.x; b.b.y = d.y; b.b.scales = d.thresholds; b.b.zps = reinterpret_cast<const int32_t*>(d.table);
+      b.b.n = (uint32_t)n; b.b.inner = one_row ? (uint32_t)n : (uint32_t)d.inner; b.b.channels = one_row ? 1u : (uint32_t)d.channels;
+      b.b.tile_begin = chunk << tg.shift; b.b.tiles = t; b.b.reserved = 0; b.b.lo = 0.f; b.b.hi = 0.f;
+      b.mult = d.mult; b.cmin = d.clip_min; b.cmax = d.clip_max; b.eps = d.eps; b.thr_div = d.thr_div; b.thr_mul = d.thr_mul;
+      b.entries = d.entries; b.step_round = d.step_round;
+      const uint32_t c = (t + (1u << tg.shift) - 1) >> tg.shift;
+      for (uint32_t j = 0; j < c; ++j) map[chunk + j] = (uint16_t)m;
+      chunk += c;
+      tg.out_bytes += n * 4;
+      const uint32_t lds = (uint32_t)table_bytes(d.entries);
+      if (lds > tg.lds_bytes) tg.lds_bytes = lds;
+      ++m;
+    }
+    tg.grid = chunk << tg.shift;
+  }
+  mctq_lut_item* sg = reinterpret_cast<mctq_lut_item*>(base + singles_off);
+  uint32_t sidx = 0;
+  for (int32_t k = 0; k < n_items; ++k)
+    if (items[k].outer * items[k].channels * items[k].inner != 0 && !lut_batchable(items[k])) sg[sidx++] = items[k];
+  return (int64_t)off;
+}
+
+int mctq_lutt_batch_run(const void* host_table, const void* device_table, void* stream) {
+  if (!host_table) return fail_arg("host_table is NULL");
+  const uint8_t* base = static_cast<const uint8_t*>(host_table);
+  const LutTableHeader* h = reinterpret_cast<const LutTableHeader*>(base);
+  if (h->magic != kLutTableMagic || h->version != (uint32_t)MCTQ_ABI_VERSION || h->n_groups > 3)
+    return fail_arg("not a table packed by this library version (mctq_lutt_batch_pack)");
+  if (h->n_groups && (!device_table || ((uintptr_t)device_table & 15u))) return fail_arg("device_table is NULL or not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t* dev = static_cast<const uint8_t*>(device_table);
+  for (uint32_t g = 0; g < h->n_groups; ++g) {
+    const LutTableGroup& tg = h->g[g];
+    LutTableSrc src;
+    src.it = reinterpret_cast<const LutBatchItem*>(dev + tg.items_off);
+    src.map = reinterpret_cast<const uint32_t*>(dev + tg.map_off);
+    src.shift = tg.shift;
+    int rc;
+    if (tg.dtype == MCTQ_DT_F32) rc = launch_lut_batch<float>(src, tg.grid, tg.lds_bytes, tg.out_bytes, st);
+    else if (tg.dtype == MCTQ_DT_F16) rc = launch_lut_batch<_Float16>(src, tg.grid, tg.lds_bytes, tg.out_bytes, st);
+    else rc = launch_lut_batch<__bf16>(src, tg.grid, tg.lds_bytes, tg.out_bytes, st);
+    if (rc) return rc;
+  }
+  const mctq_lut_item* sg = reinterpret_cast<const mctq_lut_item*>(base + h->singles_off);
+  for (uint32_t k = 0; k < h->n_singles; ++k)
+    if (int rc = launch_lut_single(sg[k], stream)) return rc;
   return 0;
 }
 

@@ -39,6 +39,17 @@ class FqItem(ctypes.Structure):
                 ("dtype", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
+class LutItem(ctypes.Structure):
+    """mctq_lut_item of include/mctq_hip.h (one tensor of a batched LUT launch)."""
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("outer", ctypes.c_int64), ("channels", ctypes.c_int64), ("inner", ctypes.c_int64),
+                ("thresholds", ctypes.c_void_p), ("table", ctypes.c_void_p),
+                ("entries", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("thr_div", ctypes.c_float), ("thr_mul", ctypes.c_float),
+                ("mult", ctypes.c_float), ("clip_min", ctypes.c_float), ("clip_max", ctypes.c_float),
+                ("dtype", ctypes.c_int32), ("step_round", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/mctq_hip.h
 SIGNATURES = {
     "mctq_abi_version": (ctypes.c_int, []),
@@ -66,6 +77,8 @@ SIGNATURES = {
     "mctq_fq_batched": (ctypes.c_int, [ctypes.POINTER(FqItem), ctypes.c_int32, ctypes.c_void_p]),
     "mctq_fq_batch_pack": (ctypes.c_int64, [ctypes.POINTER(FqItem), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64]),
     "mctq_fq_batch_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "mctq_lutt_batch_pack": (ctypes.c_int64, [ctypes.POINTER(LutItem), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64]),
+    "mctq_lutt_batch_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mctq_lut_per_tensor_f64": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_float,
                                                _c_f32p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_void_p]),

@@ -388,3 +388,82 @@ def test_fuzz_batched_launch_random_shapes_axes_dtypes_against_oracle(seed):
         for y, want, c in zip(outs, wants, cases):
             got = y.float().cpu().numpy()
             assert bits_equal(got, want), f"table {c[0].shape} {c[1]} axis={c[4]}: {first_mismatch(got, want, c[0])}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the same grid for LUT quantizers with a decision table (mctq_lutt_batch_pack / mctq_lutt_batch_run)
+# ---------------------------------------------------------------------------------------------------------------
+
+LUT16 = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+
+
+@pytest.mark.gpu
+def test_batched_lut_launch_raw_abi_against_oracle_and_single_launches():
+    """60 LUT items (per channel along axis 0 / a middle axis / the last axis, per tensor, float32 / float16 / bfloat16
+    storage, two codebooks, rows shorter / longer than a tile, ragged tails) in one table launch per storage type:
+    equal to the oracle's literal op chain and to the single-tensor entry points, nothing written outside a tensor."""
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd.hip import native, ops
+    lib = native.load()
+    rng = np.random.default_rng(77)
+    books = [(LUT16, 8, True), ([0.0, 9.0, 40.0, 100.0, 180.0, 255.0], 8, False)]
+    tables = []
+    for lut, bits, signed in books:
+        mult, cmin, cmax = float(2 ** (bits - int(signed))), (float(-2 ** (bits - 1)) if signed else 0.0), float(2 ** (bits - 1) - 1 if signed else 2 ** bits - 1)
+        tables.append((ops.make_lut_table(np.float32(lut), mult, cmin, cmax, "cuda"), mult, cmin, cmax))
+    shapes = [((96, 2048), 0), ((33, 4096), 0), ((17, 4608), 0), ((5, 11008), 0), ((64, 64, 3, 3), 0), ((2, 48, 100), 1),
+              ((12, 1031), 0), ((4099,), None), ((70000,), None), ((16, 37), 1), ((10, 6, 5), 2), ((512, 1, 3, 3), 0)]
+    dtc = {torch.float32: native.DT_F32, torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}
+    n_items = 60
+    arr = (native.LutItem * n_items)()
+    keep, cases = [], []
+    GUARD = 64
+    for k in range(n_items):
+        shape, axis = shapes[k % len(shapes)]
+        b = k % 2
+        lut, bits, signed = books[b]
+        table, mult, cmin, cmax = tables[b]
+        dt = (torch.float32, torch.float16, torch.bfloat16)[(k // 4) % 3] if axis is not None else torch.float32
+        x = (rng.standard_normal(shape) * 1.5).astype(np.float32)
+        xd = torch.from_numpy(x).to(dt).cuda()
+        n = xd.numel()
+        frame = torch.full((n + 2 * GUARD,), 768.0, dtype=torch.float32, device="cuda")
+        y = frame[GUARD:GUARD + n]
+        it = arr[k]
+        it.x, it.y, it.table, it.entries = xd.data_ptr(), y.data_ptr(), table.data_ptr(), table.shape[0] - 1
+        it.mult, it.clip_min, it.clip_max, it.dtype, it.step_round = mult, cmin, cmax, dtc[dt], 0
+        if axis is None:
+            thr = np.float32(rng.uniform(1.0, 3.0))
+            it.outer, it.channels, it.inner, it.thresholds = 1, 1, n, None
+            it.eps, it.thr_div, it.thr_mul = 0.0, float(np.float32(thr + np.float32(1e-8))), float(thr)
+            thr_np = np.float32([thr])
+            keep.append((xd, frame, None))
+        else:
+            c = shape[axis]
+            thr_np = rng.uniform(0.8, 3.0, size=c).astype(np.float32)
+            td = torch.from_numpy(thr_np).cuda()
+            it.outer, it.channels, it.inner = int(np.prod(shape[:axis])), c, int(np.prod(shape[axis + 1:]))
+            it.thresholds, it.eps, it.thr_div, it.thr_mul = td.data_ptr(), 1e-8, 0.0, 0.0
+            keep.append((xd, frame, td))
+        cases.append((xd.float().cpu().numpy(), lut, thr_np, signed, bits, axis, dt))
+    need = lib.mctq_lutt_batch_pack(arr, n_items, None, 0)
+    host = np.zeros(need, np.uint8)
+    assert lib.mctq_lutt_batch_pack(arr, n_items, host.ctypes.data, need) == need
+    dev = torch.from_numpy(host).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mctq_lutt_batch_run(host.ctypes.data, dev.data_ptr(), st) == 0, lib.mctq_last_error()
+    torch.cuda.synchronize()
+    assert "batched_lut_kernel<table>" in native.last_launch()
+    for k, ((xw, lut, thr_np, signed, bits, axis, dt), (xd, frame, td)) in enumerate(zip(cases, keep)):
+        n = xd.numel()
+        got = frame[GUARD:GUARD + n].cpu().numpy().reshape(xw.shape)
+        if axis is None:
+            want = O.lut_quantize(xw, lut, thr_np, signed, bits, 1e-8)
+        else:
+            want = O.lut_quantize(xw, lut, thr_np, signed, bits, 1e-8, per_channel=True, channel_axis=axis)
+        assert bits_equal(got, np.asarray(want, np.float32)), f"#{k} {xw.shape} {dt} axis={axis}: {first_mismatch(got, want, xw)}"
+        edge = torch.cat([frame[:GUARD], frame[GUARD + n:]])
+        assert bool((edge == 768.0).all()), f"#{k} {xw.shape}: wrote outside its tensor"
+    # errors are reported before anything runs
+    arr[0].entries = 5
+    assert lib.mctq_lutt_batch_pack(arr, n_items, None, 0) == native.MCTQ_E_ARG and b"entries" in lib.mctq_last_error()
