@@ -129,11 +129,18 @@ def batched_plans(quantizer, x0, tensors: int, ring: int):
     plans, outs = [], []
     for _ in range(ring):
         xs = [x0.clone() for _ in range(tensors)]
-        ys = [torch.empty_like(x0) for _ in range(tensors)]
-        items = []
-        for x, y in zip(xs, ys):
-            xi, scales, zps, axis, qmin, qmax = quantizer.batch_item(x)
-            items.append((xi, y, scales, zps, axis, qmin, qmax))
+        items, ys = [], []
+        for x in xs:
+            if hasattr(quantizer, "batch_item"):                      # affine weights quantizers
+                xi, scales, zps, axis, qmin, qmax = quantizer.batch_item(x)
+                y = torch.empty_like(x0)
+                items.append((xi, y, scales, zps, axis, qmin, qmax))
+            else:                                                     # LUT quantizers with a decision table: float32 out
+                item = quantizer.batch_item_lut(x)
+                assert item is not None, "this LUT configuration has no decision table: no batched launch"
+                y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                items.append(item[:2] + (y,) + item[3:])
+            ys.append(y)
         plans.append(fast.BatchPlan(items))
         outs.append(ys)
     return plans, outs
@@ -213,8 +220,8 @@ def main():
         def step(i):                             # one LAUNCH: per_launch batches
             act_streams[i % ring].run()
     elif args.batched:
-        if not hasattr(quantizer, "batch_item"):
-            raise SystemExit(f"--batched: {wl.quantizer} has no batched launch (affine weights quantizers only)")
+        if not hasattr(quantizer, "batch_item") and not hasattr(quantizer, "batch_item_lut"):
+            raise SystemExit(f"--batched: {wl.quantizer} has no batched launch")
         plans, plan_outs = batched_plans(quantizer, x0, tensors, ring)
         xs, ys = None, None
 

@@ -488,9 +488,30 @@ struct BatchPlan {
   std::vector<BatchWatch>* watch;
   std::vector<uint8_t>* host_table;
   at::Tensor* dev_table;
+  // LUT items (decision-table quantizers): ("lut", x, y, thresholds | None, table, axis | None, eps, thr_div, thr_mul,
+  // mult, clip_min, clip_max, step_round[, watch]); y float32, contiguous like x
+  std::vector<mctq_lut_item>* lut_items;
+  std::vector<PyObject*>* lut_refs;      // 4 per item: x, y, thresholds (or Py_None), table
+  std::vector<std::vector<int64_t>>* lut_sizes;
+  std::vector<int64_t>* lut_axes;
+  std::vector<uint8_t>* lut_host_table;
+  at::Tensor* lut_dev_table;
   bool uploaded;
   c10::DeviceIndex device;
 };
+
+bool batchplan_upload_lut(BatchPlan* p) {
+  const int64_t need = mctq_lutt_batch_pack(p->lut_items->data(), (int32_t)p->lut_items->size(), nullptr, 0);
+  if (need < 0) { raise_rc((int)need, "mctq_lutt_batch_pack"); return false; }
+  p->lut_host_table->resize((size_t)need);
+  const int64_t got = mctq_lutt_batch_pack(p->lut_items->data(), (int32_t)p->lut_items->size(), p->lut_host_table->data(), need);
+  if (got != need) { raise_rc((int)got, "mctq_lutt_batch_pack"); return false; }
+  if (!p->lut_dev_table->defined() || p->lut_dev_table->numel() < need)
+    *p->lut_dev_table = at::Tensor(at::detail::empty_cuda({need}, c10::ScalarType::Byte, c10::Device(c10::kCUDA, p->device), std::nullopt));
+  const auto stream = c10::hip::getCurrentHIPStream(p->device);
+  c10::hip::memcpy_and_sync(p->lut_dev_table->mutable_data_ptr(), p->lut_host_table->data(), need, hipMemcpyHostToDevice, stream.stream());
+  return true;
+}
 
 bool batchplan_upload(BatchPlan* p) {
   const int64_t need = mctq_fq_batch_pack(p->items->data(), (int32_t)p->items->size(), nullptr, 0);
@@ -502,7 +523,6 @@ bool batchplan_upload(BatchPlan* p) {
     *p->dev_table = at::Tensor(at::detail::empty_cuda({need}, c10::ScalarType::Byte, c10::Device(c10::kCUDA, p->device), std::nullopt));
   const auto stream = c10::hip::getCurrentHIPStream(p->device);
   c10::hip::memcpy_and_sync(p->dev_table->mutable_data_ptr(), p->host_table->data(), need, hipMemcpyHostToDevice, stream.stream());
-  p->uploaded = true;
   return true;
 }
 
@@ -557,12 +577,48 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
       dirty = true;
     }
   }
-  if (n > 0) {
+  const size_t nl = p->lut_items->size();
+  bool lut_dirty = !p->uploaded;
+  for (size_t i = 0; i < nl; ++i) {
+    const at::Tensor& x = THPVariable_Unpack((*p->lut_refs)[4 * i]);
+    const at::Tensor& y = THPVariable_Unpack((*p->lut_refs)[4 * i + 1]);
+    const at::Tensor& tb = THPVariable_Unpack((*p->lut_refs)[4 * i + 3]);
+    mctq_lut_item& d = (*p->lut_items)[i];
+    if (x.sizes() != c10::IntArrayRef((*p->lut_sizes)[i]) || y.sizes() != x.sizes() || !x.is_cuda() || !y.is_cuda() ||
+        x.device().index() != p->device || y.device().index() != p->device || !x.is_contiguous() || !y.is_contiguous() ||
+        dtype_code(x.scalar_type()) != d.dtype || y.scalar_type() != c10::ScalarType::Float ||
+        tb.scalar_type() != c10::ScalarType::Float || !tb.is_contiguous() || tb.device() != x.device() ||
+        tb.numel() != 2 * ((int64_t)d.entries + 1))
+      return not_implemented();
+    const void* tp = nullptr;
+    if ((*p->lut_refs)[4 * i + 2] != Py_None) {
+      const at::Tensor& t = THPVariable_Unpack((*p->lut_refs)[4 * i + 2]);
+      if (t.scalar_type() != c10::ScalarType::Float || !t.is_contiguous() || t.device() != x.device() || t.numel() != d.channels)
+        return not_implemented();
+      tp = t.const_data_ptr();
+    }
+    const void* xp = x.const_data_ptr();
+    void* yp = y.mutable_data_ptr();
+    const void* bp = tb.const_data_ptr();
+    if (xp != d.x || yp != (void*)d.y || tp != (const void*)d.thresholds || bp != (const void*)d.table) {
+      d.x = xp; d.y = (float*)yp; d.thresholds = (const float*)tp; d.table = (const float*)bp;
+      lut_dirty = true;
+    }
+  }
+  if (n > 0 || nl > 0) {
     DeviceScope scope(p->device);
-    if (dirty && !batchplan_upload(p)) return nullptr;
-    const int rc = mctq_fq_batch_run(p->host_table->data(), p->dev_table->const_data_ptr(),
-                                     (void*)c10::hip::getCurrentHIPStream(p->device).stream());
-    if (rc) return raise_rc(rc, "mctq_fq_batch_run");
+    void* stream = (void*)c10::hip::getCurrentHIPStream(p->device).stream();
+    if (n > 0) {
+      if (dirty && !batchplan_upload(p)) return nullptr;
+      const int rc = mctq_fq_batch_run(p->host_table->data(), p->dev_table->const_data_ptr(), stream);
+      if (rc) return raise_rc(rc, "mctq_fq_batch_run");
+    }
+    if (nl > 0) {
+      if (lut_dirty && !batchplan_upload_lut(p)) return nullptr;
+      const int rc = mctq_lutt_batch_run(p->lut_host_table->data(), p->lut_dev_table->const_data_ptr(), stream);
+      if (rc) return raise_rc(rc, "mctq_lutt_batch_run");
+    }
+    p->uploaded = true;
   }
   Py_RETURN_NONE;
   END_HANDLE_TH_ERRORS
@@ -572,7 +628,9 @@ void batchplan_dealloc(PyObject* self) {
   BatchPlan* p = (BatchPlan*)self;
   if (p->refs) for (PyObject* o : *p->refs) Py_XDECREF(o);
   if (p->watch) for (BatchWatch& w : *p->watch) { Py_XDECREF(w.dict); Py_XDECREF(w.name); Py_XDECREF(w.obj); }
+  if (p->lut_refs) for (PyObject* o : *p->lut_refs) Py_XDECREF(o);
   delete p->items; delete p->refs; delete p->sizes; delete p->axes; delete p->watch; delete p->host_table; delete p->dev_table;
+  delete p->lut_items; delete p->lut_refs; delete p->lut_sizes; delete p->lut_axes; delete p->lut_host_table; delete p->lut_dev_table;
   Py_TYPE(self)->tp_free(self);
 }
 
@@ -607,12 +665,61 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   p->items = new std::vector<mctq_fq_item>(); p->refs = new std::vector<PyObject*>();
   p->sizes = new std::vector<std::vector<int64_t>>(); p->axes = new std::vector<int64_t>();
   p->watch = new std::vector<BatchWatch>(); p->host_table = new std::vector<uint8_t>(); p->dev_table = new at::Tensor();
+  p->lut_items = new std::vector<mctq_lut_item>(); p->lut_refs = new std::vector<PyObject*>();
+  p->lut_sizes = new std::vector<std::vector<int64_t>>(); p->lut_axes = new std::vector<int64_t>();
+  p->lut_host_table = new std::vector<uint8_t>(); p->lut_dev_table = new at::Tensor();
   p->uploaded = false;
   p->device = -1;
   const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
   const char* err = nullptr;
   for (Py_ssize_t i = 0; i < n && !err; ++i) {
     PyObject* it = PySequence_Fast_GET_ITEM(seq, i);
+    if (PyTuple_Check(it) && PyTuple_GET_SIZE(it) >= 13 && PyUnicode_Check(PyTuple_GET_ITEM(it, 0))) {
+      // ---- a LUT item ----
+      if (PyTuple_GET_SIZE(it) > 14 || PyUnicode_CompareWithASCIIString(PyTuple_GET_ITEM(it, 0), "lut") != 0) {
+        err = "LUT item: ('lut', x, y, thresholds, table, axis, eps, thr_div, thr_mul, mult, clip_min, clip_max, step_round[, watch])"; break;
+      }
+      int dt, dty;
+      const at::Tensor* xp = eligible(PyTuple_GET_ITEM(it, 1), &dt);
+      const at::Tensor* yp = eligible(PyTuple_GET_ITEM(it, 2), &dty);
+      if (!xp || !yp || dt == MCTQ_DT_F64 || yp->scalar_type() != c10::ScalarType::Float || !xp->is_contiguous() ||
+          !yp->is_contiguous() || xp->sizes() != yp->sizes() || xp->device() != yp->device()) {
+        err = "LUT item: x a contiguous float32 / float16 / bfloat16 HIP tensor, y float32 of the same shape"; break;
+      }
+      double v[6];
+      bool okv = true;
+      for (int k = 0; k < 6 && okv; ++k) okv = as_double(PyTuple_GET_ITEM(it, 6 + k), &v[k]);
+      int64_t sr, axis = -1;
+      PyObject* axis_o = PyTuple_GET_ITEM(it, 5);
+      if (!okv || !as_i64(PyTuple_GET_ITEM(it, 12), &sr) || (axis_o != Py_None && !as_i64(axis_o, &axis))) {
+        Py_DECREF(seq); Py_DECREF(p); return nullptr;
+      }
+      if (axis_o != Py_None && (axis < 0 || axis >= xp->dim())) { err = "axis out of range"; break; }
+      if (p->device < 0) p->device = xp->device().index();
+      if (xp->device().index() != p->device) { err = "all tensors of one plan must be on the same device"; break; }
+      const at::Tensor* tb = param_tensor(PyTuple_GET_ITEM(it, 4), *xp, c10::ScalarType::Float, -1);
+      if (!tb || tb->numel() < 4 || (tb->numel() & 1)) { err = "LUT item: table must be the float32 decision table on x's device"; break; }
+      const at::Tensor* th = nullptr;
+      mctq_lut_item d;
+      d.x = xp->const_data_ptr(); d.y = yp->mutable_data_ptr<float>();
+      if (axis_o == Py_None) { d.outer = 1; d.channels = 1; d.inner = xp->numel(); }
+      else channel_view(*xp, axis, &d.outer, &d.channels, &d.inner);
+      if (PyTuple_GET_ITEM(it, 3) != Py_None) {
+        th = param_tensor(PyTuple_GET_ITEM(it, 3), *xp, c10::ScalarType::Float, axis_o == Py_None ? 1 : xp->size(axis));
+        if (!th) { err = "LUT item: thresholds must be a contiguous float32 tensor on x's device with one entry per channel"; break; }
+      } else if (axis_o != Py_None) { err = "LUT item: a per-channel item needs thresholds"; break; }
+      d.thresholds = th ? th->const_data_ptr<float>() : nullptr;
+      d.table = tb->const_data_ptr<float>();
+      d.entries = (int32_t)(tb->numel() / 2 - 1);
+      d.eps = (float)v[0]; d.thr_div = (float)v[1]; d.thr_mul = (float)v[2]; d.mult = (float)v[3]; d.clip_min = (float)v[4]; d.clip_max = (float)v[5];
+      d.dtype = dt; d.step_round = (int32_t)sr;
+      p->lut_items->push_back(d);
+      p->lut_sizes->push_back(xp->sizes().vec());
+      p->lut_axes->push_back(axis_o == Py_None ? -1 : axis);
+      for (int k = 1; k <= 4; ++k) { PyObject* o = PyTuple_GET_ITEM(it, k); Py_INCREF(o); p->lut_refs->push_back(o); }
+      if (PyTuple_GET_SIZE(it) == 14) err = batchplan_add_watch(p, PyTuple_GET_ITEM(it, 13));
+      continue;
+    }
     if (!PyTuple_Check(it) || (PyTuple_GET_SIZE(it) != 7 && PyTuple_GET_SIZE(it) != 8)) {
       err = "item: (x, y, scales, zero_points, axis, quant_min, quant_max[, watch])"; break;
     }

@@ -24,9 +24,10 @@ counter, closed again by a forward hook): calling a sub-module directly, past th
 own quantizer call -- in both modes.  54 ResNet-50 weights: 70 us -> host ~4 us + ~35 us
 of GPU time (profiles/r02/requant_model_weights_batched.log).
 
-Only the affine weights quantizers (symmetric / power-of-two / uniform, per tensor or per channel) take part;
-LUT quantizers, quantizers with the reuse cache enabled, trainable quantizers and wrappers of positional
-(functional) weights keep calling their quantizer as before.
+The affine weights quantizers (symmetric / power-of-two / uniform, per tensor or per channel) take part in both modes;
+with ``reuse_buffers=True`` the LUT weights quantizers whose codebook has a decision table (every legal default
+configuration) join through a second table launch (mctq_lutt_batch_run).  Quantizers with the reuse cache enabled,
+trainable quantizers and wrappers of positional (functional) weights keep calling their quantizer as before.
 """
 from __future__ import annotations
 
@@ -60,11 +61,17 @@ class BatchedWeightQuantization:
         state["_cell"] = [0, False]
         return state
 
-    def _entries(self) -> List[Tuple[PytorchQuantizationWrapper, str, torch.Tensor, object]]:
+    def _entries(self, with_lut: bool = False) -> List[Tuple[PytorchQuantizationWrapper, str, torch.Tensor, object]]:
         out = []
         for m in self.model.modules():
             if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization and m.is_str_attr:
                 for name, weight, quantizer in m.get_weights_vars():
+                    if (with_lut and hasattr(quantizer, "batch_item_lut") and not quantizer.enable_reuse
+                            and not quantizer.__dict__.get("_versioned_reuse")
+                            and not (quantizer._use_custom_impl and torch.jit.is_tracing())
+                            and isinstance(weight, torch.Tensor) and quantizer.batch_item_lut(weight.detach()) is not None):
+                        out.append((m, name, weight, quantizer))      # LUT weights: pre-packed plan only
+                        continue
                     if (hasattr(quantizer, "batch_item") and not quantizer.enable_reuse
                             and int(getattr(quantizer, "num_bits", 0)) <= 24
                             and not quantizer.__dict__.get("_versioned_reuse")
@@ -89,6 +96,17 @@ class BatchedWeightQuantization:
         items, per_wrapper = [], {}
         for wrapper, name, weight, quantizer in entries:
             weight.requires_grad = False            # the side effect of the reference's weights quantizers
+            if not hasattr(quantizer, "batch_item"):                 # a LUT weights quantizer with a decision table
+                item = quantizer.batch_item_lut(weight)
+                if item is None:
+                    return None
+                y = torch.empty(item[1].shape, dtype=torch.float32, device=item[1].device)
+                d = quantizer.__dict__
+                watch = (d, (("_stale", d.get("_stale"), -1), ("_lut_table_torch", d.get("_lut_table_torch"), -1),
+                             ("_threshold_torch", d.get("_threshold_torch"), d["_threshold_torch"]._version)))
+                items.append(item[:2] + (y,) + item[3:] + (watch,))
+                per_wrapper.setdefault(wrapper, {})[name] = y
+                continue
             x, scales, zps, axis, qmin, qmax = quantizer.batch_item(weight)
             if quantizer.__dict__.get("_zp_out_of_range"):
                 return None                         # the per-layer call raises ATen's message
@@ -128,7 +146,7 @@ class BatchedWeightQuantization:
             for _ in range(2):                                       # a stale plan is rebuilt once, then given up
                 plan = self._plan
                 if plan is None:
-                    entries = self._entries()
+                    entries = self._entries(with_lut=True)
                     plan = self._plan = self._build_plan(entries) if entries else None
                 if plan is None:
                     break

@@ -81,10 +81,11 @@ class CapturedStream:
     ``stream(batches)``, which copies them in), ``stream.run()`` quantizes all of them, and ``stream.outputs[i]`` holds
     batch i's result until the next replay.  Two ways to run the ``depth`` calls, same bits as the eager calls either way:
 
-      fused   (affine activation quantizers: symmetric / power-of-two / uniform)  ONE launch of the batched kernel over
-              all ``depth`` batches (``BatchPlan`` -> mctq_fq_batch_run, per-tensor items): no hipGraph at all, one host
-              call and one ramp / drain per ``depth`` batches -- config 3 at N = 1: 5.2 -> ~0.5 us per batch.
-      graph   (anything else: LUT quantizers, arbitrary callables)  one hipGraph of ``depth`` kernel nodes on one branch.
+      fused   (affine activation quantizers: symmetric / power-of-two / uniform; LUT quantizers whose codebook has a
+              decision table)  ONE launch of the batched kernel over all ``depth`` batches (``BatchPlan`` ->
+              mctq_fq_batch_run / mctq_lutt_batch_run, per-tensor items): no hipGraph at all, one host call and one
+              ramp / drain per ``depth`` batches -- config 3 at N = 1: 5.2 -> ~0.3 us per batch.
+      graph   (anything else: wide codebooks, arbitrary callables)  one hipGraph of ``depth`` kernel nodes on one branch.
               Measured (profiles/r03/stream_probe.log): a replay costs ~12 us of fixed overhead, so a ONE-node graph is
               2-3x SLOWER than the eager call (14.5 vs 5.2 us) and pays only from depth >= 8 (2.2 us per batch at depth
               16); parallel branches (``lanes`` > 1) made small batches slower, so the default is 1.
@@ -106,18 +107,30 @@ class CapturedStream:
         self.graph, self._plan = None, None
         quantizer = getattr(fn, "activation_holder_quantizer", fn)
         bypass = bool(getattr(fn, "quantization_bypass", False))
-        fusable = (mode != "graph" and not bypass and hasattr(quantizer, "batch_item") and hasattr(quantizer, "_plan_args")
-                   and ops._fast_mod() is not None and ops._is_dense(example))
+        affine = hasattr(quantizer, "batch_item") and hasattr(quantizer, "_plan_args")
+        lut = (not affine and hasattr(quantizer, "batch_item_lut") and example.is_contiguous()
+               and quantizer.batch_item_lut(self.inputs[0]) is not None)
+        fusable = (mode != "graph" and not bypass and (affine or lut) and ops._fast_mod() is not None
+                   and ops._is_dense(example))
         if mode == "fused" and not fusable:
-            raise TypeError("fused streams need an affine activation quantizer (or its holder) and the compiled binding")
+            raise TypeError("fused streams need an affine or decision-table LUT activation quantizer (or its holder) and "
+                            "the compiled binding")
         if fusable:
             self.mode = "fused"
-            self.outputs = [torch.empty_like(x) for x in self.inputs]
             items = []
-            for x, y in zip(self.inputs, self.outputs):
-                xi, scale, zp, axis, qmin, qmax = quantizer.batch_item(x)
-                watch = (quantizer.__dict__, tuple((k, quantizer.__dict__[k], -1) for k in quantizer._plan_attrs))
-                items.append((xi, y, scale, zp, axis, qmin, qmax, watch))
+            if affine:
+                self.outputs = [torch.empty_like(x) for x in self.inputs]
+                for x, y in zip(self.inputs, self.outputs):
+                    xi, scale, zp, axis, qmin, qmax = quantizer.batch_item(x)
+                    watch = (quantizer.__dict__, tuple((k, quantizer.__dict__[k], -1) for k in quantizer._plan_attrs))
+                    items.append((xi, y, scale, zp, axis, qmin, qmax, watch))
+            else:                                           # LUT: float32 results whatever the input's type
+                self.outputs = [torch.empty(x.shape, dtype=torch.float32, device=x.device) for x in self.inputs]
+                d = quantizer.__dict__
+                watch = (d, (("_stale", d.get("_stale"), -1), ("_lut_table_torch", d.get("_lut_table_torch"), -1)))
+                for x, y in zip(self.inputs, self.outputs):
+                    item = quantizer.batch_item_lut(x)
+                    items.append(item[:2] + (y,) + item[3:] + (watch,))
             self._plan = ops._fast_mod().BatchPlan(items)
             self._plan()
             return

@@ -133,6 +133,28 @@ class WeightsLUTSymmetricInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
 
     _export_function = "WeightsLUTSymmetricF"
 
+    def batch_item_lut(self, inputs: torch.Tensor):
+        """This quantizer's call on ``inputs`` as one entry of a batched LUT launch (``BatchPlan`` item
+        ("lut", x, y, thresholds | None, table, axis | None, eps, thr_div, thr_mul, mult, clip_min, clip_max, step_round) with
+        y left as None for the caller to fill in), or None when the call cannot ride a batched launch (no decision
+        table for this codebook, float64 or non-contiguous tensor, rank mismatch)."""
+        if self.__dict__.get("_stale"):
+            self._resync()
+        table = self._lut_table_torch
+        if (table is None or type(inputs) not in (torch.Tensor, torch.nn.Parameter) or not inputs.is_cuda
+                or inputs.dtype not in (torch.float32, torch.float16, torch.bfloat16) or not inputs.is_contiguous()):
+            return None
+        mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, True)
+        if self.per_channel:
+            if self.input_rank != inputs.dim():
+                return None
+            thr = self._threshold_torch
+            if thr.dim() != 1 or not thr.is_contiguous():
+                return None
+            return ("lut", inputs, None, thr, table, self.channel_axis % inputs.dim(), float(self.eps), 0.0, 0.0,
+                    mult, cmin, cmax, 0)
+        return ("lut", inputs, None, None, table, None, 0.0, self._thr_div0, self._thr_mul0, mult, cmin, cmax, 0)
+
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         if self._cached(inputs):
             return self.resue_outputs
@@ -229,6 +251,29 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         self.__dict__["_plan"] = plan
         self.__dict__["_stale"] = False
         self.__dict__["_launch_ready"] = True
+
+    def batch_item_lut(self, inputs: torch.Tensor):
+        """As ``WeightsLUTSymmetricInferableQuantizer.batch_item_lut`` for one activation batch (per tensor): the divisor,
+        the per-step roundings and the clip range are those of the tensor's own type, as in ``__call__``."""
+        if self.__dict__.get("_stale"):
+            self._resync()
+        if (type(inputs) not in (torch.Tensor, torch.nn.Parameter) or not inputs.is_cuda or not inputs.is_contiguous()
+                or inputs.dtype not in (torch.float32, torch.float16, torch.bfloat16)):
+            return None
+        mult, cmin, cmax = lut_domain(self.lut_values_bitwidth, self.signed)
+        dt = inputs.dtype
+        table = self._lut_table_torch
+        step = {torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}.get(dt, 0)
+        if step:
+            bounds = self.__dict__.get("_clip_by_dtype", {}).get(dt) or _bounds_in(dt, cmin, cmax)
+            if isinstance(bounds, str):
+                return None                                   # torch.clip raises for this type: let __call__ raise it
+            if bounds != (cmin, cmax):
+                cmin, cmax = bounds
+                table = ops._op_table(self.lut_values, mult, cmin, cmax)[0]
+        if table is None:
+            return None
+        return ("lut", inputs, None, None, table, None, 0.0, self._thr_div_by_dtype[dt], self._thr_mul0, mult, cmin, cmax, step)
 
     def __call__(self, inputs: torch.Tensor):
         if self.__dict__.get("_stale"):

@@ -467,3 +467,43 @@ def test_batched_lut_launch_raw_abi_against_oracle_and_single_launches():
     # errors are reported before anything runs
     arr[0].entries = 5
     assert lib.mctq_lutt_batch_pack(arr, n_items, None, 0) == native.MCTQ_E_ARG and b"entries" in lib.mctq_last_error()
+
+
+@pytest.mark.gpu
+def test_model_with_lut_and_affine_weights_batches_both_in_plan_mode():
+    """reuse_buffers=True: affine AND decision-table LUT weights quantizers ride the pre-packed plan (two table launches),
+    results equal the per-layer calls; editing a LUT quantizer's attribute (its `_stale` flag) rebuilds the plan."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+    if native.fast() is None:
+        pytest.skip("needs the compiled binding (BatchPlan)")
+    Q = mq.pytorch_quantizers
+
+    def build():
+        torch.manual_seed(8)
+        mods = []
+        for i, (fin, fout) in enumerate(((64, 96), (96, 4096), (4096, 48))):
+            lin = torch.nn.Linear(fin, fout)
+            thr = [float(v) + 1e-3 for v in lin.weight.detach().abs().amax(dim=1)]
+            wq = Q.WeightsLUTSymmetricInferableQuantizer(4, list(LUT16), thr, True, 0, 2) if i != 1 else \
+                Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)
+            mods.append(mq.PytorchQuantizationWrapper(lin, {"weight": wq, "bias": Q.WeightsLUTPOTInferableQuantizer(
+                3, [-100.0, -20.0, 0.0, 30.0, 127.0], [1.0], False)}))
+        return torch.nn.Sequential(*mods).cuda()
+
+    ref, model = build(), build()
+    x = torch.randn(5, 64, device="cuda")
+    handle = batch_weight_quantization(model, reuse_buffers=True)
+    assert torch.equal(model(x), ref(x)) and handle._plan is not None and handle._plan[1] == 6
+    assert "batched_lut_kernel<table>" in native.last_launch() or "kernel" in native.last_launch()
+    with torch.no_grad():
+        for m, r in zip(model, ref):
+            m.weight.mul_(0.8); r.weight.mul_(0.8)
+    assert torch.equal(model(x), ref(x))
+    plan = handle._plan[0]
+    q, qr = model[0].weights_quantizers["weight"], ref[0].weights_quantizers["weight"]
+    q.eps = 1e-3; qr.eps = 1e-3                                       # the reference reads its attributes on every call
+    assert torch.equal(model(x), ref(x)) and handle._plan[0] is not plan
+    handle.remove()
+    assert torch.equal(model(x), ref(x))
