@@ -37,7 +37,10 @@ namespace mctq {
 constexpr int kMaxBatch = 48;            // descriptors per kernel-argument launch
 constexpr int kMaxChunksK = 960;         // chunk-map bytes in the kernel arguments
 constexpr uint32_t kMaxChunksT = 16384;  // chunk-map entries of a packed table (2 bytes each)
-constexpr int kBatchU = 4;
+#ifndef MCTQ_BATCH_U
+#define MCTQ_BATCH_U 4                   // lane-vectors per lane and tile; 2 / 8 are timing experiments (tools/batched_unroll_probe.py)
+#endif
+constexpr int kBatchU = MCTQ_BATCH_U;
 
 struct __attribute__((aligned(16))) BatchItem {   // 64 bytes
   const void* x;

@@ -80,9 +80,10 @@ def run(name, shapes, reps=200):
     for k, (v, h) in res.items():
         print(f"    {k:48s} {v:9.1f} us per model (host {h:7.1f})   {nbytes / v / 1e3:7.0f} GB/s algorithmic")
 
-run("ResNet-50 weights", resnet50_shapes())
-run("MobileNet-like pointwise/depthwise stack", [(c, 1, 3, 3) for c in (32, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024)] +
-    [(co, ci, 1, 1) for ci, co in ((32, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 1024), (1024, 1024))])
-run("16 x Linear(4096,4096)", [(4096, 4096)] * 16, reps=50)
-run_lut("ResNet-50 weights", resnet50_shapes())
-run_lut("16 x Linear(4096,4096)", [(4096, 4096)] * 16, reps=50)
+if __name__ == "__main__":
+    run("ResNet-50 weights", resnet50_shapes())
+    run("MobileNet-like pointwise/depthwise stack", [(c, 1, 3, 3) for c in (32, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024)] +
+        [(co, ci, 1, 1) for ci, co in ((32, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 1024), (1024, 1024))])
+    run("16 x Linear(4096,4096)", [(4096, 4096)] * 16, reps=50)
+    run_lut("ResNet-50 weights", resnet50_shapes())
+    run_lut("16 x Linear(4096,4096)", [(4096, 4096)] * 16, reps=50)
