@@ -21,8 +21,9 @@ Protocol
     own device has finished its K steps; the closing barrier follows and rank 0 takes the MAX over ranks).  Three clocks,
     one claim each:
       - the host wall clock gives ``value``, ``ms_per_step``, ``achieved_gbs`` and ``roofline.frac_wall``;
-      - HIP events on the launch stream around the K launches give ``roofline.frac_events_whole_region`` (the idle
-        stream's start-up before the first launch included);
+      - (only when there is no steady part -- hipGraph replay, several streams -- HIP events around the K launches give
+        ``roofline.frac_events_whole_region``; otherwise that field repeats ``frac_wall``: every marker inside the region
+        costs ~5 us of stream time, so the judged region carries two, not three);
       - the event behind the FIRST launch to the event behind the LAST gives ``roofline.kernel_us`` / ``achieved`` /
         ``frac``: the average launch period of launches 2..K, bubbles between launches included -- the figure that
         rocprofv3's average kernel duration (profiles/) must agree with.
@@ -107,6 +108,10 @@ def metric_label(config: str, wl, batched: int) -> str:
         return BASELINE_METRIC
     tail = f", {batched} tensors per launch" if batched else ""
     return f"elems/s + achieved HBM GB/s, {wl.name} {'x'.join(str(s) for s in wl.shape)} fp32{tail}"
+
+
+def graph_ok_for_calibration(args) -> bool:
+    return not args.graph and args.streams == 1 and args.device == "cuda"
 
 
 def per_launch_periods(step, launches: int):
@@ -259,6 +264,7 @@ def main():
         step(i)
     dev_sync()
     kernel_variant = "aten cpu operator (dry run)" if dry else native.last_launch()
+    sync_method = bench_dist.calibrate_sync(step, device) if graph_ok_for_calibration(args) else "torch.cuda.synchronize()"
 
     graph = None
     if args.graph:
@@ -271,15 +277,18 @@ def main():
     # ---- timed region ---------------------------------------------------------------------
     steady = graph is None and streams is None and n_launch >= 2 and not dry
     if not dry:
+        # two markers only inside the judged region (each costs ~5 us of stream time, tools/region_overhead_probe.py): one
+        # behind the FIRST launch, one behind the last; a third in front of the first launch only when there is no steady part
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev_first = torch.cuda.Event(enable_timing=True)   # behind the FIRST launch: ev0 -> ev_first carries the host's launch latency
+        ev_first = torch.cuda.Event(enable_timing=True)
 
     def run_all(_):
         if dry:
             for i in range(n_launch):
                 step(i)
             return None
-        ev0.record()
+        if not steady:
+            ev0.record()
         if graph is not None:
             graph.replay()
         else:
@@ -294,7 +303,8 @@ def main():
         return ev1                                 # the region's closing synchronize polls this event first
 
     wall = bench_dist.timed_region(run_all, 1, device, dist)
-    dev_ms = wall * 1e3 if dry else ev0.elapsed_time(ev1)      # events on the stream the kernels were launched on
+    # events on the stream the kernels were launched on; with a steady part the whole-region figure is the host wall clock
+    dev_ms = wall * 1e3 if (dry or steady) else ev0.elapsed_time(ev1)
     wall, dev_ms = bench_dist.max_over_ranks([wall, dev_ms], dist, control_plane, device)
 
     value = elems * args.steps * world / wall
@@ -334,7 +344,8 @@ def main():
                    "binding": "none (dry run)" if dry else ("compiled" if native.fast() is not None else "ctypes"),
                    "prewarm_s": round(prewarm_s, 3), "prewarm_steps": n_pre,
                    "parallelism": f"replicated x{world} (weak, no collective)",
-                   "control_plane": control_plane, "ranks_seen": ranks_seen},
+                   "control_plane": control_plane, "ranks_seen": ranks_seen,
+                   "region_end": sync_method},
         "achieved_gbs": achieved_wall,                       # same clock as value / ms_per_step (host wall)
         "achieved_gbs_steady": achieved,                     # = roofline.achieved (event period of launches 2..K)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

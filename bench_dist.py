@@ -64,19 +64,43 @@ def init_process_group(backend: str, device: torch.device, force_gloo: bool = Fa
     return dist, control
 
 
+SPIN_FIRST = False      # set by calibrate_sync(): poll the region's last event before torch.cuda.synchronize()?
+
+
 def sync(device: torch.device, spin_on=None):
-    """torch.cuda.synchronize(), reached by polling an event first: the blocking wait of the runtime wakes up tens of
-    microseconds after the GPU has finished, which a 20-step timed region of ~0.5 ms would otherwise carry as cost.
-    ``spin_on``: an event the caller has already recorded behind its last launch (saves one more marker packet,
-    ~15 us on an idle stream, tools/sync_probe.py)."""
+    """torch.cuda.synchronize() -- optionally reached by polling an event first.  Which is cheaper depends on the machine:
+    where the runtime's blocking wait wakes up late, polling the event recorded behind the last launch saves tens of
+    microseconds (round 2's box); where synchronize() on an already idle device costs ~20 us by itself, the plain call is
+    cheaper (round 3's box: 458 vs 490 us for a 20-step region, tools/region_overhead_probe.py).  calibrate_sync() times
+    both on short regions outside the timed region; the choice is reported in the bench line."""
     if device.type == "cuda":
-        ev = spin_on
-        if ev is None:
+        if SPIN_FIRST and spin_on is not None:
+            while not spin_on.query():
+                pass
+        torch.cuda.synchronize(device)
+
+
+def calibrate_sync(step: Callable[[int], None], device: torch.device, steps: int = 10, rounds: int = 5) -> str:
+    """Pick the cheaper way to reach torch.cuda.synchronize() at the end of a region (see sync); outside the timed region."""
+    global SPIN_FIRST
+    if device.type != "cuda":
+        return "n/a"
+    best = {}
+    for spin in (False, True):
+        SPIN_FIRST = spin
+        ts = []
+        for _ in range(rounds):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
             ev = torch.cuda.Event()
             ev.record()
-        while not ev.query():
-            pass
-        torch.cuda.synchronize(device)
+            sync(device, ev)
+            ts.append(time.perf_counter() - t0)
+        best[spin] = sorted(ts)[len(ts) // 2]
+    SPIN_FIRST = best[True] < best[False]
+    return "poll the last event, then torch.cuda.synchronize()" if SPIN_FIRST else "torch.cuda.synchronize()"
 
 
 def timed_region(step: Callable[[int], None], steps: int, device: torch.device, dist=None) -> float:
