@@ -7,6 +7,9 @@ namespace mctq {        // mctq_f64.hip
 int fq64_per_tensor(const void* x, void* y, int64_t n, float scale, int32_t zp, int32_t qmin, int32_t qmax, hipStream_t st);
 int fq64_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
                      const int32_t* zps, int32_t qmin, int32_t qmax, bool wide, hipStream_t st);
+// mctq_batched.hip: one float32 tensor through the batched grid's tile code (per-lane-vector parameters)
+int fq_gather_one_f32(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
+                      const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st);
 }
 
 extern "C" {
@@ -37,6 +40,14 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
   if (n > 0 && (!x || !y || !scales)) return fail_arg("NULL pointer");
   if (dtype == MCTQ_DT_F64)
     return fq64_per_channel(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, true, (hipStream_t)stream);
+  // float32 rows that are neither long and vector-divisible (rows_kernel) nor the fastest axis (lastaxis_kernel), of at
+  // least 32 elements: the batched grid's per-lane-vector parameter path (no LDS window, no block barrier) as a one-tensor
+  // launch (descriptor in preloaded scalar arguments) is 6-9 % faster than window_kernel there (inner 64 ... 1020, 4099-wide rows: 24.3 -> 22.4 us per 128 MiB,
+  // profiles/r03/short_rows_probe.log); 16-bit storage and inner < 32 stay with the window kernel (equal or better).
+  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !(inner % 4 == 0 && inner / 4 >= kThreads) &&
+      (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && n < (1ll << 31) - 4096 && channels <= 0x7fffffffLL) {
+    return fq_gather_one_f32(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
+  }
   AffineOp op;
   op.scales = scales; op.zps = zero_points;
   op.lo = (float)quant_min; op.hi = (float)quant_max;

@@ -360,6 +360,26 @@ __global__ __launch_bounds__(kThreads) void batched_table_kernel(const BatchItem
   batched_block<TI, TO, U, NT>(src);
 }
 
+// ONE tensor through the same tile code, its descriptor in nine scalar kernel arguments (all preloaded into SGPRs: no
+// map word, no descriptor load): the single-tensor entry point's route for float32 rows that are neither long and
+// vector-divisible (rows_kernel) nor the fastest axis -- the per-lane-vector parameter path beats window_kernel's LDS
+// window + block barrier there (mctq_affine.hip).
+template <class TI, class TO, int U, int NT>
+__global__ __launch_bounds__(kThreads) void batched_one_kernel(const TI* __restrict__ x, TO* __restrict__ y,
+                                                               const float* __restrict__ scales,
+                                                               const int32_t* __restrict__ zps, uint32_t n, uint32_t inner,
+                                                               uint32_t channels, float lo, float hi) {
+  constexpr uint32_t TILE = kThreads * U * IO<TI, TO>::N;
+  BatchItem it;
+  it.x = x; it.y = y; it.scales = scales; it.zps = zps; it.n = n; it.inner = inner; it.channels = channels;
+  it.tile_begin = 0; it.tiles = gridDim.x; it.reserved = 0; it.lo = lo; it.hi = hi;
+  const uint32_t e0 = blockIdx.x * TILE;
+  const uint32_t left = n - e0;
+  AffinePol<TI, TO> pol(it);
+  if (left >= TILE) batched_tile<true, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, TILE);
+  else batched_tile<false, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, left);
+}
+
 // The same grid for LUT quantizers with a decision table: all LUT weights of a model, or a group of LUT activation
 // batches, in one launch.  Output float32 (the reference's chain promotes), table staged in dynamic LDS per block.
 struct LutTableSrc {
@@ -432,6 +452,22 @@ static int launch_lut_batch(const LutTableSrc& src, uint32_t grid, size_t lds, i
     note<LutTableOp, TI, float>("batched_lut_kernel<table>", kBatchU, NT);
   });
   return check_launch("batched LUT launch");
+}
+
+// float32 [rows][inner] with per-channel parameters, x / y 16-byte aligned, n < 2^31 - tile (checked by the caller)
+int fq_gather_one_f32(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
+                      const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st) {
+  const int64_t n = outer * channels * inner;
+  if (n == 0) return 0;
+  constexpr uint32_t tile_e = kThreads * kBatchU * 4;
+  const uint32_t grid = (uint32_t)((n + tile_e - 1) / tile_e);
+  MCTQ_WITH_MODE(nt_mode(n * 4) == 0 ? 1 : nt_mode(n * 4), false, {
+    hipLaunchKernelGGL((batched_one_kernel<float, float, kBatchU, NT>), dim3(grid), dim3(kThreads), 0, st,
+                       static_cast<const float*>(x), static_cast<float*>(y), scales, zps, (uint32_t)n, (uint32_t)inner,
+                       (uint32_t)channels, (float)qmin, (float)qmax);
+    note<AffineOp, float, float>("gather_kernel", kBatchU, NT);
+  });
+  return check_launch("gather launch");
 }
 
 // ---- host: which tensors one grid can take, and how the grid is cut ---------------------------------------

@@ -880,8 +880,8 @@ __global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op:
 // channels: their parameters are fetched (16-byte table loads) and inverted once per lane, not per element.
 // ------------------------------------------------------------------------------------------
 template <class Op, class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void lastaxis_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
-                                                            uint64_t rows, uint32_t vc, uint32_t k, uint32_t bps) {
+__global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,
+                                                            uint64_t rows, uint32_t vc, uint32_t k, uint32_t bps, Op op) {
   typedef IO<TI, TO> io;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t g = (blockIdx.x % bps) * kThreads + threadIdx.x;      // lane inside the k-row group
@@ -931,9 +931,9 @@ __device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t d, float r) {
 }
 
 template <class Op, class TI, class TO, int U, bool VEC, int NT, typename IdxT>
-__global__ __launch_bounds__(kThreads) void window_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys, IdxT n,
+__global__ __launch_bounds__(kThreads) void window_kernel(const TI* __restrict__ xs, TO* __restrict__ ys, IdxT n,
                                                           uint32_t inner, uint32_t channels,
-                                                          uint32_t stride /* LDS entries per param word */) {
+                                                          uint32_t stride /* LDS entries per param word */, Op op) {
   typedef IO<TI, TO> io;
   constexpr uint32_t V = VEC ? io::N : 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1271,7 +1271,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
     if (blocks <= 0x7fffffffLL && k * vc <= 0x7fffffffLL) {
       MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
         hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                           op, x, y, (uint64_t)outer, (uint32_t)vc, (uint32_t)k, (uint32_t)bps);
+                           x, y, (uint64_t)outer, (uint32_t)vc, (uint32_t)k, (uint32_t)bps, op);
         note<Op, TI, TO>("lastaxis_kernel", LU, NT);
       });
       return check_launch("lastaxis launch");
@@ -1300,7 +1300,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   const bool idx32 = n <= (int64_t)0xffffffffLL - (int64_t)tile;
 #define MCTQ_WINDOW(WU_, VEC_, IDX_)                                                                               \
   hipLaunchKernelGGL((window_kernel<Op, TI, TO, WU_, VEC_, NT, IDX_>), dim3((unsigned)blocks), dim3(kThreads), lds, st, \
-                     op, x, y, (IDX_)n, (uint32_t)inner, (uint32_t)channels, stride)
+                     x, y, (IDX_)n, (uint32_t)inner, (uint32_t)channels, stride, op)
 #define MCTQ_WINDOW_WU(VEC_, IDX_)                                    \
   do {                                                                \
     if (wu == 4) MCTQ_WINDOW(4, VEC_, IDX_);                          \
