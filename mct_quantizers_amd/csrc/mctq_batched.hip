@@ -175,11 +175,12 @@ struct LutPol {
   }
   template <bool UNI, int N>
   __device__ __forceinline__ void run(const float* in, float* out, const Param& p) const {
-    if constexpr (UNI) {
-      const bool fast = __builtin_amdgcn_readfirstlane((int)LutCommon::can_fast(p)) != 0;   // wave-uniform
-      if (fast) { op.template tile<true, N>(in, out, p, book); return; }
-    }
-    op.template tile<false, N>(in, out, p, book);
+    // the exact reciprocal division (LutCommon::divide_fast) is per element: it works with per-lane divisors too, as long
+    // as every active lane's divisor qualifies (wave-uniform test either way)
+    const bool fast = UNI ? __builtin_amdgcn_readfirstlane((int)LutCommon::can_fast(p)) != 0
+                          : __builtin_amdgcn_ballot_w64(!LutCommon::can_fast(p)) == 0;
+    if (fast) op.template tile<true, N>(in, out, p, book);
+    else op.template tile<false, N>(in, out, p, book);
   }
   __device__ __forceinline__ static Param pick(bool first, const Param& a, const Param& b) {
     Param p; p.d = first ? a.d : b.d; p.t = first ? a.t : b.t; p.r = first ? a.r : b.r; p.ds = first ? a.ds : b.ds; return p;

@@ -991,7 +991,12 @@ __global__ __launch_bounds__(kThreads) void window_kernel(const TI* __restrict__
       float in[V], out[V];
       io::unpack(v[u], in);
       if (same_row || lrem + V <= inner) {                  // the lane-vector lies inside one row (always, when rows
-        run<false, (int)V>(op, in, out, Op::get(tab, li, stride), book);   // are whole vectors): one parameter set
+        const typename Op::Param p = Op::get(tab, li, stride);             // are whole vectors): one parameter set
+        bool fast = false;
+        if constexpr (Op::kHeavy)          // LUT ops: the exact reciprocal division works per lane as well (r, ds are in the
+          fast = __builtin_amdgcn_ballot_w64(!Op::can_fast(p)) == 0;       // window); taken when every active lane qualifies
+        if (fast) run<true, (int)V>(op, in, out, p, book);
+        else run<false, (int)V>(op, in, out, p, book);
       } else
 #pragma unroll
       for (uint32_t j = 0; j < V; ++j) {
