@@ -181,6 +181,8 @@ def main():
         args.config, args.batched, args.graph, args.streams, args.extras = "cfg1", 0, False, 1, False
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU"
+        if os.environ.get("MCTQ_BENCH_WRAP_DEVICES"):        # rehearsal of the N > 1 path on fewer GPUs than ranks (tests)
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     dist, control_plane = None, None
