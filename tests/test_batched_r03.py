@@ -531,3 +531,39 @@ def test_plain_python_bench_gpus_2_on_the_gpu_box():
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["control_plane"] == "gloo"
     assert len(d["per_rank_kernel_us"]) == 2 and all(v > 5 for v in d["per_rank_kernel_us"])
     assert d["value"] > 1e11 and d["scaling"] == "weak" and "rows_kernel" in d["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_captured_forward_with_lut_and_affine_weights_replays_the_batched_launches():
+    """capture_forward (one hipGraph for the whole forward) on a model whose wrappers mix affine and LUT weights quantizers:
+    both table launches are capture-legal (no allocation, no upload once the plan is warm); replays follow in-place
+    weight updates and equal the eager forward."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
+    if native.fast() is None:
+        pytest.skip("needs the compiled binding (BatchPlan)")
+    Q = mq.pytorch_quantizers
+
+    def build():
+        torch.manual_seed(4)
+        mods = []
+        for i, (fin, fout) in enumerate(((64, 128), (128, 2048), (2048, 32))):
+            lin = torch.nn.Linear(fin, fout)
+            thr = [float(v) + 1e-3 for v in lin.weight.detach().abs().amax(dim=1)]
+            wq = Q.WeightsLUTSymmetricInferableQuantizer(4, list(LUT16), thr, True, 0, 2) if i % 2 == 0 else \
+                Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)
+            mods += [mq.PytorchQuantizationWrapper(lin, {"weight": wq}),
+                     mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-3.0], [3.0]))]
+        return torch.nn.Sequential(*mods).cuda().eval()
+
+    ref, model = build(), build()
+    x = torch.randn(4, 64, device="cuda")
+    fwd = mq.capture_forward(model, x)
+    with torch.no_grad():
+        assert torch.equal(fwd(x).clone(), ref(x))
+        for m, r in zip(model, ref):
+            if hasattr(m, "weight"):
+                m.weight.mul_(0.7); r.weight.mul_(0.7)
+        x2 = torch.randn(4, 64, device="cuda")
+        assert torch.equal(fwd(x2).clone(), ref(x2))
+    fwd.release()
