@@ -567,3 +567,41 @@ def test_captured_forward_with_lut_and_affine_weights_replays_the_batched_launch
         x2 = torch.randn(4, 64, device="cuda")
         assert torch.equal(fwd(x2).clone(), ref(x2))
     fwd.release()
+
+
+@pytest.mark.gpu
+def test_batch_plan_holds_and_releases_its_references():
+    """The plan keeps x / y / parameter tensors and the watched objects alive while it exists and releases every one of
+    them when it goes away (affine and LUT items, with watches), also when construction fails half way."""
+    import gc
+    import sys
+    from mct_quantizers_amd.hip import native, ops
+    fast = native.fast()
+    if fast is None:
+        pytest.skip("needs the compiled binding (BatchPlan)")
+    x = torch.randn(64, 256, device="cuda"); y = torch.empty_like(x); yl = torch.empty(64, 256, device="cuda")
+    s = torch.rand(64, device="cuda") + 0.1
+    thr = torch.rand(64, device="cuda") + 1.0
+    table = ops.make_lut_table(np.float32(LUT16), 128.0, -128.0, 127.0, "cuda")
+    owner = {"scales": s, "flag": False}
+    watch = (owner, (("scales", s, s._version), ("flag", False, -1)))
+    objs = (x, y, yl, s, thr, table)
+    base = [sys.getrefcount(o) for o in objs]
+    for _ in range(200):
+        plan = fast.BatchPlan([(x, y, s, None, 0, -128, 127, watch),
+                               ("lut", x, yl, thr, table, 0, 1e-8, 0.0, 0.0, 128.0, -128.0, 127.0, 0, watch)])
+        assert plan() is None
+        del plan
+    for _ in range(50):                                         # construction that fails after the first item was taken
+        with pytest.raises(TypeError):
+            fast.BatchPlan([(x, y, s, None, 0, -128, 127, watch), (x, y, s.double(), None, 0, -128, 127)])
+        with pytest.raises(TypeError):
+            fast.BatchPlan([("lut", x, yl, thr, table, 0, 1e-8, 0.0, 0.0, 128.0, -128.0, 127.0, 0), ("lut", x, y.half(), thr, table, 0, 1e-8, 0.0, 0.0, 128.0, -128.0, 127.0, 0)])
+    gc.collect()
+    torch.cuda.synchronize()
+    assert [sys.getrefcount(o) for o in objs] == base
+    z = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert torch.equal(y, torch.fake_quantize_per_channel_affine(x, s, z, 0, -128, 127))
+    owner["flag"] = True                                       # a watched object replaced: the plan declines
+    plan = fast.BatchPlan([(x, y, s, None, 0, -128, 127, (owner, (("flag", False, -1),)))])
+    assert plan() is NotImplemented
