@@ -1261,6 +1261,20 @@ def test_integration_md_stub_runs_as_written(lib):
     got = ns["fake_quantize_per_channel_hip"](x, s, z, 1, -128, 127)
     assert torch.equal(got, torch.fake_quantize_per_channel_affine(x, s, z, 1, -128, 127))
     assert ctypes_sizeof(ns["FqItem"]) == 72
+    # the table-form hook of the same document (block with `class BatchedWeights`), run as written on three quantizers
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    hook_src = next(b for b in blocks if "class BatchedWeights" in b)
+    exec(compile(hook_src, "INTEGRATION.md", "exec"), ns)
+    torch.manual_seed(1)
+    ws = [torch.randn(40, 96, device="cuda"), torch.randn(8, 3, 5, 5, device="cuda"), torch.randn(1000, device="cuda")]
+    qs = [Q.WeightsSymmetricInferableQuantizer(8, [1.0 + 0.1 * i for i in range(40)], True, 0),
+          Q.WeightsUniformInferableQuantizer(4, [-1.0] * 3, [2.0] * 3, True, 1),
+          Q.WeightsSymmetricInferableQuantizer(8, [3.0], False)]
+    outs = ns["BatchedWeights"](list(zip(ws, qs)))()
+    torch.cuda.synchronize()
+    for w, q, y in zip(ws, qs, outs):
+        assert torch.equal(y, q(w.clone())), type(q).__name__
 
 
 def ctypes_sizeof(t):
