@@ -230,6 +230,31 @@ __global__ __launch_bounds__(kThreads) void lut64_steps_kernel(Lut64Steps op, co
     const float q = (val != val) ? nan_q : Q[idx];            // torch.clip keeps NaN: every distance NaN, argmin = entry 0
     return q * tm;
   };
+  auto params = [&](uint32_t cc, double& d, float& tm) {
+    if (op.thr) { tm = op.thr[cc]; d = (double)(tm + op.eps); }        // float32 tensor + scalar: a float32 sum
+    else { tm = op.t0; d = op.d0; }
+  };
+  // the whole tile inside one row (rows of at least a tile, tile-aligned -- Linear weights along axis 0), or one parameter
+  // set for the tensor: the divisor and the multiplier are wave-uniform, no per-lane row search
+  const IdxT row0 = (op.thr && channels > 1) ? e0 / inner : 0;
+  const IdxT rem0 = e0 - row0 * inner;
+  if (!(op.thr && channels > 1) || rem0 + count <= inner) {
+    double d; float tm;
+    params((op.thr && channels > 1) ? (uint32_t)(row0 % channels) : 0u, d, tm);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t off = (u * kThreads + threadIdx.x) * V;
+      if (off >= count) continue;
+      if (VEC && off + V <= count) {
+        f32x2 r;
+        r.x = one(v[u].x, d, tm); r.y = one(v[u].y, d, tm);
+        *reinterpret_cast<f32x2*>(y + e0 + off) = r;
+      } else {
+        for (uint32_t j = 0; j < V && off + j < count; ++j) y[e0 + off + j] = one(x[e0 + off + j], d, tm);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * V;
@@ -242,10 +267,6 @@ __global__ __launch_bounds__(kThreads) void lut64_steps_kernel(Lut64Steps op, co
       rem = pos - row * inner;
       c = (uint32_t)(row % channels);
     }
-    auto params = [&](uint32_t cc, double& d, float& tm) {
-      if (op.thr) { tm = op.thr[cc]; d = (double)(tm + op.eps); }      // float32 tensor + scalar: a float32 sum
-      else { tm = op.t0; d = op.d0; }
-    };
     double d; float tm;
     params(c, d, tm);
     if (VEC && off + V <= count) {
