@@ -31,20 +31,25 @@ run_cfg cfg3_n64_eager --config cfg3 --batch 64 --stream-depth -1
 run_cfg cfg3_n8 --config cfg3 --batch 8
 run_cfg cfg4 --config cfg4 --steps 300
 run_cfg cfg5 --config cfg5 --steps 300
-# stall counters of the headline kernel: one pass per group (8 SQ slots, 4 TCC slots)
-out=$R/gpurun_out/pmc/cfg2
-i=0
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
-           "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum" \
-           "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_NC_READ_REQ_sum"; do
-  i=$((i+1)); rm -rf /tmp/pmc_stall_$i
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_$i -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 > $out/bench_stall_$i.log 2>&1
-  f=$(find /tmp/pmc_stall_$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq::" $f | tail -400 >> $out/stall_$i.csv; else echo "group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
-done
+# stall counters of the headline kernel and of the batched launch: one pass per group (8 SQ slots, 4 TCC slots)
+stall_passes() {   # name, bench args...
+  local name=$1; shift
+  local out=$R/gpurun_out/pmc/$name
+  local i=0
+  for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+             "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
+             "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum" \
+             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+             "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum" \
+             "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" \
+             "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_NC_READ_REQ_sum"; do
+    i=$((i+1)); rm -rf /tmp/pmc_stall_${name}_$i
+    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_${name}_$i -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 "$@" > $out/bench_stall_$i.log 2>&1
+    f=$(find /tmp/pmc_stall_${name}_$i -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq::" $f | tail -400 >> $out/stall_$i.csv; else echo "$name group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
+  done
+}
+stall_passes cfg2
+stall_passes cfg2_batched16 --batched 16 --steps 30 --warmup 5
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
 for c in cfg2 cfg2_batched16 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done

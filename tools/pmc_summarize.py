@@ -56,19 +56,24 @@ for cfg in sorted(os.listdir(SRC)):
 with open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
 
-# stall counters of the headline kernel -> one table
-stall = {}
-d = os.path.join(SRC, "cfg2")
-for fn in sorted(os.listdir(d)):
-    if fn.startswith("stall_") and fn.endswith(".csv"):
-        for r in csv.DictReader(open(os.path.join(d, fn))):
-            if "rows_kernel" in r["Kernel_Name"]:
-                stall.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-if stall:
-    with open(os.path.join(DST, "cfg2_rows_kernel_stall_counters.csv"), "w") as f:
-        f.write("counter,avg_per_dispatch,dispatches\n")
-        for k in sorted(stall):
-            f.write(f"{k},{sum(stall[k]) / len(stall[k]):.1f},{len(stall[k])}\n")
-    print(open(os.path.join(DST, "cfg2_rows_kernel_stall_counters.csv")).read())
+# stall counters of the headline kernel and of the batched launch -> one table each
+for cfg, needle, fname in (("cfg2", "rows_kernel", "cfg2_rows_kernel_stall_counters.csv"),
+                           ("cfg2_batched16", "batched_table_kernel", "cfg2_batched16_table_kernel_stall_counters.csv")):
+    stall = {}
+    d = os.path.join(SRC, cfg)
+    if not os.path.isdir(d):
+        continue
+    for fn in sorted(os.listdir(d)):
+        if fn.startswith("stall_") and fn.endswith(".csv"):
+            for r in csv.DictReader(open(os.path.join(d, fn))):
+                if needle in r["Kernel_Name"]:
+                    stall.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if stall:
+        with open(os.path.join(DST, fname), "w") as f:
+            f.write("counter,avg_per_dispatch,dispatches\n")
+            for k in sorted(stall):
+                f.write(f"{k},{sum(stall[k]) / len(stall[k]):.1f},{len(stall[k])}\n")
+        print(fname)
+        print(open(os.path.join(DST, fname)).read())
 if os.path.exists(os.path.join(SRC, "available_counters.txt")):
     shutil.copy(os.path.join(SRC, "available_counters.txt"), os.path.join(DST, "rocprofv3_available_counters.txt"))
