@@ -58,13 +58,19 @@ class BatchedWeightQuantization:
         # table, raw pointers) stays behind and is rebuilt at the copy's first forward
         state = dict(self.__dict__)
         state["_plan"] = None
+        state["_wrappers"] = None
         state["_cell"] = [0, False]
         return state
 
     def _entries(self, with_lut: bool = False) -> List[Tuple[PytorchQuantizationWrapper, str, torch.Tensor, object]]:
         out = []
-        for m in self.model.modules():
-            if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization and m.is_str_attr:
+        wrappers = self.__dict__.get("_wrappers")
+        if wrappers is None:              # the walk over the module tree, once (refresh() after adding / removing wrappers)
+            wrappers = self.__dict__["_wrappers"] = [
+                m for m in self.model.modules()
+                if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization and m.is_str_attr]
+        for m in wrappers:
+            if True:
                 for name, weight, quantizer in m.get_weights_vars():
                     if (with_lut and hasattr(quantizer, "batch_item_lut") and not quantizer.enable_reuse
                             and not quantizer.__dict__.get("_versioned_reuse")
@@ -133,6 +139,7 @@ class BatchedWeightQuantization:
 
     def _drop_plan(self):
         self._plan = None
+        self.__dict__["_wrappers"] = None
         for m in self.model.modules():
             if isinstance(m, PytorchQuantizationWrapper):
                 m.__dict__.pop("_prequantized_plan", None)
