@@ -44,7 +44,15 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
   // least 32 elements: the batched grid's per-lane-vector parameter path (no LDS window, no block barrier) as a one-tensor
   // launch (descriptor in preloaded scalar arguments) is 6-9 % faster than window_kernel there (inner 64 ... 1020, 4099-wide rows: 24.3 -> 22.4 us per 128 MiB,
   // profiles/r03/short_rows_probe.log); 16-bit storage and inner < 32 stay with the window kernel (equal or better).
-  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !(inner % 4 == 0 && inner / 4 >= kThreads) &&
+  // ... and long vector-divisible rows whose last row tile would be mostly idle lanes (4100-wide: 1025 lane-vectors = four
+  // full 256-lane tiles + one lane: 23.1 -> 22.5 us); rows that nearly fill their tiles (11008-wide: 2 % idle) stay.
+  // ... and rows of 256-511 lane-vectors, which rows_kernel could only cut into 4 KiB tiles (16384 x 1024: 22.9 -> 22.3 us).
+  bool long_rows = inner % 4 == 0 && inner / 4 >= 2 * kThreads;
+  if (long_rows) {
+    const int64_t innerv = inner / 4, tiles = (innerv + kThreads - 1) / kThreads;
+    if ((tiles * kThreads - innerv) * 12 > tiles * kThreads) long_rows = false;      // > 1/12 of the row's lanes idle
+  }
+  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !long_rows &&
       (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && n < (1ll << 31) - 4096 && channels <= 0x7fffffffLL) {
     return fq_gather_one_f32(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
   }

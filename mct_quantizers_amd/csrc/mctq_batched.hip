@@ -300,6 +300,11 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, Pol& pol, floa
       io::unpack(v[u], in);
       if (rem + N <= inner) {                               // the vector lies in one row
         pol.template run<false, (int)N>(in, out, pv[u]);
+      } else if (inner >= N) {                              // it crosses exactly one row boundary: two sets, chosen per element
+        const uint32_t split = inner - rem;
+        const Param pb = pol.lane(c + 1 == channels ? 0 : c + 1);
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) pol.template run<false, 1>(in + j, out + j, Pol::pick(j < split, pv[u], pb));
       } else {
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
