@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Benchmark of the inferable-quantizer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--batched T] [--batch N] [--no-cpu] ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|...|resnet50] [--batched T] [--batch N] [--no-cpu] ...
 
 A *step* is one call of the configuration's quantizer (through the public class, hence through the
 C ABI and the gfx950 kernel) on one device-resident synthetic tensor.  Default workload: BASELINE
 config 2, WeightsSymmetricInferableQuantizer per-channel (axis 0) 8-bit on 4096x4096 float32.
 ``--batched T``: a step is ONE batched launch over T such tensors (the launch a wrapped model issues per forward,
 pytorch/batching.py -> mctq_fq_batch_run; reference call site pytorch/quantize_wrapper.py:228-240), algorithmic bytes
-T x 128 MiB per launch.
+T x 128 MiB per launch.  ``--config resnet50`` / ``linear16``: a step re-quantizes ALL weight tensors of that model (54
+tensors, 25.5 M elements / 16 x 4096^2), each with its own per-channel quantizer, in ONE table launch.
 
 Protocol
   * cache: the 128 MiB in+out working set of config 2 fits the 256 MiB Infinity Cache, so the steps rotate
@@ -72,7 +73,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "resnet50", "linear16"],
+                    help="cfg1..cfg5: the BASELINE configurations; resnet50 / linear16: ALL weights of that model re-quantized "
+                         "in one batched launch per step (what a wrapped model does per forward)")
     ap.add_argument("--batched", type=int, default=0,
                     help="T > 0: a step is ONE batched launch over T tensors of the configuration (affine configs)")
     ap.add_argument("--batch", type=int, default=64, help="N of config 3")
@@ -106,6 +109,8 @@ def parse():
 def metric_label(config: str, wl, batched: int) -> str:
     if config == "cfg2" and not batched:
         return BASELINE_METRIC
+    if config in ("resnet50", "linear16"):
+        return f"elems/s + achieved HBM GB/s, {wl.name} fp32, one batched launch per step"
     tail = f", {batched} tensors per launch" if batched else ""
     return f"elems/s + achieved HBM GB/s, {wl.name} {'x'.join(str(s) for s in wl.shape)} fp32{tail}"
 
@@ -202,9 +207,23 @@ def main():
                 native.set_tuning(key, val)
 
     # ---- workload -------------------------------------------------------------------------
-    x_np = workloads.make_input(args.config, batch=args.batch)
-    wl = workloads.make_workload(args.config, x_np)
-    quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
+    model_mode = args.config in ("resnet50", "linear16")
+    if model_mode:
+        # every weight of the model, each with its own per-channel quantizer, ONE table launch per step
+        assert not dry and native.fast() is not None, "the model workloads need a GPU and the compiled binding"
+        weights = workloads.make_model_weights(args.config)
+        quantizers = [mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(**kw) for _, kw in weights]
+        total = sum(int(x.size) for x, _ in weights)
+        import types
+        wl = types.SimpleNamespace(name=f"{args.config}: all {len(weights)} weight tensors, WeightsSymmetric per-channel(axis0) 8b",
+                                   shape=(len(weights), "tensors"), quantizer="WeightsSymmetricInferableQuantizer",
+                                   numel=total, bytes_per_elem=8, kwargs=None)
+        x_np, quantizer = None, quantizers[0]
+        args.batched = len(weights)
+    else:
+        x_np = workloads.make_input(args.config, batch=args.batch)
+        wl = workloads.make_workload(args.config, x_np)
+        quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
     tensors = max(1, args.batched)
     per_launch = 1                               # steps served by one launch (activation stream: D batches per replay)
     stream_on = (args.config == "cfg3" and not args.batched and not dry and not args.graph and args.streams == 1
@@ -213,10 +232,10 @@ def main():
         cap = args.stream_depth if args.stream_depth > 0 else min(32, max(1, args.steps // 2))
         per_launch = max(d for d in range(1, cap + 1) if args.steps % d == 0)
         stream_on = per_launch > 1
-    elems = wl.numel * tensors
+    elems = wl.numel if model_mode else wl.numel * tensors
     alg_bytes = elems * wl.bytes_per_elem        # per STEP
     ring = args.ring or max(2, -(-(512 << 20) // (alg_bytes * per_launch)) + 1)
-    x0 = torch.from_numpy(x_np).to(device)
+    x0 = None if model_mode else torch.from_numpy(x_np).to(device)
     streams = None
     if stream_on:
         from mct_quantizers_amd.pytorch.graphs import capture_stream
@@ -226,6 +245,21 @@ def main():
 
         def step(i):                             # one LAUNCH: per_launch batches
             act_streams[i % ring].run()
+    elif model_mode:
+        plans, plan_outs = [], []
+        for _ in range(ring):
+            items, ys_ = [], []
+            for (xw, _), q in zip(weights, quantizers):
+                xi, scales, zps, axis, qmin, qmax = q.batch_item(torch.from_numpy(xw).to(device))
+                y = torch.empty_like(xi)
+                items.append((xi, y, scales, zps, axis, qmin, qmax))
+                ys_.append(y)
+            plans.append(native.fast().BatchPlan(items))
+            plan_outs.append(ys_)
+        xs, ys = None, None
+
+        def step(i):
+            plans[i % ring]()
     elif args.batched:
         if not hasattr(quantizer, "batch_item") and not hasattr(quantizer, "batch_item_lut"):
             raise SystemExit(f"--batched: {wl.quantizer} has no batched launch")
@@ -335,7 +369,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (portable splitmix64 generator, mct_quantizers_amd/workloads.py)",
-        "config": {"workload": wl.name + (f", {tensors} tensors in one batched launch" if args.batched else ""),
+        "config": {"workload": wl.name + (f", {tensors} tensors in one batched launch" if args.batched and not model_mode else
+                                          ", one batched launch per step" if model_mode else ""),
                    "shape": list(wl.shape), "quantizer": wl.quantizer, "tensors_per_step": tensors,
                    "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
                    "launch": ("hipGraph" if graph is not None else
@@ -394,7 +429,7 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
                 key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
-                if args.batched:
+                if args.batched and not model_mode:
                     key = f"{key}_batched{tensors}"
                 if stream_on:
                     key = f"{key}_stream{per_launch}"
@@ -534,7 +569,30 @@ def main():
             except Exception as e:  # noqa: BLE001  (extras only)
                 result["sharded_cfg5"] = {"error": repr(e)[:300]}
 
-    if rank == 0 and world == 1 and not args.no_cpu and not dry:
+    if rank == 0 and world == 1 and not args.no_cpu and not dry and model_mode:
+        # CPU baseline of the model workloads: ATen's CPU operator on every weight in turn, oracle-derived parameters
+        from oracle import torch_cpu
+        fs = [torch_cpu.prepare("WeightsSymmetricInferableQuantizer", kw) for _, kw in weights]
+        xcs = [torch.from_numpy(xw) for xw, _ in weights]
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        wants = [f(x) for f, x in zip(fs, xcs)]
+        same = all(bool(torch.equal(y.cpu(), w)) for y, w in zip(y_last, wants))
+        n, c0 = 0, time.perf_counter()
+        while True:
+            for f, x in zip(fs, xcs):
+                f(x)
+            n += 1
+            el = time.perf_counter() - c0
+            if el >= args.cpu_seconds or n >= 2000:
+                break
+        result["cpu_baseline"] = {"value": elems * n / el, "unit": "elems/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"{n} passes over all {len(weights)} weight tensors with the ATen CPU operator the "
+                                            f"reference calls (oracle/torch_cpu.py parameters), {el:.1f} s",
+                                  "ms_per_call": el * 1e3 / n, "gpu_output_bit_equal": same,
+                                  "gpu_output_checked": f"all {len(weights)} outputs of the last timed step"}
+        if not same:
+            result["parity_error"] = "GPU output differs from the CPU oracle"
+    elif rank == 0 and world == 1 and not args.no_cpu and not dry:
         from oracle import torch_cpu
         f = torch_cpu.prepare(wl.quantizer, wl.kwargs)
         x_cpu = torch.from_numpy(x_np)

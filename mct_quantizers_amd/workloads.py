@@ -121,3 +121,36 @@ def make_workload(cfg: str, x: np.ndarray) -> Workload:
         return Workload("cfg5 WeightsPOT per-channel(axis0) 4b", "WeightsPOTInferableQuantizer",
                         dict(num_bits=4, threshold=thr, per_channel=True, channel_axis=0), x.shape, 1005)
     raise KeyError(cfg)
+
+
+# ---- a whole model's weights (the list a wrapped model re-quantizes per forward, quantize_wrapper.py:228-240) ----------
+
+def model_weight_shapes(name: str):
+    """Weight shapes of a model, in forward order.  "resnet50": the 53 convolutions + the classifier of ResNet-50
+    (25.5 M parameters); "linear16": sixteen 4096 x 4096 layers."""
+    if name == "resnet50":
+        shapes = [(64, 3, 7, 7)]
+        cin = 64
+        for width, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+            for b in range(blocks):
+                shapes += [(width, cin, 1, 1), (width, width, 3, 3), (width * 4, width, 1, 1)]
+                if b == 0:
+                    shapes.append((width * 4, cin, 1, 1))
+                cin = width * 4
+        shapes.append((1000, 2048))
+        return shapes
+    if name == "linear16":
+        return [(4096, 4096)] * 16
+    raise KeyError(name)
+
+
+def make_model_weights(name: str):
+    """[(x float32 array, constructor kwargs of WeightsSymmetricInferableQuantizer per channel along axis 0, 8 bit)] for
+    every weight of the model, from the portable generator (seed 2000 + k for tensor k; thresholds = the row maxima)."""
+    out = []
+    for k, shape in enumerate(model_weight_shapes(name)):
+        n = int(np.prod(shape))
+        x = (bell_f32(n, 2000 + k) * np.float32(0.05)).reshape(shape)
+        thr = [float(v) for v in np.max(np.abs(x.reshape(shape[0], -1)), axis=1)]
+        out.append((x, dict(num_bits=8, threshold=thr, per_channel=True, channel_axis=0)))
+    return out

@@ -321,6 +321,7 @@ def test_same_numel_reshape_is_not_served_by_a_stale_plan():
     (["--config", "cfg2", "--batched", "2", "--steps", "6", "--warmup", "2"], "batched_kernel<table>"),
     (["--config", "cfg3", "--batch", "2", "--steps", "12", "--warmup", "2"], "batched_kernel<table>"),
     (["--config", "cfg3", "--batch", "2", "--steps", "6", "--warmup", "2", "--stream-depth", "-1"], "flat_kernel"),
+    (["--config", "resnet50", "--steps", "6", "--warmup", "2"], "batched_kernel<table>"),
 ])
 def test_bench_lines_of_the_batched_and_stream_modes(args, key):
     """bench.py's --batched and activation-stream modes as the driver would run them: one JSON line, the kernel named,
@@ -345,6 +346,8 @@ def test_bench_lines_of_the_batched_and_stream_modes(args, key):
     assert d["cpu_baseline"]["gpu_output_bit_equal"] is True and d["value"] > 0
     per_launch = d["config"]["steps_per_launch"]
     assert rf["algorithmic_bytes_per_launch"] == d["config"]["per_gpu_elems"] * 8 * per_launch
+    if "resnet50" in args:
+        assert d["config"]["per_gpu_elems"] == 25502912 and d["config"]["tensors_per_step"] == 54
 
 
 @pytest.mark.gpu

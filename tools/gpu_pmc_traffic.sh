@@ -26,6 +26,7 @@ run_cfg() {   # name, bench args...
 }
 run_cfg cfg2
 run_cfg cfg2_batched16 --batched 16 --steps 60 --warmup 5
+run_cfg resnet50 --config resnet50 --steps 200 --warmup 10
 run_cfg cfg3_n64 --config cfg3 --batch 64
 run_cfg cfg3_n64_eager --config cfg3 --batch 64 --stream-depth -1
 run_cfg cfg3_n8 --config cfg3 --batch 8
@@ -52,4 +53,4 @@ stall_passes() {   # name, bench args...
 stall_passes cfg2
 stall_passes cfg2_batched16 --batched 16 --steps 30 --warmup 5
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
-for c in cfg2 cfg2_batched16 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
+for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done

@@ -5,7 +5,7 @@ python -m pytest tests -q -m gpu -x 2>&1 | tail -4 > gpurun_out/r03/pytest_gpu.l
 python bench.py --steps 20 --warmup 5 > gpurun_out/r03/bench_20.json 2> gpurun_out/r03/bench.err
 python bench.py > gpurun_out/r03/bench_default.json 2>> gpurun_out/r03/bench.err
 : > gpurun_out/r03/bench_all_configs.jsonl
-for args in "--config cfg1" "--config cfg2 --batched 16 --steps 100 --warmup 10" "--config cfg3 --batch 1" "--config cfg3 --batch 8" "--config cfg3 --batch 64" "--config cfg3 --batch 64 --stream-depth -1" "--config cfg3 --batch 256" "--config cfg4 --steps 300" "--config cfg5 --steps 300" "--config cfg5 --batched 4 --steps 100 --warmup 10"; do
+for args in "--config cfg1" "--config cfg2 --batched 16 --steps 100 --warmup 10" "--config cfg3 --batch 1" "--config cfg3 --batch 8" "--config cfg3 --batch 64" "--config cfg3 --batch 64 --stream-depth -1" "--config cfg3 --batch 256" "--config cfg4 --steps 300" "--config cfg5 --steps 300" "--config cfg5 --batched 4 --steps 100 --warmup 10" "--config resnet50 --steps 300 --warmup 20" "--config linear16 --steps 60 --warmup 5"; do
   python bench.py $args --no-cpu >> gpurun_out/r03/bench_all_configs.jsonl 2>> gpurun_out/r03/bench.err
 done
 python - <<'PY'

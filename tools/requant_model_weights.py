@@ -10,16 +10,8 @@ from mct_quantizers_amd.hip import native, ops
 Q = mq.pytorch_quantizers
 
 def resnet50_shapes():
-    shapes = [(64, 3, 7, 7)]
-    cin = 64
-    for width, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
-        for b in range(blocks):
-            shapes += [(width, cin, 1, 1), (width, width, 3, 3), (width * 4, width, 1, 1)]
-            if b == 0:
-                shapes.append((width * 4, cin, 1, 1))
-            cin = width * 4
-    shapes.append((1000, 2048))
-    return shapes
+    from mct_quantizers_amd import workloads
+    return workloads.model_weight_shapes("resnet50")
 
 LUT16 = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
 
