@@ -114,6 +114,7 @@ struct AffinePol {
     s_lane = (const float MCTQ_GLOBAL*)it.scales; z_lane = (const int32_t MCTQ_GLOBAL*)it.zps;
     op.scales = nullptr; op.zps = nullptr; op.lo = it.lo; op.hi = it.hi;
   }
+  __device__ __forceinline__ void pre() {}
   __device__ __forceinline__ void init(float*) {}
   __device__ __forceinline__ Param uniform(uint32_t c) const { return AffineOp::make(s_uniform[c], z_uniform ? z_uniform[c] : 0); }
   __device__ __forceinline__ Param lane(uint32_t c) const { return AffineOp::make(s_lane[c], z_lane ? z_lane[c] : 0); }
@@ -157,9 +158,23 @@ struct LutPol {
     op.step_round = it.step_round; op.table = nullptr; op.entries = it.entries;
     op.koff = 0.5f - 2.0f * it.cmin; op.kmax = (float)(it.entries - 1);
   }
+  // the table is requested BEFORE the tile's data loads and written to LDS after them: vector loads return in order, so
+  // a table read queued behind the data loads could not be staged before all of them had landed (LutTableOp::prefetch)
+  f32x2 pf[8];
+  __device__ __forceinline__ void pre() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = (int)threadIdx.x + i * kThreads;
+      if (j <= op.entries) pf[i] = table[j];
+    }
+  }
   __device__ __forceinline__ void init(float* smem) {      // every thread of the block: the table goes to LDS
     f32x2* dst = reinterpret_cast<f32x2*>(smem);
-    for (int j = threadIdx.x; j <= op.entries; j += kThreads) dst[j] = table[j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = (int)threadIdx.x + i * kThreads;
+      if (j <= op.entries) dst[j] = pf[i];
+    }
     __syncthreads();
     book.tab = dst; book.nan_q = dst[op.entries].x;
   }
@@ -199,7 +214,9 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, Pol& pol, floa
   TO MCTQ_GLOBAL* __restrict__ y = (TO MCTQ_GLOBAL*)it.y;
   const uint32_t inner = it.inner, channels = it.channels;
 
-  // data loads first; the table staging / row search / parameter fetch below run under their latency
+  // (an op's table reads first,) then the data loads; the LDS staging / row search / parameter fetch run under their latency
+  pol.pre();
+  __builtin_amdgcn_sched_barrier(0);
   typename io::VI v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
