@@ -7,6 +7,8 @@ snapshot to the GPU machine; it is git-ignored.
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -31,6 +33,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per checkout (several ranks or test workers may call build() at once): the others wait,
+    then find the library up to date."""
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(os.path.join(os.path.dirname(OUT), ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
@@ -41,6 +56,13 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
+    with _build_lock():
+        if not force and not needs_build():          # another process built it while this one waited
+            return OUT
+        return _build(verbose)
+
+
+def _build(verbose: bool) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libmctq_hip.so")
@@ -84,6 +106,13 @@ def build_binding(force: bool = False, verbose: bool = True) -> str:
     time through rpaths ($ORIGIN for the kernels' library, torch's own lib directory)."""
     if not force and not binding_needs_build():
         return BINDING_OUT
+    with _build_lock():
+        if not force and not binding_needs_build():
+            return BINDING_OUT
+        return _build_binding(verbose)
+
+
+def _build_binding(verbose: bool) -> str:
     import sysconfig
     import torch
     tdir = os.path.dirname(torch.__file__)
