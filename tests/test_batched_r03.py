@@ -7,6 +7,7 @@ Reference call site this launch serves: pytorch/quantize_wrapper.py:228-240 (one
 import copy
 import ctypes
 import io
+import os
 import struct
 
 import numpy as np
@@ -359,7 +360,7 @@ def test_fuzz_batched_launch_random_shapes_axes_dtypes_against_oracle(seed):
     source, every output compared with the oracle bit for bit."""
     from mct_quantizers_amd.hip import native, ops
     native.load()
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + 10 * int(os.environ.get("MCTQ_FUZZ_SEED", "0")))
     cases = []
     for k in range(150):
         rank = int(rng.integers(1, 5))
@@ -470,6 +471,81 @@ def test_batched_lut_launch_raw_abi_against_oracle_and_single_launches():
     # errors are reported before anything runs
     arr[0].entries = 5
     assert lib.mctq_lutt_batch_pack(arr, n_items, None, 0) == native.MCTQ_E_ARG and b"entries" in lib.mctq_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_batched_lut_launch_random_shapes_axes_dtypes_codebooks_against_oracle(seed):
+    """Seeded fuzz of the LUT flavour of the table-driven grid: random ranks and extents (rows shorter than / equal to /
+    longer than / not a multiple of a tile or a lane vector, outer > 1 so that channels wrap inside a tile and a lane
+    vector straddles two rows), channel axes or per tensor, three storage types, random integer codebooks of 2..32 entries
+    (signed and unsigned), ~120 items per launch; every output equals the oracle's literal op chain bit for bit and no
+    launch writes outside its tensor.  MCTQ_FUZZ_SEED shifts the seeds for soak runs."""
+    import os
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd.hip import native, ops
+    lib = native.load()
+    rng = np.random.default_rng(5000 + seed + 10 * int(os.environ.get("MCTQ_FUZZ_SEED", "0")))
+    dtc = {torch.float32: native.DT_F32, torch.float16: native.DT_F16, torch.bfloat16: native.DT_BF16}
+    books = []
+    for _ in range(6):
+        signed = bool(rng.random() < 0.6)
+        bits = 8
+        lo, hi = (-128, 127) if signed else (0, 255)
+        lut = np.unique(rng.integers(lo, hi + 1, size=int(rng.integers(2, 33)))).astype(np.float32)
+        mult, cmin, cmax = float(2 ** (bits - int(signed))), float(lo), float(hi)
+        books.append((list(map(float, lut)), bits, signed, ops.make_lut_table(lut, mult, cmin, cmax, "cuda"), mult, cmin, cmax))
+    n_items = int(os.environ.get("MCTQ_FUZZ_CASES", "120"))
+    arr = (native.LutItem * n_items)()
+    keep, cases = [], []
+    GUARD = 64
+    for k in range(n_items):
+        rank = int(rng.integers(1, 5))
+        while True:
+            shape = tuple(int(rng.choice([1, 2, 3, 5, 7, 8, 16, 31, 64, 100, 147, 256, 1000, 1031, 2048, 4100, 4608]))
+                          for _ in range(rank))
+            if 0 < int(np.prod(shape)) <= 200000:
+                break
+        axis = None if rng.random() < 0.2 else int(rng.integers(0, rank))
+        lut, bits, signed, table, mult, cmin, cmax = books[int(rng.integers(0, len(books)))]
+        dt = (torch.float32, torch.float32, torch.float16, torch.bfloat16)[int(rng.integers(0, 4))] if axis is not None else torch.float32
+        x = (rng.standard_normal(shape) * rng.uniform(0.3, 2.5)).astype(np.float32)
+        xd = torch.from_numpy(x).to(dt).cuda()
+        n = xd.numel()
+        frame = torch.full((n + 2 * GUARD,), 768.0, dtype=torch.float32, device="cuda")
+        it = arr[k]
+        it.x, it.y, it.table, it.entries = xd.data_ptr(), frame[GUARD:GUARD + n].data_ptr(), table.data_ptr(), table.shape[0] - 1
+        it.mult, it.clip_min, it.clip_max, it.dtype, it.step_round = mult, cmin, cmax, dtc[dt], 0
+        if axis is None:
+            thr = np.float32(rng.uniform(0.5, 3.0))
+            it.outer, it.channels, it.inner, it.thresholds = 1, 1, n, None
+            it.eps, it.thr_div, it.thr_mul = 0.0, float(np.float32(thr + np.float32(1e-8))), float(thr)
+            thr_np, td = np.float32([thr]), None
+        else:
+            c = shape[axis]
+            thr_np = rng.uniform(0.5, 3.0, size=c).astype(np.float32)
+            td = torch.from_numpy(thr_np).cuda()
+            it.outer, it.channels, it.inner = int(np.prod(shape[:axis])), c, int(np.prod(shape[axis + 1:]))
+            it.thresholds, it.eps, it.thr_div, it.thr_mul = td.data_ptr(), 1e-8, 0.0, 0.0
+        keep.append((xd, frame, td))
+        cases.append((xd.float().cpu().numpy(), lut, thr_np, signed, bits, axis, dt))
+    need = lib.mctq_lutt_batch_pack(arr, n_items, None, 0)
+    assert need > 0, lib.mctq_last_error()
+    host = np.zeros(need, np.uint8)
+    assert lib.mctq_lutt_batch_pack(arr, n_items, host.ctypes.data, need) == need
+    dev = torch.from_numpy(host).cuda()
+    assert lib.mctq_lutt_batch_run(host.ctypes.data, dev.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0, lib.mctq_last_error()
+    torch.cuda.synchronize()
+    for k, ((xw, lut, thr_np, signed, bits, axis, dt), (xd, frame, td)) in enumerate(zip(cases, keep)):
+        n = xd.numel()
+        got = frame[GUARD:GUARD + n].cpu().numpy().reshape(xw.shape)
+        if axis is None:
+            want = O.lut_quantize(xw, lut, thr_np, signed, bits, 1e-8)
+        else:
+            want = O.lut_quantize(xw, lut, thr_np, signed, bits, 1e-8, per_channel=True, channel_axis=axis)
+        assert bits_equal(got, np.asarray(want, np.float32)), f"#{k} {xw.shape} {dt} axis={axis} L={len(lut)}: {first_mismatch(got, want, xw)}"
+        edge = torch.cat([frame[:GUARD], frame[GUARD + n:]])
+        assert bool((edge == 768.0).all()), f"#{k} {xw.shape}: wrote outside its tensor"
 
 
 @pytest.mark.gpu
