@@ -410,7 +410,10 @@ typedef __attribute__((address_space(3))) void ql_lds_void;
 typedef const __attribute__((address_space(1))) void ql_glb_void;
 __device__ __attribute__((aligned(16))) const int8_t g_ql_zero_chunk[16] = {0};
 
-template <int BM, int BN, int kTileBK, bool A_U8>
+// ST: LDS buffers in the ring (ST - 1 tiles requested ahead).  ST = 2 is the form above; with ST >= 3 the barrier of a K
+// step only retires the copies of the tile about to be multiplied (counted vmcnt: copies return in issue order), so
+// ST - 2 later tiles stay in flight across it.
+template <int BM, int BN, int kTileBK, bool A_U8, int ST = 2>
 __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
   constexpr int CPR = kTileBK / 16;
   constexpr int SA = BM * CPR, SB = BN * CPR;        // slots of the A and of the B image
   constexpr int LT = (SA + SB) / 256;                // copies per thread per tile
-  __shared__ i32x4 lds[2][SA + SB];
+  static_assert(ST >= 2 && ST * (SA + SB) * 16 <= 160 * 1024 && (ST - 2) * LT <= 63, "ring depth");
+  __shared__ i32x4 lds[ST][SA + SB];
 
   // Blocks are dealt round-robin to the 8 XCDs, each with its own L2: an XCD takes CONSECUTIVE tiles, ordered in bands
   // of gm tile rows (all gm row tiles of a column tile first), so what one XCD reads -- gm x BM activation rows and its
@@ -465,6 +469,11 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
 
   const int64_t kt_n = (K + kTileBK - 1) / kTileBK;
   copy_tile(0, 0);
+  if constexpr (ST > 2) {
+#pragma unroll
+    for (int i = 1; i < ST - 1; ++i)
+      if (i < kt_n) copy_tile(i, i * (int64_t)kTileBK);
+  }
   int e_corr[TN];                                    // epilogue constants of this lane's columns, fetched early
   float e_scale[TN], e_bias[TN];
 #pragma unroll
@@ -474,10 +483,17 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
     e_scale[u] = sa * w_scales[n];
     e_bias[u] = bias ? bias[n] : 0.0f;
   }
+  int buf = 0, nbuf = ST - 1;                         // ring positions of tile kt and of tile kt + ST - 1
   for (int64_t kt = 0; kt < kt_n; ++kt) {
-    const int buf = (int)(kt & 1);
-    __syncthreads();                                  // tile kt has landed; buffer buf ^ 1 is free
-    if (kt + 1 < kt_n) copy_tile(buf ^ 1, (kt + 1) * (int64_t)kTileBK);
+    if constexpr (ST == 2) {
+      __syncthreads();                                // tile kt has landed; buffer buf ^ 1 is free
+    } else {
+      // tile kt has landed in every wave's share (its copies are older than the (ST - 2) * LT newest); the buffer of
+      // tile kt - 1, read before this barrier by every wave, is free
+      if (kt + ST - 2 < kt_n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((ST - 2) * LT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (kt + ST - 1 < kt_n) copy_tile(nbuf, (kt + ST - 1) * (int64_t)kTileBK);
 #pragma unroll
     for (int ks = 0; ks < kTileBK / 64; ++ks) {
       i32x4 fa[TM], fb[TN];
@@ -498,6 +514,8 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
         for (int u = 0; u < TN; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], acc[t][u], 0, 0, 0);
     }
+    buf = buf + 1 == ST ? 0 : buf + 1;
+    nbuf = nbuf + 1 == ST ? 0 : nbuf + 1;
   }
 
 #pragma unroll
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
   }
 }
 
-template <int BM, int BN, int BK, bool A_U8>
+template <int BM, int BN, int BK, bool A_U8, int ST = 2>
 static int launch_glds(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
                        const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
                        const QlOut& oq, hipStream_t stream) {
@@ -532,11 +550,13 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
     gm = (int)(sqrt(chunk * BN / BM) + 0.5);
   }
   gm = gm < 1 ? 1 : gm > mbl ? mbl : gm;
-  hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
+  hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8, ST>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
-  static const char* const kName = BM == 128 && BN == 128 ? (BK == 128 ? "qlinear_tiled_128x128x128" : "qlinear_tiled_128x128x256")
+  static const char* const kName2 = BM == 128 && BN == 128 ? (BK == 128 ? "qlinear_tiled_128x128x128" : "qlinear_tiled_128x128x256")
       : BM == 64 && BN == 128 ? "qlinear_tiled_64x128x128" : BK == 128 ? "qlinear_tiled_64x64x128" : "qlinear_tiled_64x64x256";
-  note_ql<A_U8>(kName, gm);
+  static const char* const kNameR = BM == 128 && BN == 128 ? "qlinear_tiled_ring_128x128x128" : BM == 64 && BN == 128 ? "qlinear_tiled_ring_64x128x128"
+      : BK == 128 ? "qlinear_tiled_ring_64x64x128" : "qlinear_tiled_ring_64x64x256";
+  note_ql<A_U8>(ST == 2 ? kName2 : kNameR, gm);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
 }
 
@@ -992,6 +1012,21 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
                          : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
     default: break;
   }
+#define MCTQ_QGR(BM_, BN_, BK_, ST_)                                                                                   \
+  (u8 ? launch_glds<BM_, BN_, BK_, true, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
+      : launch_glds<BM_, BN_, BK_, false, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  switch (g_ql_variant) {                            // rings of the tiled kernel: <tile code><stages>
+    case 6623: return MCTQ_QGR(64, 64, 256, 3);
+    case 6624: return MCTQ_QGR(64, 64, 256, 4);
+    case 663: return MCTQ_QGR(64, 64, 128, 3);
+    case 664: return MCTQ_QGR(64, 64, 128, 4);
+    case 666: return MCTQ_QGR(64, 64, 128, 6);
+    case 6123: return MCTQ_QGR(64, 128, 128, 3);
+    case 6124: return MCTQ_QGR(64, 128, 128, 4);
+    case 12123: return MCTQ_QGR(128, 128, 128, 3);
+    case 12124: return MCTQ_QGR(128, 128, 128, 4);
+    default: break;
+  }
   switch (g_ql_variant) {
     case 1212: return MCTQ_QG(128, 128, 128);
     case 612: return MCTQ_QG(64, 128, 128);
@@ -1033,9 +1068,14 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     if (blocks(128, 128) >= 2 * cus) return MCTQ_QG(128, 128, 128);
     if (blocks(64, 128) >= 2 * cus) return MCTQ_QG(64, 128, 128);
     if (blocks(64, 64) >= 4 * cus) return MCTQ_QG(64, 64, 128);
-    return MCTQ_QG(64, 64, 256);                     // few blocks: longer K steps hide the copy latency instead
+    // few blocks: longer K steps hide the copy latency instead; at most one block per CU: a third LDS buffer (two tiles
+    // requested ahead across the barrier) is worth 4-5 % (256 x 4096^2: 18.5 -> 17.7 us, profiles/r03/qlinear_ring_probe.log)
+    // -- the tiles run at the CU's copy issue rate, not at a latency, so deeper rings give nothing more
+    if (blocks(64, 64) <= cus) return MCTQ_QGR(64, 64, 256, 3);
+    return MCTQ_QG(64, 64, 256);
   }
 #undef MCTQ_QG
+#undef MCTQ_QGR
 #undef MCTQ_QW
 #undef MCTQ_QL
 #undef MCTQ_QLL
