@@ -554,9 +554,10 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
   static const char* const kName2 = BM == 128 && BN == 128 ? (BK == 128 ? "qlinear_tiled_128x128x128" : "qlinear_tiled_128x128x256")
       : BM == 64 && BN == 128 ? "qlinear_tiled_64x128x128" : BK == 128 ? "qlinear_tiled_64x64x128" : "qlinear_tiled_64x64x256";
-  static const char* const kNameR = BM == 128 && BN == 128 ? "qlinear_tiled_ring_128x128x128" : BM == 64 && BN == 128 ? "qlinear_tiled_ring_64x128x128"
+  static const char* const kNameR = BM == 128 && BN == 64 ? (BK == 128 ? "qlinear_tiled_ring_128x64x128" : "qlinear_tiled_ring_128x64x256")
+      : BM == 128 && BN == 128 ? "qlinear_tiled_ring_128x128x128" : BM == 64 && BN == 128 ? "qlinear_tiled_ring_64x128x128"
       : BK == 128 ? "qlinear_tiled_ring_64x64x128" : "qlinear_tiled_ring_64x64x256";
-  note_ql<A_U8>(ST == 2 ? kName2 : kNameR, gm);
+  note_ql<A_U8>(ST == 2 && !(BM == 128 && BN == 64) ? kName2 : kNameR, gm);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
 }
 
@@ -1016,6 +1017,10 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
   switch (g_ql_variant) {                            // rings of the tiled kernel: <tile code><stages>
+    case 12623: return MCTQ_QGR(128, 64, 256, 3);
+    case 12622: return MCTQ_QGR(128, 64, 256, 2);
+    case 12613: return MCTQ_QGR(128, 64, 128, 3);
+    case 12614: return MCTQ_QGR(128, 64, 128, 4);
     case 6623: return MCTQ_QGR(64, 64, 256, 3);
     case 6624: return MCTQ_QGR(64, 64, 256, 4);
     case 663: return MCTQ_QGR(64, 64, 128, 3);
@@ -1059,20 +1064,28 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
                 : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
     if (w48_rate > old_rate) return MCTQ_QW(4, 8);
   }
-  // One round of whole 128 x 128 tiles (1024 x 4096^2): the asm-pinned 4-stage kernel at one block per CU runs at the CU's
-  // operand intake (~40 GB/s of direct-to-LDS copies per CU: 1 MiB of operands per tile in 26 us, profiles/r03/
-  // qlinear_mid_probe.log) like the compiler-scheduled tiles below, but without their second wave of blocks: 30.7 vs 34.6 us.
-  if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0 && blocks(128, 128) >= cus && blocks(128, 128) < 2 * cus)
+  // Between the two regimes every tile shape runs at the CU's intake of direct-to-LDS copies (an issue rate: about 36 KiB/us
+  // for one resident block per CU, 48-54 for two, 64 for three; profiles/r03/qlinear_tile_sweep.log, EXPERIMENTS.md), so
+  // the time is (operand bytes of a tile) x (tiles a CU must take) / rate and the choice is the tile that makes that least.
+  // At most one 64 x 64 block per CU: a third LDS buffer (two tiles requested ahead across the barrier) is worth 4-5 %
+  // (256 x 4096^2: 18.5 -> 17.7 us, qlinear_ring_probe.log); deeper rings give nothing more.
+  if (blocks(64, 64) <= cus) return MCTQ_QGR(64, 64, 256, 3);
+  // Whole 128 x 128 tiles, at most one per CU, where 64 x 64 tiles would need more than one round of two per CU: the
+  // asm-pinned 4-stage kernel (640 ... 1024 x 4096^2: 28-30 us against 36-39; 256 x 11008 x 4096: 30.6 against 39.5).
+  if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0 && blocks(128, 128) <= cus && blocks(64, 64) > 2 * cus)
     return MCTQ_QW(4, 4);
-  {                                                  // tiled: the largest tile that still gives every CU two blocks
-    if (blocks(128, 128) >= 2 * cus) return MCTQ_QG(128, 128, 128);
-    if (blocks(64, 128) >= 2 * cus) return MCTQ_QG(64, 128, 128);
-    if (blocks(64, 64) >= 4 * cus) return MCTQ_QG(64, 64, 128);
-    // few blocks: longer K steps hide the copy latency instead; at most one block per CU: a third LDS buffer (two tiles
-    // requested ahead across the barrier) is worth 4-5 % (256 x 4096^2: 18.5 -> 17.7 us, profiles/r03/qlinear_ring_probe.log)
-    // -- the tiles run at the CU's copy issue rate, not at a latency, so deeper rings give nothing more
-    if (blocks(64, 64) <= cus) return MCTQ_QGR(64, 64, 256, 3);
-    return MCTQ_QG(64, 64, 256);
+  {
+    const auto cost = [&](int bm, int bn, int occ, double r1, double r2, double r3) {      // us, up to a common constant
+      const double kib = (double)(bm + bn) * (double)K / 1024.0, rate[4] = {1.0, r1, r2, r3};
+      const int64_t per_cu = (blocks(bm, bn) + cus - 1) / cus, full = per_cu / occ, rem = per_cu % occ;
+      return (double)(full * occ) * kib / rate[occ] + (rem ? (double)rem * kib / rate[rem] : 0.0);
+    };
+    const double c66 = cost(64, 64, 2, 36, 54, 0), c126 = cost(128, 64, 2, 36, 54, 0), c612 = cost(64, 128, 3, 36, 50, 64),
+                 c1212 = cost(128, 128, 2, 30, 48, 0);
+    if (c66 <= c126 && c66 <= c612 && c66 <= c1212) return MCTQ_QG(64, 64, 256);
+    if (c126 <= c612 && c126 <= c1212) return MCTQ_QGR(128, 64, 128, 3);
+    if (c612 <= c1212) return MCTQ_QG(64, 128, 128);
+    return MCTQ_QG(128, 128, 128);
   }
 #undef MCTQ_QG
 #undef MCTQ_QGR

@@ -13,7 +13,7 @@ from mct_quantizers_amd.hip import native
 HBM_PEAK_GBS, I8_PEAK_TOPS = 8000.0, 5000.0
 GIT_HEAD = sys.argv[1] if len(sys.argv) > 1 else os.environ.get("MCTQ_GIT_HEAD", "unknown")
 lib = native.load(); dev = torch.device("cuda"); S = lambda: torch.cuda.current_stream().cuda_stream
-for (M, N, K) in [(16, 4096, 4096), (16, 11008, 4096), (32, 4096, 4096), (64, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (4096, 4096, 4096), (4096, 4096, 11008), (8192, 8192, 8192)]:
+for (M, N, K) in [(16, 4096, 4096), (16, 11008, 4096), (32, 4096, 4096), (64, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (256, 4096, 4096), (256, 11008, 4096), (512, 4096, 4096), (768, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (4096, 4096, 4096), (4096, 4096, 11008), (8192, 8192, 8192)]:
     ring = max(2, int(np.ceil(400e6 / (N * K))))
     ws = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(ring)]
     a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)

@@ -11,7 +11,10 @@ from mct_quantizers_amd.hip import native
 lib = native.load()
 dev = torch.device("cuda")
 S = lambda: torch.cuda.current_stream().cuda_stream
-shapes = [(int(a), 4096, 4096) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "256,512,1024,2048".split(","))]
+def _shape(a):                                   # "M" (4096 x 4096 weights) or "MxNxK"
+    p = [int(v) for v in a.split("x")]
+    return (p[0], 4096, 4096) if len(p) == 1 else tuple(p)
+shapes = [_shape(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "256,512,1024,2048".split(","))]
 variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,662,66,612,1212,12122,2548,2560".split(","))]
 bands = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,1".split(","))]
 PEAK = 5000.0
@@ -35,7 +38,7 @@ for (M, N, K) in shapes:
                                            bias.data_ptr(), ys[i % ring].data_ptr(), M, N, K, S())
             rc = call(0)
             if rc != 0:
-                print(f"M={M:5d} variant {v:6d} band {b}: not applicable ({lib.mctq_last_error().decode()[:60]})")
+                print(f"M={M:5d} N={N} K={K} variant {v:6d} band {b}: not applicable ({lib.mctq_last_error().decode()[:60]})")
                 continue
             torch.cuda.synchronize()
             ok = bool(torch.equal(ys[0], want))
@@ -47,5 +50,5 @@ for (M, N, K) in shapes:
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             tops = 2.0 * M * N * K / us / 1e6
-            print(f"M={M:5d} variant {v:6d} band {b}: {us:8.2f} us  {tops:7.1f} TOP/s  {tops / PEAK:.3f} of int8 peak  exact={ok}", flush=True)
+            print(f"M={M:5d} N={N} K={K} variant {v:6d} band {b}: {us:8.2f} us  {tops:7.1f} TOP/s  {tops / PEAK:.3f} of int8 peak  exact={ok}", flush=True)
 lib.mctq_set_tuning(b"ql_variant", 0); lib.mctq_set_tuning(b"ql_band", 0)
