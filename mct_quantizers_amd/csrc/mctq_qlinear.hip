@@ -552,12 +552,10 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
   gm = gm < 1 ? 1 : gm > mbl ? mbl : gm;
   hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8, ST>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
-  static const char* const kName2 = BM == 128 && BN == 128 ? (BK == 128 ? "qlinear_tiled_128x128x128" : "qlinear_tiled_128x128x256")
-      : BM == 64 && BN == 128 ? "qlinear_tiled_64x128x128" : BK == 128 ? "qlinear_tiled_64x64x128" : "qlinear_tiled_64x64x256";
-  static const char* const kNameR = BM == 128 && BN == 64 ? (BK == 128 ? "qlinear_tiled_ring_128x64x128" : "qlinear_tiled_ring_128x64x256")
-      : BM == 128 && BN == 128 ? "qlinear_tiled_ring_128x128x128" : BM == 64 && BN == 128 ? "qlinear_tiled_ring_64x128x128"
-      : BK == 128 ? "qlinear_tiled_ring_64x64x128" : "qlinear_tiled_ring_64x64x256";
-  note_ql<A_U8>(ST == 2 && !(BM == 128 && BN == 64) ? kName2 : kNameR, gm);
+  static char name[48];                              // "qlinear_tiled[_ring]_<BM>x<BN>x<BK>", formatted once per instantiation
+  static const bool named = (snprintf(name, sizeof(name), "qlinear_tiled%s_%dx%dx%d", ST > 2 || (BM == 128 && BN == 64) ? "_ring" : "", BM, BN, BK), true);
+  (void)named;
+  note_ql<A_U8>(name, gm);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
 }
 
@@ -1017,6 +1015,10 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
   switch (g_ql_variant) {                            // rings of the tiled kernel: <tile code><stages>
+    case 3263: return MCTQ_QGR(32, 64, 256, 3);
+    case 3262: return MCTQ_QGR(32, 64, 256, 2);
+    case 6433: return MCTQ_QGR(64, 32, 256, 3);
+    case 3233: return MCTQ_QGR(32, 32, 256, 3);
     case 12623: return MCTQ_QGR(128, 64, 256, 3);
     case 12622: return MCTQ_QGR(128, 64, 256, 2);
     case 12613: return MCTQ_QGR(128, 64, 128, 3);
@@ -1047,9 +1049,6 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   // 8.8 -> 8.4, 64 x 4096^2 12.5 -> 10.0, 64 x 4096 x 11008 28.5 -> 20.5, 128 x 4096^2 18.2 -> 15.3).
   if (M <= 16) return MCTQ_QLL(8, 1);
   if (M <= 32) return MCTQ_QLL(8, 2);
-  // up to 128 rows: weight streaming, unless there are enough 64 x 64 tiles to occupy more than half the chip --
-  // then the tiled kernel's shared activation tile wins (64 x 11008 x 4096: 19.1 vs 25.5 us; 256 x 4096^2: 18.7 vs 26.6)
-  if (M <= 128 && blocks(64, 64) * 2 <= cus) return MCTQ_QLL(8, 4);
   // Many rows and columns, whole tiles: the 256 x 256 ping-pong kernel (2.2-2.3 POP/s against 1.5 for the 128 x 128
   // tiles; profiles/r02/qgemm_wide_probe.log) or, when there are too few such tiles for the chip, 128 x 256 wave-wide
   // tiles -- weighed by how full their last round of blocks is (one block per CU; the 128 x 128 kernel fits two).
@@ -1064,28 +1063,43 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
                 : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
     if (w48_rate > old_rate) return MCTQ_QW(4, 8);
   }
-  // Between the two regimes every tile shape runs at the CU's intake of direct-to-LDS copies (an issue rate: about 36 KiB/us
-  // for one resident block per CU, 48-54 for two, 64 for three; profiles/r03/qlinear_tile_sweep.log, EXPERIMENTS.md), so
-  // the time is (operand bytes of a tile) x (tiles a CU must take) / rate and the choice is the tile that makes that least.
-  // At most one 64 x 64 block per CU: a third LDS buffer (two tiles requested ahead across the barrier) is worth 4-5 %
-  // (256 x 4096^2: 18.5 -> 17.7 us, qlinear_ring_probe.log); deeper rings give nothing more.
-  if (blocks(64, 64) <= cus) return MCTQ_QGR(64, 64, 256, 3);
-  // Whole 128 x 128 tiles, at most one per CU, where 64 x 64 tiles would need more than one round of two per CU: the
-  // asm-pinned 4-stage kernel (640 ... 1024 x 4096^2: 28-30 us against 36-39; 256 x 11008 x 4096: 30.6 against 39.5).
-  if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0 && blocks(128, 128) <= cus && blocks(64, 64) > 2 * cus)
-    return MCTQ_QW(4, 4);
+  // Between the two regimes every kernel runs at the CU's intake of direct-to-LDS copies, an issue rate: about 36 KiB/us
+  // with one resident block per CU, 48-58 with two, 64 with three (profiles/r03/qlinear_tile_sweep.log,
+  // qlinear_small_tiles.log, EXPERIMENTS.md).  So the time of a launch is (operand bytes of a block) x (blocks the busiest
+  // CU takes) / rate, and the choice is the kernel that makes that least: the weight-streaming kernel (a block = 16
+  // columns x all rows, 64 rows per pass), 32 x 32 ... 128 x 128 tiles with two or three LDS buffers, and the asm-pinned
+  // 128 x 128 kernel where the problem is whole tiles.  Earlier candidates win ties (smaller tiles first).
   {
-    const auto cost = [&](int bm, int bn, int occ, double r1, double r2, double r3) {      // us, up to a common constant
+    const auto tiles_cost = [&](int bm, int bn, int occ, double r1, double r2, double r3) {   // us, up to a common constant
       const double kib = (double)(bm + bn) * (double)K / 1024.0, rate[4] = {1.0, r1, r2, r3};
       const int64_t per_cu = (blocks(bm, bn) + cus - 1) / cus, full = per_cu / occ, rem = per_cu % occ;
       return (double)(full * occ) * kib / rate[occ] + (rem ? (double)rem * kib / rate[rem] : 0.0);
     };
-    const double c66 = cost(64, 64, 2, 36, 54, 0), c126 = cost(128, 64, 2, 36, 54, 0), c612 = cost(64, 128, 3, 36, 50, 64),
-                 c1212 = cost(128, 128, 2, 30, 48, 0);
-    if (c66 <= c126 && c66 <= c612 && c66 <= c1212) return MCTQ_QG(64, 64, 256);
-    if (c126 <= c612 && c126 <= c1212) return MCTQ_QGR(128, 64, 128, 3);
-    if (c612 <= c1212) return MCTQ_QG(64, 128, 128);
-    return MCTQ_QG(128, 128, 128);
+    enum { kStream, kT33, kT63, kT66R, kT66, kT126, kT612, kT1212, kW44 };
+    double best = 1e300;
+    int pick = kT66;
+    const auto consider = [&](int id, double c) { if (c < best) { best = c; pick = id; } };
+    if (M <= 128)                                    // 80 K bytes per pass and block: 16 weight rows + 64 activation rows
+      consider(kStream, (double)(((N + 15) / 16 + cus - 1) / cus) * (double)((M + 63) / 64) * 80.0 * (double)K / 1024.0 / 47.0);
+    consider(kT33, tiles_cost(32, 32, 3, 36, 58, 64));
+    consider(kT63, tiles_cost(64, 32, 2, 36, 54, 0));
+    consider(kT66R, tiles_cost(64, 64, 1, 36, 0, 0));
+    consider(kT66, tiles_cost(64, 64, 2, 36, 54, 0));
+    consider(kT126, tiles_cost(128, 64, 2, 36, 54, 0));
+    consider(kT612, tiles_cost(64, 128, 3, 36, 50, 64));
+    consider(kT1212, tiles_cost(128, 128, 2, 30, 48, 0));
+    if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0) consider(kW44, tiles_cost(128, 128, 2, 38, 43, 0));
+    switch (pick) {
+      case kStream: return MCTQ_QLL(8, 4);
+      case kT33: return MCTQ_QGR(32, 32, 256, 3);
+      case kT63: return MCTQ_QGR(64, 32, 256, 3);
+      case kT66R: return MCTQ_QGR(64, 64, 256, 3);
+      case kT126: return MCTQ_QGR(128, 64, 128, 3);
+      case kT612: return MCTQ_QG(64, 128, 128);
+      case kT1212: return MCTQ_QG(128, 128, 128);
+      case kW44: return MCTQ_QW(4, 4);
+      default: return MCTQ_QG(64, 64, 256);
+    }
   }
 #undef MCTQ_QG
 #undef MCTQ_QGR
