@@ -413,16 +413,24 @@ __device__ __attribute__((aligned(16))) const int8_t g_ql_zero_chunk[16] = {0};
 // ST: LDS buffers in the ring (ST - 1 tiles requested ahead).  ST = 2 is the form above; with ST >= 3 the barrier of a K
 // step only retires the copies of the tile about to be multiplied (counted vmcnt: copies return in issue order), so
 // ST - 2 later tiles stay in flight across it.
-template <int BM, int BN, int kTileBK, bool A_U8, int ST = 2>
-__global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
+// KG: wave groups (1 or 2).  With KG = 2 the block has 8 waves: both groups copy (twice the waves issuing copies -- the
+// tiles run at the copy issue rate, which grows with the waves that issue), group g multiplies the g-th half of the
+// 64-byte sub-steps of every K tile into its own accumulators, and the two partial sums meet in LDS at the end (exact
+// integer sums: the order does not matter).
+template <int BM, int BN, int kTileBK, bool A_U8, int ST = 2, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
     int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, int gm, QlOut oq) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int CPR = kTileBK / 16;
   constexpr int SA = BM * CPR, SB = BN * CPR;        // slots of the A and of the B image
-  constexpr int LT = (SA + SB) / 256;                // copies per thread per tile
+  constexpr int T = 256 * KG;                        // threads
+  constexpr int LT = (SA + SB) / T;                  // copies per thread per tile
+  constexpr int NKS = kTileBK / 64 / KG;             // 64-byte sub-steps of a tile per wave group
   static_assert(ST >= 2 && ST * (SA + SB) * 16 <= 160 * 1024 && (ST - 2) * LT <= 63, "ring depth");
+  static_assert((KG == 1 || KG == 2) && (SA + SB) % T == 0 && LT >= 1 && (kTileBK / 64) % KG == 0, "wave groups");
+  static_assert(KG == 1 || 4 * TM * TN * 64 <= ST * (SA + SB), "the partial sums of group 1 must fit the ring");
   __shared__ i32x4 lds[ST][SA + SB];
 
   // Blocks are dealt round-robin to the 8 XCDs, each with its own L2: an XCD takes CONSECUTIVE tiles, ordered in bands
@@ -438,14 +446,15 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
   const int m0 = mb * BM, n0 = nb * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = wave >> 2, w4 = wave & 3;           // wave group, position in the 2 x 2 arrangement
+  const int wm = w4 >> 1, wn = w4 & 1;
   const int r = lane & 15, g = lane >> 4;
 
   const int8_t* src[LT];        // source of this thread's j-th slot at k = 0
   int koff[LT];                 // byte offset of that chunk inside the K step (ragged-K test)
 #pragma unroll
   for (int j = 0; j < LT; ++j) {
-    const int s = j * 256 + tid;
+    const int s = j * T + tid;
     const bool is_a = s < SA;
     const int q = is_a ? s : s - SA;
     const int row = q / CPR, c = (q % CPR) ^ ql_swizzle<CPR>(row);
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
 #pragma unroll
     for (int j = 0; j < LT; ++j) {
       const int8_t* p = (full || k0 + koff[j] < K) ? src[j] + k0 : g_ql_zero_chunk;     // beyond K: zeros
-      __builtin_amdgcn_global_load_lds((ql_glb_void*)p, (ql_lds_void*)&lds[buf][j * 256 + wave * 64], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((ql_glb_void*)p, (ql_lds_void*)&lds[buf][j * T + wave * 64], 16, 0, 0);
     }
   };
 
@@ -495,7 +504,8 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
     }
     if (kt + ST - 1 < kt_n) copy_tile(nbuf, (kt + ST - 1) * (int64_t)kTileBK);
 #pragma unroll
-    for (int ks = 0; ks < kTileBK / 64; ++ks) {
+    for (int ksi = 0; ksi < NKS; ++ksi) {
+      const int ks = kg * NKS + ksi;
       i32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
@@ -518,6 +528,23 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
     nbuf = nbuf + 1 == ST ? 0 : nbuf + 1;
   }
 
+  if constexpr (KG == 2) {                            // group 1 hands its partial sums to group 0 through the (dead) ring
+    i32x4* red = &lds[0][0];
+    __syncthreads();                                  // every wave has read its last fragments, every copy has landed
+    if (kg == 1) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) red[((w4 * TM + t) * TN + u) * 64 + lane] = acc[t][u];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int u = 0; u < TN; ++u) acc[t][u] += red[((w4 * TM + t) * TN + u) * 64 + lane];
+  }
+
 #pragma unroll
   for (int u = 0; u < TN; ++u) {
     const int n = n0 + wn * (BN / 2) + 16 * u + r;
@@ -537,7 +564,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_glds_kernel(
   }
 }
 
-template <int BM, int BN, int BK, bool A_U8, int ST = 2>
+template <int BM, int BN, int BK, bool A_U8, int ST = 2, int KG = 1>
 static int launch_glds(const void* a, const int8_t* w, const float* w_scales, const int32_t* w_rowsum,
                        const float* bias, void* y, int64_t M, int64_t N, int64_t K, int za, float sa,
                        const QlOut& oq, hipStream_t stream) {
@@ -550,10 +577,11 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
     gm = (int)(sqrt(chunk * BN / BM) + 0.5);
   }
   gm = gm < 1 ? 1 : gm > mbl ? mbl : gm;
-  hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8, ST>), dim3((unsigned)(mbl * nbl)), dim3(256), 0, stream,
+  hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8, ST, KG>), dim3((unsigned)(mbl * nbl)), dim3(256 * KG), 0, stream,
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
   static char name[48];                              // "qlinear_tiled[_ring]_<BM>x<BN>x<BK>", formatted once per instantiation
-  static const bool named = (snprintf(name, sizeof(name), "qlinear_tiled%s_%dx%dx%d", ST > 2 || (BM == 128 && BN == 64) ? "_ring" : "", BM, BN, BK), true);
+  static const bool named = (snprintf(name, sizeof(name), "qlinear_tiled%s%s_%dx%dx%d", ST > 2 || (BM == 128 && BN == 64) ? "_ring" : "",
+                                      KG == 2 ? "_8waves" : "", BM, BN, BK), true);
   (void)named;
   note_ql<A_U8>(name, gm);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
@@ -1014,6 +1042,20 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
 #define MCTQ_QGR(BM_, BN_, BK_, ST_)                                                                                   \
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+#define MCTQ_QG8(BM_, BN_, BK_, ST_)                                                                                       \
+  (u8 ? launch_glds<BM_, BN_, BK_, true, ST_, 2>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
+      : launch_glds<BM_, BN_, BK_, false, ST_, 2>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  switch (g_ql_variant) {                            // 8-wave blocks (two wave groups): 8<tile code><stages>
+    case 86623: return MCTQ_QG8(64, 64, 256, 3);
+    case 86622: return MCTQ_QG8(64, 64, 256, 2);
+    case 86633: return MCTQ_QG8(64, 64, 128, 3);
+    case 86433: return MCTQ_QG8(64, 32, 256, 3);
+    case 83233: return MCTQ_QG8(32, 32, 256, 3);
+    case 812613: return MCTQ_QG8(128, 64, 128, 3);
+    case 812123: return MCTQ_QG8(128, 128, 128, 3);
+    case 812122: return MCTQ_QG8(128, 128, 128, 2);
+    default: break;
+  }
   switch (g_ql_variant) {                            // rings of the tiled kernel: <tile code><stages>
     case 3263: return MCTQ_QGR(32, 64, 256, 3);
     case 3262: return MCTQ_QGR(32, 64, 256, 2);
@@ -1067,34 +1109,38 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   // with one resident block per CU, 48-58 with two, 64 with three (profiles/r03/qlinear_tile_sweep.log,
   // qlinear_small_tiles.log, EXPERIMENTS.md).  So the time of a launch is (operand bytes of a block) x (blocks the busiest
   // CU takes) / rate, and the choice is the kernel that makes that least: the weight-streaming kernel (a block = 16
-  // columns x all rows, 64 rows per pass), 32 x 32 ... 128 x 128 tiles with two or three LDS buffers, and the asm-pinned
-  // 128 x 128 kernel where the problem is whole tiles.  Earlier candidates win ties (smaller tiles first).
+  // columns x all rows, 64 rows per pass), 32 x 32 ... 128 x 128 tiles with two or three LDS buffers and four or eight
+  // waves (eight: two wave groups that both copy and each multiply half of a K tile -- more waves issuing copies raise the
+  // rate by 10-25 %), and the asm-pinned 128 x 128 kernel where the problem is whole tiles.  Earlier candidates win ties (smaller tiles first).
   {
     const auto tiles_cost = [&](int bm, int bn, int occ, double r1, double r2, double r3) {   // us, up to a common constant
       const double kib = (double)(bm + bn) * (double)K / 1024.0, rate[4] = {1.0, r1, r2, r3};
       const int64_t per_cu = (blocks(bm, bn) + cus - 1) / cus, full = per_cu / occ, rem = per_cu % occ;
       return (double)(full * occ) * kib / rate[occ] + (rem ? (double)rem * kib / rate[rem] : 0.0);
     };
-    enum { kStream, kT33, kT63, kT66R, kT66, kT126, kT612, kT1212, kW44 };
+    enum { kStream, kT33, kT63, kT66R, kT66, kT66S, kT126, kT612, kT1212, kW44 };
     double best = 1e300;
     int pick = kT66;
     const auto consider = [&](int id, double c) { if (c < best) { best = c; pick = id; } };
     if (M <= 128)                                    // 80 K bytes per pass and block: 16 weight rows + 64 activation rows
       consider(kStream, (double)(((N + 15) / 16 + cus - 1) / cus) * (double)((M + 63) / 64) * 80.0 * (double)K / 1024.0 / 47.0);
-    consider(kT33, tiles_cost(32, 32, 3, 36, 58, 64));
-    consider(kT63, tiles_cost(64, 32, 2, 36, 54, 0));
-    consider(kT66R, tiles_cost(64, 64, 1, 36, 0, 0));
-    consider(kT66, tiles_cost(64, 64, 2, 36, 54, 0));
-    consider(kT126, tiles_cost(128, 64, 2, 36, 54, 0));
+    // 8-wave blocks (two wave groups, 3-buffer ring): rates fitted on profiles/r03/qlinear_8waves.log
+    consider(kT33, tiles_cost(32, 32, 3, 42, 63, 65));
+    consider(kT63, tiles_cost(64, 32, 2, 50, 61, 0));
+    consider(kT66R, tiles_cost(64, 64, 1, 46, 0, 0));
+    consider(kT66, tiles_cost(64, 64, 2, 36, 54, 0));           // 4 waves, two buffers, two blocks per CU
+    consider(kT66S, tiles_cost(64, 64, 3, 36, 56, 59));         // 8 waves, 128-byte K steps, three blocks per CU
+    consider(kT126, tiles_cost(128, 64, 2, 44, 54, 0));
     consider(kT612, tiles_cost(64, 128, 3, 36, 50, 64));
     consider(kT1212, tiles_cost(128, 128, 2, 30, 48, 0));
     if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0) consider(kW44, tiles_cost(128, 128, 2, 38, 43, 0));
     switch (pick) {
       case kStream: return MCTQ_QLL(8, 4);
-      case kT33: return MCTQ_QGR(32, 32, 256, 3);
-      case kT63: return MCTQ_QGR(64, 32, 256, 3);
-      case kT66R: return MCTQ_QGR(64, 64, 256, 3);
-      case kT126: return MCTQ_QGR(128, 64, 128, 3);
+      case kT33: return MCTQ_QG8(32, 32, 256, 3);
+      case kT63: return MCTQ_QG8(64, 32, 256, 3);
+      case kT66R: return MCTQ_QG8(64, 64, 256, 3);
+      case kT66S: return MCTQ_QG8(64, 64, 128, 3);
+      case kT126: return MCTQ_QG8(128, 64, 128, 3);
       case kT612: return MCTQ_QG(64, 128, 128);
       case kT1212: return MCTQ_QG(128, 128, 128);
       case kW44: return MCTQ_QW(4, 4);
@@ -1103,6 +1149,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   }
 #undef MCTQ_QG
 #undef MCTQ_QGR
+#undef MCTQ_QG8
 #undef MCTQ_QW
 #undef MCTQ_QL
 #undef MCTQ_QLL
