@@ -413,7 +413,7 @@ __device__ __attribute__((aligned(16))) const int8_t g_ql_zero_chunk[16] = {0};
 // ST: LDS buffers in the ring (ST - 1 tiles requested ahead).  ST = 2 is the form above; with ST >= 3 the barrier of a K
 // step only retires the copies of the tile about to be multiplied (counted vmcnt: copies return in issue order), so
 // ST - 2 later tiles stay in flight across it.
-// KG: wave groups (1 or 2).  With KG = 2 the block has 8 waves: both groups copy (twice the waves issuing copies -- the
+// KG: wave groups (1, 2 or 4).  With KG = 2 the block has 8 waves (4: 16 waves, the groups' sums meet pairwise): both groups copy (twice the waves issuing copies -- the
 // tiles run at the copy issue rate, which grows with the waves that issue), group g multiplies the g-th half of the
 // 64-byte sub-steps of every K tile into its own accumulators, and the two partial sums meet in LDS at the end (exact
 // integer sums: the order does not matter).
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
   constexpr int LT = (SA + SB) / T;                  // copies per thread per tile
   constexpr int NKS = kTileBK / 64 / KG;             // 64-byte sub-steps of a tile per wave group
   static_assert(ST >= 2 && ST * (SA + SB) * 16 <= 160 * 1024 && (ST - 2) * LT <= 63, "ring depth");
-  static_assert((KG == 1 || KG == 2) && (SA + SB) % T == 0 && LT >= 1 && (kTileBK / 64) % KG == 0, "wave groups");
-  static_assert(KG == 1 || 4 * TM * TN * 64 <= ST * (SA + SB), "the partial sums of group 1 must fit the ring");
+  static_assert((KG == 1 || KG == 2 || KG == 4) && (SA + SB) % T == 0 && LT >= 1 && (kTileBK / 64) % KG == 0, "wave groups");
+  static_assert(KG == 1 || (KG / 2) * 4 * TM * TN * 64 <= ST * (SA + SB), "the partial sums of half the groups must fit the ring");
   __shared__ i32x4 lds[ST][SA + SB];
 
   // Blocks are dealt round-robin to the 8 XCDs, each with its own L2: an XCD takes CONSECUTIVE tiles, ordered in bands
@@ -528,21 +528,26 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
     nbuf = nbuf + 1 == ST ? 0 : nbuf + 1;
   }
 
-  if constexpr (KG == 2) {                            // group 1 hands its partial sums to group 0 through the (dead) ring
-    i32x4* red = &lds[0][0];
-    __syncthreads();                                  // every wave has read its last fragments, every copy has landed
-    if (kg == 1) {
+  if constexpr (KG > 1) {             // the upper half of the groups hands its partial sums to the lower half through the
+    i32x4* red = &lds[0][0];          // (dead) ring, until group 0 holds the whole sum
 #pragma unroll
-      for (int t = 0; t < TM; ++t)
+    for (int h = KG / 2; h >= 1; h >>= 1) {
+      __syncthreads();                // every wave has read its last fragments / partial sums, every copy has landed
+      if (kg >= h && kg < 2 * h) {
 #pragma unroll
-        for (int u = 0; u < TN; ++u) red[((w4 * TM + t) * TN + u) * 64 + lane] = acc[t][u];
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) red[((((kg - h) * 4 + w4) * TM + t) * TN + u) * 64 + lane] = acc[t][u];
+      }
+      __syncthreads();
+      if (kg < h) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] += red[(((kg * 4 + w4) * TM + t) * TN + u) * 64 + lane];
+      }
     }
-    __syncthreads();
-    if (kg == 1) return;
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-      for (int u = 0; u < TN; ++u) acc[t][u] += red[((w4 * TM + t) * TN + u) * 64 + lane];
+    if (kg != 0) return;
   }
 
 #pragma unroll
@@ -581,7 +586,7 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
                      (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
   static char name[48];                              // "qlinear_tiled[_ring]_<BM>x<BN>x<BK>", formatted once per instantiation
   static const bool named = (snprintf(name, sizeof(name), "qlinear_tiled%s%s_%dx%dx%d", ST > 2 || (BM == 128 && BN == 64) ? "_ring" : "",
-                                      KG == 2 ? "_8waves" : "", BM, BN, BK), true);
+                                      KG == 2 ? "_8waves" : KG == 4 ? "_16waves" : "", BM, BN, BK), true);
   (void)named;
   note_ql<A_U8>(name, gm);
   return check_launch("mctq_qlinear_i8 (tiled, direct-to-LDS)");
@@ -1042,6 +1047,16 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
 #define MCTQ_QGR(BM_, BN_, BK_, ST_)                                                                                   \
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+#define MCTQ_QG16(BM_, BN_, BK_, ST_)                                                                                      \
+  (u8 ? launch_glds<BM_, BN_, BK_, true, ST_, 4>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
+      : launch_glds<BM_, BN_, BK_, false, ST_, 4>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  switch (g_ql_variant) {                            // 16-wave blocks (four wave groups): 16<tile code><stages>
+    case 1612122: return MCTQ_QG16(128, 128, 256, 2);
+    case 1612623: return MCTQ_QG16(128, 64, 256, 3);
+    case 1612622: return MCTQ_QG16(128, 64, 256, 2);
+    case 166623: return MCTQ_QG16(64, 64, 256, 3);
+    default: break;
+  }
 #define MCTQ_QG8(BM_, BN_, BK_, ST_)                                                                                       \
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_, 2>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_, 2>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
@@ -1110,15 +1125,15 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   // qlinear_small_tiles.log, EXPERIMENTS.md).  So the time of a launch is (operand bytes of a block) x (blocks the busiest
   // CU takes) / rate, and the choice is the kernel that makes that least: the weight-streaming kernel (a block = 16
   // columns x all rows, 64 rows per pass), 32 x 32 ... 128 x 128 tiles with two or three LDS buffers and four or eight
-  // waves (eight: two wave groups that both copy and each multiply half of a K tile -- more waves issuing copies raise the
-  // rate by 10-25 %), and the asm-pinned 128 x 128 kernel where the problem is whole tiles.  Earlier candidates win ties (smaller tiles first).
+  // waves (eight / sixteen: two / four wave groups that all copy and each multiply a share of a K tile -- more waves
+  // issuing copies raise the rate by 10-30 %), and the asm-pinned 128 x 128 kernel where the problem is whole tiles.  Earlier candidates win ties (smaller tiles first).
   {
     const auto tiles_cost = [&](int bm, int bn, int occ, double r1, double r2, double r3) {   // us, up to a common constant
       const double kib = (double)(bm + bn) * (double)K / 1024.0, rate[4] = {1.0, r1, r2, r3};
       const int64_t per_cu = (blocks(bm, bn) + cus - 1) / cus, full = per_cu / occ, rem = per_cu % occ;
       return (double)(full * occ) * kib / rate[occ] + (rem ? (double)rem * kib / rate[rem] : 0.0);
     };
-    enum { kStream, kT33, kT63, kT66R, kT66, kT66S, kT126, kT612, kT1212, kW44 };
+    enum { kStream, kT33, kT63, kT66R, kT66, kT66S, kT126, kT126X, kT612, kT1212, kW44 };
     double best = 1e300;
     int pick = kT66;
     const auto consider = [&](int id, double c) { if (c < best) { best = c; pick = id; } };
@@ -1127,10 +1142,11 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     // 8-wave blocks (two wave groups, 3-buffer ring): rates fitted on profiles/r03/qlinear_8waves.log
     consider(kT33, tiles_cost(32, 32, 3, 42, 63, 65));
     consider(kT63, tiles_cost(64, 32, 2, 50, 61, 0));
-    consider(kT66R, tiles_cost(64, 64, 1, 46, 0, 0));
+    consider(kT66R, tiles_cost(64, 64, 1, 48, 0, 0));           // 16 waves (qlinear_16waves.log): one block per CU
     consider(kT66, tiles_cost(64, 64, 2, 36, 54, 0));           // 4 waves, two buffers, two blocks per CU
     consider(kT66S, tiles_cost(64, 64, 3, 36, 56, 59));         // 8 waves, 128-byte K steps, three blocks per CU
     consider(kT126, tiles_cost(128, 64, 2, 44, 54, 0));
+    consider(kT126X, tiles_cost(128, 64, 1, 48, 0, 0));         // 16 waves, 256-byte K steps: one block per CU
     consider(kT612, tiles_cost(64, 128, 3, 36, 50, 64));
     consider(kT1212, tiles_cost(128, 128, 2, 30, 48, 0));
     if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0) consider(kW44, tiles_cost(128, 128, 2, 38, 43, 0));
@@ -1138,9 +1154,10 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
       case kStream: return MCTQ_QLL(8, 4);
       case kT33: return MCTQ_QG8(32, 32, 256, 3);
       case kT63: return MCTQ_QG8(64, 32, 256, 3);
-      case kT66R: return MCTQ_QG8(64, 64, 256, 3);
+      case kT66R: return MCTQ_QG16(64, 64, 256, 3);
       case kT66S: return MCTQ_QG8(64, 64, 128, 3);
       case kT126: return MCTQ_QG8(128, 64, 128, 3);
+      case kT126X: return MCTQ_QG16(128, 64, 256, 3);
       case kT612: return MCTQ_QG(64, 128, 128);
       case kT1212: return MCTQ_QG(128, 128, 128);
       case kW44: return MCTQ_QW(4, 4);
@@ -1150,6 +1167,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
 #undef MCTQ_QG
 #undef MCTQ_QGR
 #undef MCTQ_QG8
+#undef MCTQ_QG16
 #undef MCTQ_QW
 #undef MCTQ_QL
 #undef MCTQ_QLL

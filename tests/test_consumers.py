@@ -150,7 +150,7 @@ def _run_kernel(lib, native, a, u8, za, sa, w, ws, bias):
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 142, 144, 1212, 612, 66, 662, 12122,
                                      6623, 6624, 663, 664, 666, 6123, 6124, 12123, 12124, 12623, 12622, 12613, 12614, 3263, 3262, 6433, 3233,
-                                     86623, 86622, 86633, 86433, 83233, 812613, 812123, 812122])
+                                     86623, 86622, 86633, 86433, 83233, 812613, 812123, 812122, 1612122, 1612623, 1612622, 166623])
 def test_qlinear_kernel_is_bit_exact_against_the_integer_oracle(variant):
     from oracle import mctq_oracle as O
     from mct_quantizers_amd.hip import native
