@@ -36,7 +36,7 @@ def timeit(m, x, n=30):
         torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3, y
 
-for layers, d, batch in ((16, 4096, 64), (16, 4096, 2048), (8, 8192, 64)):
+for layers, d, batch in ((16, 4096, 64), (16, 4096, 256), (16, 4096, 2048), (8, 8192, 64)):
     x = torch.randn(batch, d, device="cuda")
     ours, y1 = timeit(build(layers, d, False), x)
     aten, y2 = timeit(build(layers, d, True), x)
