@@ -25,6 +25,7 @@ static void note_ql(const char* shape, int u = 0) {
   g_note.shape = shape; g_note.op = A_U8 ? "u8 x i8" : "i8 x i8"; g_note.unroll = u; g_note.nt = 0;
   g_note.in_bytes = 1; g_note.out_bytes = 4;
 }
+extern int g_ql_rot;                    // tuning hook "ql_rot": K rotation between the blocks that share a weight tile (default off)
 extern int g_ql_band;                   // tuning hook "ql_band": tile rows per band of the tiled kernel, 0 = automatic
 
 // Output form: float32 values, or the next layer's activation codes (the fake-quant arithmetic of
@@ -422,6 +423,9 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
     int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, int gm, QlOut oq) {
+  // gm < 0: -gm tile rows per band AND K rotation (below)
+  const bool rotate = gm < 0;
+  gm = rotate ? -gm : gm;
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int CPR = kTileBK / 16;
   constexpr int SA = BM * CPR, SB = BN * CPR;        // slots of the A and of the B image
@@ -477,11 +481,19 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
     for (int u = 0; u < TN; ++u) acc[t][u] = i32x4{0, 0, 0, 0};
 
   const int64_t kt_n = (K + kTileBK - 1) / kTileBK;
-  copy_tile(0, 0);
+  // The band_rows blocks of a band that share a weight tile run in step; started at the same k, all of them would wait
+  // for each line's first fetch from HBM.  Block j of them starts its walk over K at tile j * kt_n / band_rows and wraps:
+  // a line is then fetched by one block and found in the XCD's L2 by the others a fraction of the K loop later (an exact
+  // integer sum does not depend on the order of its terms).  Measured (profiles/r03/qlinear_rot{0,1}.log): 8-15 % for the
+  // two-buffer 4-wave tiles at K = 4096, nothing for the ring tiles, and 10-18 % SLOWER at K >= 8192, where the weight
+  // tiles of an XCD no longer stay in its L2 for a quarter of the loop -- off by default (tuning key "ql_rot").
+  const int64_t kt_rot = rotate ? (int64_t)(in_band % band_rows) * kt_n / band_rows : 0;
+  const auto k_of = [&](int64_t kt) { const int64_t t = kt + kt_rot; return (t >= kt_n ? t - kt_n : t) * (int64_t)kTileBK; };
+  copy_tile(0, k_of(0));
   if constexpr (ST > 2) {
 #pragma unroll
     for (int i = 1; i < ST - 1; ++i)
-      if (i < kt_n) copy_tile(i, i * (int64_t)kTileBK);
+      if (i < kt_n) copy_tile(i, k_of(i));
   }
   int e_corr[TN];                                    // epilogue constants of this lane's columns, fetched early
   float e_scale[TN], e_bias[TN];
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
       if (kt + ST - 2 < kt_n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((ST - 2) * LT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (kt + ST - 1 < kt_n) copy_tile(nbuf, (kt + ST - 1) * (int64_t)kTileBK);
+    if (kt + ST - 1 < kt_n) copy_tile(nbuf, k_of(kt + ST - 1));
 #pragma unroll
     for (int ksi = 0; ksi < NKS; ++ksi) {
       const int ks = kg * NKS + ksi;
@@ -582,8 +594,9 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
     gm = (int)(sqrt(chunk * BN / BM) + 0.5);
   }
   gm = gm < 1 ? 1 : gm > mbl ? mbl : gm;
+  const int gm_arg = g_ql_rot && gm > 1 ? -gm : gm;
   hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8, ST, KG>), dim3((unsigned)(mbl * nbl)), dim3(256 * KG), 0, stream,
-                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, oq);
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm_arg, oq);
   static char name[48];                              // "qlinear_tiled[_ring]_<BM>x<BN>x<BK>", formatted once per instantiation
   static const bool named = (snprintf(name, sizeof(name), "qlinear_tiled%s%s_%dx%dx%d", ST > 2 || (BM == 128 && BN == 64) ? "_ring" : "",
                                       KG == 2 ? "_8waves" : KG == 4 ? "_16waves" : "", BM, BN, BK), true);
