@@ -21,7 +21,7 @@ PEAK = 5000.0
 if os.environ.get("QL_ROT"):                      # K rotation between the blocks that share a weight tile (default on)
     assert lib.mctq_set_tuning(b"ql_rot", int(os.environ["QL_ROT"])) == 0
 for (M, N, K) in shapes:
-    ring = max(2, int(np.ceil(400e6 / (N * K))))
+    ring = int(os.environ["QL_RING"]) if os.environ.get("QL_RING") else max(2, int(np.ceil(400e6 / (N * K))))   # 1: warm weights
     ws = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(ring)]
     a = torch.randint(0, 256, (M, K), dtype=torch.uint8, device=dev)
     sc = torch.rand(N, device=dev) * 0.01
