@@ -109,7 +109,7 @@ int mctq_set_tuning(const char* key, int32_t value) {
     return 0;
   }
   if (!strcmp(key, "ql_variant")) {
-    static const int ok[] = {0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 142, 144, 1212, 612, 66, 662, 12122, 2588, 2548, 2584, 2544, 2560, 3448, 3486, 3846, 4442,
+    static const int ok[] = {0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 141, 142, 144, 1212, 612, 66, 662, 12122, 2588, 2548, 2584, 2544, 2560, 3448, 3486, 3846, 4442,
                              6623, 6624, 663, 664, 666, 6123, 6124, 12123, 12124, 12623, 12622, 12613, 12614, 3263, 3262, 6433, 3233, 86623, 86622, 86633, 86433, 83233, 812613, 812123, 812122, 1612122, 1612623, 1612622, 166623};   // <tile code><ring stages> of the tiled kernel
     bool found = false;
     for (int v : ok) found = found || v == value;

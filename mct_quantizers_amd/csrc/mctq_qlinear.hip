@@ -1025,6 +1025,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     case 181: return MCTQ_QLL(8, 1);
     case 182: return MCTQ_QLL(8, 2);
     case 184: return MCTQ_QLL(8, 4);
+    case 141: return MCTQ_QLL(4, 1);
     case 142: return MCTQ_QLL(4, 2);
     case 144: return MCTQ_QLL(4, 4);
     default: break;
@@ -1114,11 +1115,8 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   }
   const int64_t cus = cu_count();
   const auto blocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-  // Few rows: stream the weights once, activation codes staged through per-wave LDS (full-line copies instead of
-  // fragment-shaped L2 reads; profiles/r02/qlinear_probe.log: 16 x 11008 x 4096 16.3 -> 14.8 us, 32 x 4096^2
-  // 8.8 -> 8.4, 64 x 4096^2 12.5 -> 10.0, 64 x 4096 x 11008 28.5 -> 20.5, 128 x 4096^2 18.2 -> 15.3).
-  if (M <= 16) return MCTQ_QLL(8, 1);
-  if (M <= 32) return MCTQ_QLL(8, 2);
+  // Few rows: the weight-streaming kernels (activation codes staged through per-wave LDS: full-line copies instead of
+  // fragment-shaped L2 reads; profiles/r02/qlinear_probe.log) are candidates of the cost model below.
   // Many rows and columns, whole tiles: the 256 x 256 ping-pong kernel (2.2-2.3 POP/s against 1.5 for the 128 x 128
   // tiles; profiles/r02/qgemm_wide_probe.log) or, when there are too few such tiles for the chip, 128 x 256 wave-wide
   // tiles -- weighed by how full their last round of blocks is (one block per CU; the 128 x 128 kernel fits two).
@@ -1146,12 +1144,20 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
       const int64_t per_cu = (blocks(bm, bn) + cus - 1) / cus, full = per_cu / occ, rem = per_cu % occ;
       return (double)(full * occ) * kib / rate[occ] + (rem ? (double)rem * kib / rate[rem] : 0.0);
     };
-    enum { kStream, kT33, kT63, kT66R, kT66, kT66S, kT126, kT126X, kT612, kT1212, kW44 };
+    enum { kStream1, kStream2, kStream, kT33, kT63, kT66R, kT66, kT66S, kT126, kT126X, kT612, kT1212, kW44 };
     double best = 1e300;
     int pick = kT66;
     const auto consider = [&](int id, double c) { if (c < best) { best = c; pick = id; } };
-    if (M <= 128)                                    // 80 K bytes per pass and block: 16 weight rows + 64 activation rows
-      consider(kStream, (double)(((N + 15) / 16 + cus - 1) / cus) * (double)((M + 63) / 64) * 80.0 * (double)K / 1024.0 / 47.0);
+    // weight streaming: a block = 16 weight rows + 16 MT activation rows per pass; MT = 1 fits two blocks per CU.  Rates
+    // fitted on profiles/r03/qlinear_small_m.log (16 / 32 rows) and qlinear_small_tiles.log (64 ... 128 rows).
+    const int64_t s_per_cu = ((N + 15) / 16 + cus - 1) / cus;
+    const double k_kib = (double)K / 1024.0;
+    if (M <= 16)
+      consider(kStream1, (double)(s_per_cu / 2 * 2) * 32.0 * k_kib / 36.5 + (double)(s_per_cu % 2) * 32.0 * k_kib / 29.0);
+    else if (M <= 32)
+      consider(kStream2, (double)s_per_cu * 48.0 * k_kib / 38.0);
+    else if (M <= 128)
+      consider(kStream, (double)s_per_cu * (double)((M + 63) / 64) * 80.0 * k_kib / 47.0);
     // 8-wave blocks (two wave groups, 3-buffer ring): rates fitted on profiles/r03/qlinear_8waves.log
     consider(kT33, tiles_cost(32, 32, 3, 42, 63, 65));
     consider(kT63, tiles_cost(64, 32, 2, 50, 61, 0));
@@ -1164,6 +1170,8 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     consider(kT1212, tiles_cost(128, 128, 2, 30, 48, 0));
     if (K % 128 == 0 && K >= 256 && N % 128 == 0 && M % 128 == 0) consider(kW44, tiles_cost(128, 128, 2, 38, 43, 0));
     switch (pick) {
+      case kStream1: return MCTQ_QLL(8, 1);
+      case kStream2: return MCTQ_QLL(8, 2);
       case kStream: return MCTQ_QLL(8, 4);
       case kT33: return MCTQ_QG8(32, 32, 256, 3);
       case kT63: return MCTQ_QG8(64, 32, 256, 3);
