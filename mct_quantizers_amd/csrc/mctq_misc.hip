@@ -12,6 +12,7 @@ int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_ql_variant = 0;
 int g_ql_band = 0;
+int g_ql_stagger = 0;         // tiled consumer kernel: half of the waves copy after multiplying (experiment: no gain)
 int g_ql_rot = 0;            // tiled consumer kernel: blocks that share a weight tile start at different K offsets (experiment: no gain)
 int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)
 
@@ -115,6 +116,11 @@ int mctq_set_tuning(const char* key, int32_t value) {
     for (int v : ok) found = found || v == value;
     if (!found) return fail_arg("ql_variant must be 0, <waves><row tiles> (41 ... 84) a tile (1212, 612, 66, 662, 12122) or a wide tile (2588, 2548, 2584, 2544, 2560)");
     g_ql_variant = value;
+    return 0;
+  }
+  if (!strcmp(key, "ql_stagger")) {
+    if (value != 0 && value != 1) return fail_arg("ql_stagger must be 0 or 1");
+    g_ql_stagger = value;
     return 0;
   }
   if (!strcmp(key, "ql_rot")) {

@@ -25,6 +25,7 @@ static void note_ql(const char* shape, int u = 0) {
   g_note.shape = shape; g_note.op = A_U8 ? "u8 x i8" : "i8 x i8"; g_note.unroll = u; g_note.nt = 0;
   g_note.in_bytes = 1; g_note.out_bytes = 4;
 }
+extern int g_ql_stagger;                // tuning hook "ql_stagger": half of the tiled kernel's waves copy after multiplying (default off)
 extern int g_ql_rot;                    // tuning hook "ql_rot": K rotation between the blocks that share a weight tile (default off)
 extern int g_ql_band;                   // tuning hook "ql_band": tile rows per band of the tiled kernel, 0 = automatic
 
@@ -411,6 +412,10 @@ typedef __attribute__((address_space(3))) void ql_lds_void;
 typedef const __attribute__((address_space(1))) void ql_glb_void;
 __device__ __attribute__((aligned(16))) const int8_t g_ql_zero_chunk[16] = {0};
 
+#ifdef MCTQ_QL_STAMP      // diagnostic build only (tools/kbench_ql_stamps.hip): where a K step of the tiled kernel spends its cycles
+__device__ unsigned long long g_ql_stamp[16 * 8];      // per wave of ONE block: wait+barrier, copy issue, multiply, total, steps
+#define MCTQ_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 // ST: LDS buffers in the ring (ST - 1 tiles requested ahead).  ST = 2 is the form above; with ST >= 3 the barrier of a K
 // step only retires the copies of the tile about to be multiplied (counted vmcnt: copies return in issue order), so
 // ST - 2 later tiles stay in flight across it.
@@ -422,10 +427,9 @@ template <int BM, int BN, int kTileBK, bool A_U8, int ST = 2, int KG = 1>
 __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
     const int8_t* __restrict__ a, const int8_t* __restrict__ w, const float* __restrict__ w_scales,
     const int32_t* __restrict__ w_rowsum, const float* __restrict__ bias, void* __restrict__ y,
-    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, int gm, QlOut oq) {
-  // gm < 0: -gm tile rows per band AND K rotation (below)
-  const bool rotate = gm < 0;
-  gm = rotate ? -gm : gm;
+    int M, int N, int64_t K, int za, float sa, int m_blocks, int n_blocks, int gm, int flags, QlOut oq) {
+  const bool rotate = (flags & 1) != 0;              // K rotation (below)
+  const bool stagger = (flags & 2) != 0;             // half of the waves request the later tile AFTER multiplying (below)
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int CPR = kTileBK / 16;
   constexpr int SA = BM * CPR, SB = BN * CPR;        // slots of the A and of the B image
@@ -505,7 +509,14 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
     e_bias[u] = bias ? bias[n] : 0.0f;
   }
   int buf = 0, nbuf = ST - 1;                         // ring positions of tile kt and of tile kt + ST - 1
+#ifdef MCTQ_QL_STAMP
+  unsigned long long st_wait = 0, st_copy = 0, st_mul = 0, st_t0, st_a, st_b;
+  MCTQ_STAMP(st_t0);
+#endif
   for (int64_t kt = 0; kt < kt_n; ++kt) {
+#ifdef MCTQ_QL_STAMP
+    MCTQ_STAMP(st_a);
+#endif
     if constexpr (ST == 2) {
       __syncthreads();                                // tile kt has landed; buffer buf ^ 1 is free
     } else {
@@ -514,7 +525,19 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
       if (kt + ST - 2 < kt_n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((ST - 2) * LT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (kt + ST - 1 < kt_n) copy_tile(nbuf, k_of(kt + ST - 1));
+#ifdef MCTQ_QL_STAMP
+    MCTQ_STAMP(st_b); st_wait += st_b - st_a;
+#endif
+    // A wave's copies, fragment reads and products are ONE instruction stream (profiles/r03/kbench_ql_stamps.log: per K step
+    // of the 4-wave 64 x 64 x 256 tile 810 cycles issuing 8 copies, 930 reading fragments and multiplying, 280 at the
+    // barrier).  Experiment "ql_stagger": half of the waves multiply first and copy afterwards (the buffer they fill, tile
+    // kt - 1's, is free in either order) so that the address unit is not idle while all waves multiply -- +-3 %
+    // (qlinear_stagger{0,1}.log), off by default.
+    const bool copy_first = ST == 2 || !stagger || (((KG > 1 ? kg : wave) & 1) == 0);   // two buffers: the copy has only this step to land
+    if (copy_first && kt + ST - 1 < kt_n) copy_tile(nbuf, k_of(kt + ST - 1));
+#ifdef MCTQ_QL_STAMP
+    MCTQ_STAMP(st_a); st_copy += st_a - st_b;
+#endif
 #pragma unroll
     for (int ksi = 0; ksi < NKS; ++ksi) {
       const int ks = kg * NKS + ksi;
@@ -536,9 +559,24 @@ __global__ __launch_bounds__(256 * KG) void qgemm_i8_glds_kernel(
         for (int u = 0; u < TN; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], acc[t][u], 0, 0, 0);
     }
+#ifdef MCTQ_QL_STAMP
+    { i32x4 keep = acc[0][0]; asm volatile("" : "+v"(keep)); acc[0][0] = keep; }     // the products of this step are issued before the stamp
+    MCTQ_STAMP(st_b); st_mul += st_b - st_a;
+#endif
+    if (!copy_first && kt + ST - 1 < kt_n) copy_tile(nbuf, k_of(kt + ST - 1));
+#ifdef MCTQ_QL_STAMP
+    MCTQ_STAMP(st_a); st_copy += st_a - st_b;
+#endif
     buf = buf + 1 == ST ? 0 : buf + 1;
     nbuf = nbuf + 1 == ST ? 0 : nbuf + 1;
   }
+#ifdef MCTQ_QL_STAMP
+  if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+    MCTQ_STAMP(st_a);
+    unsigned long long* o = g_ql_stamp + wave * 8;
+    o[0] = st_wait; o[1] = st_copy; o[2] = st_mul; o[3] = st_a - st_t0; o[4] = (unsigned long long)kt_n;
+  }
+#endif
 
   if constexpr (KG > 1) {             // the upper half of the groups hands its partial sums to the lower half through the
     i32x4* red = &lds[0][0];          // (dead) ring, until group 0 holds the whole sum
@@ -594,9 +632,9 @@ static int launch_glds(const void* a, const int8_t* w, const float* w_scales, co
     gm = (int)(sqrt(chunk * BN / BM) + 0.5);
   }
   gm = gm < 1 ? 1 : gm > mbl ? mbl : gm;
-  const int gm_arg = g_ql_rot && gm > 1 ? -gm : gm;
+  const int flags = (g_ql_rot && gm > 1 ? 1 : 0) | (g_ql_stagger ? 2 : 0);
   hipLaunchKernelGGL((qgemm_i8_glds_kernel<BM, BN, BK, A_U8, ST, KG>), dim3((unsigned)(mbl * nbl)), dim3(256 * KG), 0, stream,
-                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm_arg, oq);
+                     (const int8_t*)a, w, w_scales, w_rowsum, bias, y, (int)M, (int)N, K, za, sa, mbl, nbl, gm, flags, oq);
   static char name[48];                              // "qlinear_tiled[_ring]_<BM>x<BN>x<BK>", formatted once per instantiation
   static const bool named = (snprintf(name, sizeof(name), "qlinear_tiled%s%s_%dx%dx%d", ST > 2 || (BM == 128 && BN == 64) ? "_ring" : "",
                                       KG == 2 ? "_8waves" : KG == 4 ? "_16waves" : "", BM, BN, BK), true);
@@ -1258,5 +1296,11 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
   return MCTQ_QL4(4);
 #undef MCTQ_QL4
 }
+
+#ifdef MCTQ_QL_STAMP
+int mctq_debug_ql_stamps(unsigned long long* out16x8) {      // diagnostic build only
+  return -(int)hipMemcpyFromSymbol(out16x8, HIP_SYMBOL(mctq::g_ql_stamp), sizeof(unsigned long long) * 16 * 8);
+}
+#endif
 
 }  // extern "C"

@@ -18,6 +18,8 @@ shapes = [_shape(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "
 variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,662,66,612,1212,12122,2548,2560".split(","))]
 bands = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,1".split(","))]
 PEAK = 5000.0
+if os.environ.get("QL_STAGGER"):                  # half of the tiled kernel's waves copy after multiplying (default on)
+    assert lib.mctq_set_tuning(b"ql_stagger", int(os.environ["QL_STAGGER"])) == 0
 if os.environ.get("QL_ROT"):                      # K rotation between the blocks that share a weight tile (default on)
     assert lib.mctq_set_tuning(b"ql_rot", int(os.environ["QL_ROT"])) == 0
 for (M, N, K) in shapes:
