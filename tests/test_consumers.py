@@ -176,6 +176,30 @@ def test_qlinear_kernel_is_bit_exact_against_the_integer_oracle(variant):
 
 
 @pytest.mark.gpu
+def test_qlinear_automatic_kernel_choice_is_bit_exact_across_the_cost_models_regimes():
+    """The dispatcher picks among the streaming kernels, the 8- / 16-wave ring tiles, the two-buffer tiles and the
+    asm-pinned kernels by a cost model (csrc/mctq_qlinear.hip: qlinear_dispatch): shapes that land on every candidate, with
+    tails in M / N / K, both code types -- each equal to the integer oracle bit for bit, and every candidate reached."""
+    from oracle import mctq_oracle as O
+    from mct_quantizers_amd.hip import native
+    lib = native.load()
+    assert lib.mctq_set_tuning(b"ql_variant", 0) == 0
+    rng = np.random.default_rng(4242)
+    shapes = [(8, 4096, 2048), (32, 4096, 2048), (16, 11008, 2048), (64, 4096, 2048), (96, 4096, 2064), (128, 4096, 4096),
+              (200, 4096, 2048), (250, 4090, 2048), (320, 4096, 2048), (448, 4096, 4096), (640, 4096, 2048), (700, 4096, 1040),
+              (1100, 4096, 2048), (1900, 4096, 1024), (1024, 4096, 1024), (2048, 4096, 512), (4096, 4096, 256)]
+    seen = set()
+    for (M, N, K) in shapes:
+        u8 = (M + K) % 3 != 0
+        a, za, sa, w, ws, bias = _problem(rng, M, N, K, u8, with_bias=M % 2 == 0)
+        got = _run_kernel(lib, native, a, u8, za, sa, w, ws, bias)
+        seen.add(native.last_launch().split("<")[0])
+        want = O.qlinear_i8(a, za, sa, w, ws, bias)
+        assert bits_equal(got, want), f"M={M} N={N} K={K} u8={u8} [{native.last_launch()}]: {first_mismatch(got, want)}"
+    assert len(seen) >= 8, sorted(seen)             # streaming, ring tiles of several shapes and wave counts, two-buffer, wide
+
+
+@pytest.mark.gpu
 def test_qlinear_rejects_bad_arguments():
     from mct_quantizers_amd.hip import native
     lib = native.load()
