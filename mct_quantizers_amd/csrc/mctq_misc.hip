@@ -114,7 +114,7 @@ int mctq_set_tuning(const char* key, int32_t value) {
                              6623, 6624, 663, 664, 666, 6123, 6124, 12123, 12124, 12623, 12622, 12613, 12614, 3263, 3262, 6433, 3233, 86623, 86622, 86633, 86433, 83233, 812613, 812123, 812122, 1612122, 1612623, 1612622, 166623};   // <tile code><ring stages> of the tiled kernel
     bool found = false;
     for (int v : ok) found = found || v == value;
-    if (!found) return fail_arg("ql_variant must be 0, <waves><row tiles> (41 ... 84) a tile (1212, 612, 66, 662, 12122) or a wide tile (2588, 2548, 2584, 2544, 2560)");
+    if (!found) return fail_arg("ql_variant must be 0 (automatic) or one of the launch-variant codes listed in mctq_misc.hip (streaming 41 ... 184, tiles 66 ... 12124, 8- / 16-wave tiles 8xxxx / 16xxxxx, wide tiles 25xx ... 4442)");
     g_ql_variant = value;
     return 0;
   }
