@@ -450,7 +450,11 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *   key "cached_store_max_mb" : with nt = 1, outputs of at most this many MiB are stored through the caches
  *                  (mode 2) so that a consumer launched right after finds them in L2 / the Infinity Cache; default 32, 0 = never
  *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
- *   key "ql_variant" : mctq_qlinear_i8 launch shape, <waves per block><16-row tiles per pass> (41 ... 84) or a tile (1212, 612, 66, 662, 12122); 0 = automatic
+ *   key "ql_variant" : mctq_qlinear_i8 launch shape: 0 = automatic (cost model, csrc/mctq_qlinear.hip: qlinear_dispatch), or one
+ *                  of the codes listed in csrc/mctq_misc.hip -- streaming kernels <1?><waves><16-row tiles per pass> (41 ... 184),
+ *                  tiles <BM/..><BN/..>[K step][LDS buffers] (66 ... 12124), 8- / 16-wave tiles (8xxxx / 16xxxxx), wide tiles (25xx ... 4442)
+ *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
+ *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
  *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */
