@@ -195,6 +195,11 @@ def main():
         dist, control_plane = bench_dist.init_process_group(
             "gloo" if dry else "nccl", device, force_gloo=bool(os.environ.get("MCTQ_BENCH_FORCE_GLOO")))
     ranks_seen = dist.get_world_size() if dist is not None else 1
+    if ranks_seen != args.gpus and control_plane == "nccl":
+        # a scaling line must not claim GPUs the process group did not see (one rank per GPU over RCCL)
+        print(f"[bench] --gpus {args.gpus} but the RCCL process group has {ranks_seen} ranks", file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        sys.exit(5)
 
     import mct_quantizers_amd as mq
     from mct_quantizers_amd import workloads
@@ -361,6 +366,7 @@ def main():
         "value": value,
         "unit": "elems/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps,

@@ -152,31 +152,59 @@ def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: in
         y = sq(xs[i % 3])
     t_comp = timed_region(lambda i: sq(xs[i % 3]), reps, device, dist) / reps
     y = sq(xs[0])
-    buffers = sq.gather_buffers(y) if world > 1 else None      # the 256 MiB result lives outside the timed gather
+    # the 256 MiB result lives outside the timed gather.  The collective is issued at world size 1 too (a group of one rank:
+    # RCCL copies y into the result), so that all_gather_into_tensor has run on HIP tensors before any multi-GPU run
+    buffers = sq.gather_buffers(y)
     full = None
     for _ in range(min(3, gather_reps)):
-        full = sq.all_gather(y, buffers)
+        full = sq.all_gather(y, buffers, force_collective=True)
     box = {}
 
     def gather(i):
-        box["full"] = sq.all_gather(y, buffers)
+        box["full"] = sq.all_gather(y, buffers, force_collective=True)
     t_gather = timed_region(gather, gather_reps, device, dist) / gather_reps
     full = box.get("full", full)
     recv = (rows - (stop - start)) * cols * 4
-    ok = full is not None and tuple(full.shape) == (rows, cols) and bool(torch.equal(full[start:stop], y))
+    ok = (full is not None and tuple(full.shape) == (rows, cols) and full.data_ptr() != y.data_ptr()
+          and bool(torch.equal(full[start:stop], y)))
     recv_gbs = recv / t_gather / 1e9 if t_gather > 0 else None
+    digest = full_digest_check(full, rows, cols) if rank == 0 else None
     return {
         "workload": f"cfg5 WeightsPOT per-channel(axis0) 4b {rows}x{cols}, dim-0 shards",
         "scaling": "strong", "rows_per_rank": stop - start, "ranks": world,
         "compute_ms": t_comp * 1e3, "compute_elems_per_s": rows * cols / t_comp,
         "allgather_ms": t_gather * 1e3, "allgather_recv_bytes_per_rank": recv,
         "allgather_recv_gbs_per_rank": recv_gbs,
+        "allgather_backend": dist.get_backend() if dist is not None else None,
+        "allgather_device": str(full.device) if full is not None else None,
+        # a group of one rank moves nothing between GPUs: the figure is RCCL's local copy of the 256 MiB result
+        "allgather_local_copy_gbs": (stop - start) * cols * 4 / t_gather / 1e9 if world == 1 and t_gather > 0 else None,
         # xGMI is point to point: a rank receives from its world - 1 peers over world - 1 links at once
         "allgather_gbs_per_link": recv_gbs / (world - 1) if recv_gbs is not None and world > 1 else None,
         "allgather_output": "pre-allocated outside the timed region",
         "compute_plus_allgather_elems_per_s": rows * cols / (t_comp + t_gather),
         "gathered_rows_match_local": ok,
+        "gathered_equals_reference_digest": digest,
     }
+
+
+def full_digest_check(full: torch.Tensor, rows: int, cols: int) -> Optional[bool]:
+    """SHA-256 of the re-assembled tensor against the REFERENCE's digest of BASELINE config 5 (tests/golden/full_sha.json,
+    written by tools/gen_golden.py from the reference's output on the same portable input); None when the size has no
+    recorded digest (the dry run's small shape)."""
+    import hashlib
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "full_sha.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    entry = rec.get("configs", {}).get("cfg5", {})
+    want = entry.get("y_sha256") if list(entry.get("shape", [])) == [rows, cols] else None
+    if want is None:
+        return None
+    return hashlib.sha256(full.detach().cpu().contiguous().numpy().tobytes()).hexdigest() == want
 
 
 class Watchdog:

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 5
+#define MCTQ_ABI_VERSION 6
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
@@ -64,6 +64,10 @@ extern "C" {
 /* ABI version of the loaded library (== MCTQ_ABI_VERSION it was built with). */
 int mctq_abi_version(void);
 
+/* Content hash of the sources, headers and compiler flags this binary was built from (hip/build.py: tree_build_id()):
+ * the loader refuses a library whose id differs from the tree's, so a stale binary cannot be used silently. */
+const char* mctq_build_id(void);
+
 /* Message of the last failing call on this thread ("" if none). */
 const char* mctq_last_error(void);
 
@@ -71,6 +75,12 @@ const char* mctq_last_error(void);
  * "rows_kernel<AffineOp,in4B,out4B,U=4,NT=1>" ("" before the first launch).  Benchmarks use it to tie profiler
  * counters (profiles/pmc_traffic.json) to the variant they were measured on.  Valid until the next call. */
 const char* mctq_last_launch(void);
+
+/* Diagnostic: number of kernel launches the library has enqueued from the calling thread since it was loaded (every
+ * launch that mctq_last_launch() would name counts once; the one-by-one tail of a batched call counts per tensor).
+ * Tests use the difference around a model forward to show how many launches the forward issued: the reference issues
+ * one per wrapped weight per forward (pytorch/quantize_wrapper.py:228-240); an accelerated model one per storage type. */
+int64_t mctq_launch_count(void);
 
 /* y[i] = (clamp(rint(x[i] * (1/scale)) + zero_point, quant_min, quant_max) - zero_point) * scale, i < n. */
 int mctq_fq_per_tensor_f32(const float* x, float* y, int64_t n,

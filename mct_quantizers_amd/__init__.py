@@ -28,6 +28,9 @@ def __getattr__(name):
     if name == "capture_stream":                     # a fixed-shape activation stream replayed from one hipGraph
         from mct_quantizers_amd.pytorch.graphs import capture_stream
         return capture_stream
+    if name in ("accelerate", "decelerate", "accelerated"):   # one launch per forward for all wrapped weights, stand-aside form
+        from mct_quantizers_amd.pytorch import accelerate as _acc
+        return getattr(_acc, name)
     if name == "batch_weight_quantization":          # all wrapped weights of a model in ONE launch per forward
         from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
         return batch_weight_quantization

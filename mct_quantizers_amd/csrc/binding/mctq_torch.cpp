@@ -390,6 +390,85 @@ void plan_dealloc(PyObject* self) {
 
 PyTypeObject AffinePlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
+// ---- the whole eager call of an activation holder in ONE C call ---------------------------------------------
+// PytorchActivationQuantizationHolder.forward (reference: pytorch/activation_quantization_holder.py:43-53) is
+// `return self.activation_holder_quantizer(inputs)`; nn.Module.__call__ around it serves hooks, compiled calls and
+// tracing.  fast = HolderCall(holder.__dict__, quantizer, quantizer.__dict__, plan, (hook dicts ...), check_bypass)
+// fast(x) -> tensor | NotImplemented: checks, in C, that none of that machinery is in use and that the objects the
+// launch state was derived from are still the ones in place --
+//   every dict in `hook dicts` is empty (the module's and torch's global forward / backward hook tables),
+//   holder.__dict__["_compiled_call_impl"] is None, holder.__dict__["activation_holder_quantizer"] is `quantizer`,
+//   (check_bypass) holder.__dict__["quantization_bypass"] is False,
+//   quantizer.__dict__["_plan"] is `plan` (assigning to a public parameter of the quantizer drops its plan) --
+// and then makes the plan's call (which itself declines anything but a plain eager HIP tensor).
+struct HolderCall {
+  PyObject_HEAD
+  vectorcallfunc vectorcall;
+  PyObject* holder_dict;
+  PyObject* quantizer;
+  PyObject* quantizer_dict;
+  PyObject* plan;
+  PyObject* hook_dicts;     // tuple
+  int check_bypass;
+};
+
+PyObject *kw_compiled = nullptr, *kw_quantizer = nullptr, *kw_bypass = nullptr, *kw_plan = nullptr;
+
+PyObject* holdercall_vectorcall(PyObject* self, PyObject* const* args, size_t nargsf, PyObject* kwnames) {
+  HolderCall* h = (HolderCall*)self;
+  if (PyVectorcall_NARGS(nargsf) != 1 || (kwnames && PyTuple_GET_SIZE(kwnames))) {
+    PyErr_SetString(PyExc_TypeError, "HolderCall.__call__(x)");
+    return nullptr;
+  }
+  const Py_ssize_t nd = PyTuple_GET_SIZE(h->hook_dicts);
+  for (Py_ssize_t i = 0; i < nd; ++i)
+    if (PyDict_GET_SIZE(PyTuple_GET_ITEM(h->hook_dicts, i)) != 0) return not_implemented();
+  if (PyDict_GetItem(h->holder_dict, kw_compiled) != Py_None) return not_implemented();
+  if (PyDict_GetItem(h->holder_dict, kw_quantizer) != h->quantizer) return not_implemented();
+  if (h->check_bypass && PyDict_GetItem(h->holder_dict, kw_bypass) != Py_False) return not_implemented();
+  if (PyDict_GetItem(h->quantizer_dict, kw_plan) != h->plan) return not_implemented();
+  return plan_vectorcall(h->plan, args, 1, nullptr);
+}
+
+PyObject* holdercall_new(PyTypeObject* type, PyObject* args, PyObject*) {
+  PyObject *hd, *q, *qd, *plan, *hooks;
+  int bypass = 0;
+  if (!PyArg_ParseTuple(args, "O!OO!O!O!|p", &PyDict_Type, &hd, &q, &PyDict_Type, &qd, &AffinePlanType, &plan,
+                        &PyTuple_Type, &hooks, &bypass)) return nullptr;
+  for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(hooks); ++i)
+    if (!PyDict_Check(PyTuple_GET_ITEM(hooks, i))) {
+      PyErr_SetString(PyExc_TypeError, "HolderCall: the hook tables must be dicts");
+      return nullptr;
+    }
+  HolderCall* h = (HolderCall*)type->tp_alloc(type, 0);
+  if (!h) return nullptr;
+  h->vectorcall = holdercall_vectorcall;
+  h->holder_dict = hd; h->quantizer = q; h->quantizer_dict = qd; h->plan = plan; h->hook_dicts = hooks;
+  h->check_bypass = bypass;
+  Py_INCREF(hd); Py_INCREF(q); Py_INCREF(qd); Py_INCREF(plan); Py_INCREF(hooks);
+  return (PyObject*)h;
+}
+
+int holdercall_traverse(PyObject* self, visitproc visit, void* arg) {
+  HolderCall* h = (HolderCall*)self;
+  Py_VISIT(h->holder_dict); Py_VISIT(h->quantizer); Py_VISIT(h->quantizer_dict); Py_VISIT(h->plan); Py_VISIT(h->hook_dicts);
+  return 0;
+}
+
+int holdercall_clear(PyObject* self) {
+  HolderCall* h = (HolderCall*)self;
+  Py_CLEAR(h->holder_dict); Py_CLEAR(h->quantizer); Py_CLEAR(h->quantizer_dict); Py_CLEAR(h->plan); Py_CLEAR(h->hook_dicts);
+  return 0;
+}
+
+void holdercall_dealloc(PyObject* self) {
+  PyObject_GC_UnTrack(self);
+  holdercall_clear(self);
+  Py_TYPE(self)->tp_free(self);
+}
+
+PyTypeObject HolderCallType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
 // ---- pre-packed arguments of the per-tensor LUT quantizer with a decision table (the activation LUT quantizer):
 //      plan = LutPlan(table, thr_div_f32, thr_div_f16, thr_div_bf16, thr_mul, mult, clip_min, clip_max, half_steps);
 //      plan(x) -> float32 tensor | NotImplemented.  The divisor depends on the tensor's type because the reference
@@ -771,6 +850,16 @@ PyTypeObject BatchPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
 PyObject* py_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(mctq_abi_version()); }
 
+#ifndef MCTQ_BINDING_ID
+#define MCTQ_BINDING_ID "unstamped"
+#endif
+// "MCTQ_BINDING_ID=<id>": content hash of what this module was built from (hip/build.py: binding_build_id), also found
+// by scanning the file
+PyObject* py_build_id(PyObject*, PyObject*) {
+  static const char text[] = "MCTQ_BINDING_ID=" MCTQ_BINDING_ID;
+  return PyUnicode_FromString(text + sizeof("MCTQ_BINDING_ID=") - 1);
+}
+
 PyMethodDef methods[] = {
     {"fq_per_tensor", (PyCFunction)(void (*)(void))py_fq_per_tensor, METH_FASTCALL, nullptr},
     {"fq_per_channel", (PyCFunction)(void (*)(void))py_fq_per_channel, METH_FASTCALL, nullptr},
@@ -779,6 +868,7 @@ PyMethodDef methods[] = {
     {"lutt_per_channel", (PyCFunction)(void (*)(void))py_lutt_per_channel, METH_FASTCALL, nullptr},
     {"fq_batched", (PyCFunction)(void (*)(void))py_fq_batched, METH_FASTCALL, nullptr},
     {"abi_version", py_abi_version, METH_NOARGS, nullptr},
+    {"build_id", py_build_id, METH_NOARGS, nullptr},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_mctq_torch",
@@ -803,6 +893,20 @@ PyMODINIT_FUNC PyInit__mctq_torch(void) {
   LutPlanType.tp_call = PyVectorcall_Call;
   LutPlanType.tp_vectorcall_offset = offsetof(LutPlan, vectorcall);
   if (PyType_Ready(&LutPlanType) < 0) return nullptr;
+  HolderCallType.tp_name = "_mctq_torch.HolderCall";
+  HolderCallType.tp_basicsize = sizeof(HolderCall);
+  HolderCallType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL | Py_TPFLAGS_HAVE_GC;
+  HolderCallType.tp_new = holdercall_new;
+  HolderCallType.tp_dealloc = holdercall_dealloc;
+  HolderCallType.tp_traverse = holdercall_traverse;
+  HolderCallType.tp_clear = holdercall_clear;
+  HolderCallType.tp_call = PyVectorcall_Call;
+  HolderCallType.tp_vectorcall_offset = offsetof(HolderCall, vectorcall);
+  if (PyType_Ready(&HolderCallType) < 0) return nullptr;
+  kw_compiled = PyUnicode_InternFromString("_compiled_call_impl");
+  kw_quantizer = PyUnicode_InternFromString("activation_holder_quantizer");
+  kw_bypass = PyUnicode_InternFromString("quantization_bypass");
+  kw_plan = PyUnicode_InternFromString("_plan");
   BatchPlanType.tp_name = "_mctq_torch.BatchPlan";
   BatchPlanType.tp_basicsize = sizeof(BatchPlan);
   BatchPlanType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL;
@@ -819,5 +923,7 @@ PyMODINIT_FUNC PyInit__mctq_torch(void) {
   if (PyModule_AddObject(m, "LutPlan", (PyObject*)&LutPlanType) < 0) { Py_DECREF(m); return nullptr; }
   Py_INCREF(&BatchPlanType);
   if (PyModule_AddObject(m, "BatchPlan", (PyObject*)&BatchPlanType) < 0) { Py_DECREF(m); return nullptr; }
+  Py_INCREF(&HolderCallType);
+  if (PyModule_AddObject(m, "HolderCall", (PyObject*)&HolderCallType) < 0) { Py_DECREF(m); return nullptr; }
   return m;
 }

@@ -441,6 +441,9 @@ struct LutTableOp : LutCommon {
   __device__ __forceinline__ Prefetch prefetch() const {
     const f32x2* src = reinterpret_cast<const f32x2*>(table);
     Prefetch p;
+#ifdef MCTQ_ABLATE_STAGE            // timing experiment: no table traffic, no LDS writes, no barrier (results wrong)
+    return p;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = (int)threadIdx.x + i * kThreads;
@@ -450,6 +453,9 @@ struct LutTableOp : LutCommon {
   }
   __device__ __forceinline__ Book commit(const Prefetch& p, float* lds) const {
     f32x2* dst = reinterpret_cast<f32x2*>(lds);
+#ifdef MCTQ_ABLATE_STAGE
+    { Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = (int)threadIdx.x + i * kThreads;
@@ -1086,12 +1092,13 @@ inline int nt_mode(int64_t out_bytes) {
 }
 extern int g_unroll;
 // what the calling thread launched last (mctq_last_launch(): lets a benchmark tie its counters to a kernel variant)
-struct LaunchNote { const char* shape; const char* op; int unroll, nt, in_bytes, out_bytes; };
+struct LaunchNote { const char* shape; const char* op; int unroll, nt, in_bytes, out_bytes; int64_t count; };
 extern thread_local LaunchNote g_note;
 template <class Op, class TI, class TO>
 inline void note(const char* shape, int unroll, int nt) {
   g_note.shape = shape; g_note.op = Op::kName; g_note.unroll = unroll; g_note.nt = nt;
   g_note.in_bytes = (int)sizeof(TI); g_note.out_bytes = (int)sizeof(TO);
+  ++g_note.count;
 }
 extern int g_heavy_unroll;   // 0 = automatic
 extern int g_heavy_persistent;

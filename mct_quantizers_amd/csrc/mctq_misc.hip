@@ -4,7 +4,7 @@
 namespace mctq {
 
 thread_local char g_err[256] = "";
-thread_local LaunchNote g_note = {"", "", 0, 0, 0, 0};
+thread_local LaunchNote g_note = {"", "", 0, 0, 0, 0, 0};
 static thread_local char g_note_text[160] = "";
 int g_nt = 1;
 int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggregate L2 stay cached for their consumer
@@ -79,6 +79,17 @@ const char* mctq_last_launch(void) {
   snprintf(g_note_text, sizeof(g_note_text), "%s<%s,in%dB,out%dB,U=%d,NT=%d>", g_note.shape, g_note.op, g_note.in_bytes,
            g_note.out_bytes, g_note.unroll, g_note.nt);
   return g_note_text;
+}
+
+int64_t mctq_launch_count(void) { return g_note.count; }
+
+#ifndef MCTQ_BUILD_ID
+#define MCTQ_BUILD_ID "unstamped"
+#endif
+// "MCTQ_BUILD_ID=<id>" is also found by scanning the file (hip/build.py: needs_build) without loading it
+const char* mctq_build_id(void) {
+  static const char text[] = "MCTQ_BUILD_ID=" MCTQ_BUILD_ID;
+  return text + sizeof("MCTQ_BUILD_ID=") - 1;
 }
 
 int mctq_set_tuning(const char* key, int32_t value) {

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import contextlib
 import fcntl
+import hashlib
+import mmap
 import os
 import shutil
 import subprocess
@@ -46,23 +48,65 @@ def _build_lock():
             fcntl.flock(f, fcntl.LOCK_UN)
 
 
+# ---- what a binary was built from: a content hash, not modification times ----------------------------------------------
+# The built .so files are git-ignored but travel to the GPU machine with the snapshot; a binary that is NEWER than the
+# sources yet built from different ones must not be used silently.  The library carries the hash of every source, header
+# and flag it was compiled from ("MCTQ_BUILD_ID=<id>" in its read-only data, also returned by mctq_build_id()); the tree's
+# hash is recomputed from the files (~1 ms) and compared -- by needs_build() before deciding to reuse, and by the loader
+# (hip/native.py) before any call.
+
+ID_MARKER = b"MCTQ_BUILD_ID="
+BINDING_ID_MARKER = b"MCTQ_BINDING_ID="
+
+
+def _digest(paths, extra=()) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def tree_build_id() -> str:
+    """Hash of the kernel sources, the headers and the compiler flags as they are in the tree now."""
+    return _digest(SOURCES + HEADERS, FLAGS)
+
+
+def embedded_id(path: str, marker: bytes = ID_MARKER):
+    """The id stamped into a built binary, read from the file without loading it; None if absent."""
+    try:
+        with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+            at = m.find(marker)
+            while at >= 0:
+                tail = m[at + len(marker):at + len(marker) + 16]
+                if len(tail) == 16 and all(c in b"0123456789abcdef" for c in tail):
+                    return tail.decode()
+                at = m.find(marker, at + 1)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [os.path.abspath(__file__)])
+    return embedded_id(OUT) != tree_build_id()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Build the library unless the one in lib/ carries the tree's id.  ``force``: recompile every translation unit
+    (the per-unit object cache is ignored too)."""
     if not force and not needs_build():
         return OUT
     with _build_lock():
         if not force and not needs_build():          # another process built it while this one waited
             return OUT
-        return _build(verbose)
+        return _build(verbose, force)
 
 
-def _build(verbose: bool) -> str:
+def _build(verbose: bool, force: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libmctq_hip.so")
@@ -70,33 +114,55 @@ def _build(verbose: bool) -> str:
     objdir = os.path.join(os.path.dirname(OUT), "obj")
     os.makedirs(objdir, exist_ok=True)
     inc = ["-I", os.path.join(REPO, "include"), "-I", CSRC]
-    # one hipcc per translation unit, in parallel (the units are independent)
-    procs = []
+    build_id = tree_build_id()
+    # one hipcc per translation unit, in parallel (the units are independent).  Objects are cached by the hash of what
+    # they were compiled from (the unit, every header, the flags): an unchanged unit is not recompiled.
+    procs, objs, keep = [], [], set()
     for src in SOURCES:
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc, *FLAGS, *inc, "-c", "-o", obj, src]
+        stamp = ['-DMCTQ_BUILD_ID="%s"' % build_id] if os.path.basename(src) == "mctq_misc.hip" else []
+        key = _digest([src] + HEADERS, FLAGS + stamp)
+        obj = os.path.join(objdir, f"{os.path.basename(src)}.{key}.o")
+        objs.append(obj)
+        keep.add(os.path.basename(obj))
+        if os.path.exists(obj) and not force:
+            continue
+        cmd = [hipcc, *FLAGS, *stamp, *inc, "-c", "-o", obj + ".tmp", src]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((obj, cmd, subprocess.Popen(cmd)))
-    objs = []
     for obj, cmd, proc in procs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-        objs.append(obj)
+        os.replace(obj + ".tmp", obj)
+    for name in os.listdir(objdir):                  # objects of earlier source versions
+        if name not in keep:
+            os.remove(os.path.join(objdir, name))
     tmp = OUT + ".tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True)
+    if embedded_id(tmp) != build_id:
+        raise RuntimeError(f"{tmp} does not carry build id {build_id}")
     os.replace(tmp, OUT)
     return OUT
 
 
+def _binding_flags():
+    import torch
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    return ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}"]
+
+
+def binding_build_id() -> str:
+    """Hash of the binding's source, the C header, its flags, the torch version it links and the library's id."""
+    import torch
+    return _digest([BINDING_SRC, HEADERS[0]], _binding_flags() + [torch.__version__, tree_build_id()])
+
+
 def binding_needs_build() -> bool:
-    if not os.path.exists(BINDING_OUT):
-        return True
-    t = os.path.getmtime(BINDING_OUT)
-    return any(os.path.getmtime(p) > t for p in (BINDING_SRC, HEADERS[0], OUT, os.path.abspath(__file__)))
+    return embedded_id(BINDING_OUT, BINDING_ID_MARKER) != binding_build_id()
 
 
 def build_binding(force: bool = False, verbose: bool = True) -> str:
@@ -119,10 +185,9 @@ def _build_binding(verbose: bool) -> str:
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("g++ not found; cannot build the compiled binding")
-    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
     tmp = BINDING_OUT + ".tmp"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
+    bid = binding_build_id()
+    cmd = [cxx, *_binding_flags(), '-DMCTQ_BINDING_ID="%s"' % bid,
            "-I", os.path.join(REPO, "include"), "-I", os.path.join(tdir, "include"),
            "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
            "-I", sysconfig.get_paths()["include"], BINDING_SRC, "-o", tmp,
@@ -132,6 +197,8 @@ def _build_binding(verbose: bool) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    if embedded_id(tmp, BINDING_ID_MARKER) != bid:
+        raise RuntimeError(f"{tmp} does not carry binding id {bid}")
     os.replace(tmp, BINDING_OUT)
     return BINDING_OUT
 

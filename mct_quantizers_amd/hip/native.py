@@ -14,7 +14,7 @@ import ctypes
 import os
 import threading
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
 CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
 FQ_ITEM_PER_TENSOR = 1
@@ -53,8 +53,10 @@ class LutItem(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol of include/mctq_hip.h
 SIGNATURES = {
     "mctq_abi_version": (ctypes.c_int, []),
+    "mctq_build_id": (ctypes.c_char_p, []),
     "mctq_last_error": (ctypes.c_char_p, []),
     "mctq_last_launch": (ctypes.c_char_p, []),
+    "mctq_launch_count": (ctypes.c_int64, []),
     "mctq_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
     "mctq_selftest_division": (ctypes.c_int, [_c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mctq_fq_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_int32,
@@ -156,6 +158,19 @@ def lib_path() -> str:
     return os.environ.get("MCTQ_HIP_LIB", os.path.join(LIB_DIR, LIB_NAME))
 
 
+def _check_build_id(path: str, got: str, which: str):
+    """A binary in lib/ must have been built from the sources that are in the tree now (content hash, hip/build.py);
+    a stale one is refused, never used silently.  Libraries given through MCTQ_HIP_LIB are the caller's business;
+    MCTQ_SKIP_BUILD_ID_CHECK=1 turns the check off (bisecting with hand-built binaries)."""
+    if "MCTQ_HIP_LIB" in os.environ or os.environ.get("MCTQ_SKIP_BUILD_ID_CHECK", "0") not in ("", "0"):
+        return
+    from mct_quantizers_amd.hip import build as _build
+    want = getattr(_build, which)()
+    if got != want:
+        raise NativeLibraryError(f"{path} was built from other sources (build id {got}, the tree's is {want}); "
+                                 f"rebuild it: python -m mct_quantizers_amd.hip.build")
+
+
 def load():
     """Load (once) and return the ctypes handle; raises NativeLibraryError if unavailable."""
     global _lib
@@ -183,6 +198,7 @@ def load():
         got = handle.mctq_abi_version()
         if got != ABI_VERSION:
             raise NativeLibraryError(f"{path} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+        _check_build_id(path, handle.mctq_build_id().decode(), "tree_build_id")
         # deployment knob: outputs up to this many MiB are stored through the caches (see include/mctq_hip.h)
         mb = os.environ.get("MCTQ_CACHED_STORE_MAX_MB")
         if mb:
@@ -268,6 +284,7 @@ def fast():
             spec.loader.exec_module(mod)
             if mod.abi_version() != ABI_VERSION:
                 raise ImportError(f"{path} was built against ABI {mod.abi_version()}, expected {ABI_VERSION}")
+            _check_build_id(path, mod.build_id(), "binding_build_id")
             _fast = mod
         except Exception as e:  # noqa: BLE001
             if mode == "compiled":
@@ -298,6 +315,11 @@ def check(rc: int, what: str):
 def last_launch() -> str:
     """Kernel variant of this thread's last elementwise launch (see include/mctq_hip.h: mctq_last_launch)."""
     return load().mctq_last_launch().decode("utf-8", "replace")
+
+
+def launch_count() -> int:
+    """Kernel launches this thread has enqueued through the library so far (include/mctq_hip.h: mctq_launch_count)."""
+    return int(load().mctq_launch_count())
 
 
 def set_tuning(key: str, value: int):

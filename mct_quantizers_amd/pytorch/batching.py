@@ -43,9 +43,13 @@ from mct_quantizers_amd.pytorch.containers import PytorchQuantizationWrapper
 class BatchedWeightQuantization:
     """Handle returned by ``batch_weight_quantization``; ``remove()`` restores per-layer quantization."""
 
-    def __init__(self, model: nn.Module, reuse_buffers: bool = False):
+    def __init__(self, model: nn.Module, reuse_buffers: bool = False, auto: bool = False):
         self.model = model
         self.reuse_buffers = reuse_buffers
+        # auto: installed by ``accelerate`` / ``pytorch_load_quantized_model`` on a model nobody asked to batch -- it must
+        # never change what a forward does except for the number of launches: weights that are not on a GPU, an
+        # active trace or compile, or anything the pre-packed launch cannot take leave the per-layer calls in charge
+        self.auto = auto
         self._plan = None                 # (BatchPlan, tensor count) in reuse_buffers mode
         # [generation, open]: a wrapper takes its prepared tensor once per generation and only while the model's
         # forward that prepared it is running (a direct call of a sub-module later must not serve it)
@@ -70,20 +74,36 @@ class BatchedWeightQuantization:
                 m for m in self.model.modules()
                 if isinstance(m, PytorchQuantizationWrapper) and m.is_weights_quantization and m.is_str_attr]
         for m in wrappers:
-            if True:
-                for name, weight, quantizer in m.get_weights_vars():
-                    if (with_lut and hasattr(quantizer, "batch_item_lut") and not quantizer.enable_reuse
-                            and not quantizer.__dict__.get("_versioned_reuse")
-                            and not (quantizer._use_custom_impl and torch.jit.is_tracing())
-                            and isinstance(weight, torch.Tensor) and quantizer.batch_item_lut(weight.detach()) is not None):
-                        out.append((m, name, weight, quantizer))      # LUT weights: pre-packed plan only
-                        continue
-                    if (hasattr(quantizer, "batch_item") and not quantizer.enable_reuse
-                            and int(getattr(quantizer, "num_bits", 0)) <= 24
-                            and not quantizer.__dict__.get("_versioned_reuse")
-                            and not (quantizer._use_custom_impl and torch.jit.is_tracing())):
-                        out.append((m, name, weight, quantizer))
+            for name, weight, quantizer in m.get_weights_vars():
+                if (with_lut and hasattr(quantizer, "batch_item_lut") and not quantizer.enable_reuse
+                        and not quantizer.__dict__.get("_versioned_reuse")
+                        and not (quantizer._use_custom_impl and torch.jit.is_tracing())
+                        and isinstance(weight, torch.Tensor) and quantizer.batch_item_lut(weight.detach()) is not None):
+                    out.append((m, name, weight, quantizer))      # LUT weights: pre-packed plan only
+                    continue
+                if (hasattr(quantizer, "batch_item") and not quantizer.enable_reuse
+                        and int(getattr(quantizer, "num_bits", 0)) <= 24
+                        and not quantizer.__dict__.get("_versioned_reuse")
+                        and not (quantizer._use_custom_impl and torch.jit.is_tracing())):
+                    out.append((m, name, weight, quantizer))
         return out
+
+    def _auto_applies(self) -> bool:
+        """Auto mode, no plan yet: is this a forward the one-launch path may take at all?  (Cheap: runs on every forward
+        of a model that stays on the CPU.)"""
+        if torch.jit.is_tracing() or torch.compiler.is_compiling():
+            return False
+        wrappers = self.__dict__.get("_wrappers")
+        if wrappers is None:
+            self._entries()
+            wrappers = self.__dict__["_wrappers"]
+        if not wrappers:
+            return False
+        for m in wrappers:
+            vars_ = m._weights_vars
+            if vars_ and not (isinstance(vars_[0][1], torch.Tensor) and vars_[0][1].is_cuda):
+                return False
+        return True
 
     @staticmethod
     def _watch(quantizer):
@@ -149,6 +169,8 @@ class BatchedWeightQuantization:
         """Quantize every participating weight in one batched launch and hand the results to the wrappers.
         Returns the number of tensors quantized."""
         cell = self._cell
+        if self.auto and self._plan is None and not self._auto_applies():
+            return 0
         if self.reuse_buffers and not torch.jit.is_tracing():
             for _ in range(2):                                       # a stale plan is rebuilt once, then given up
                 plan = self._plan
@@ -162,6 +184,8 @@ class BatchedWeightQuantization:
                     cell[1] = True
                     return plan[1]
                 self._drop_plan()                                    # NotImplemented: shapes / dtypes / parameters changed
+                if self.auto and not self._auto_applies():           # e.g. the model went back to the CPU
+                    return 0
         entries = self._entries()
         if not entries:
             return 0
@@ -193,7 +217,9 @@ class BatchedWeightQuantization:
         self._drop_plan()
 
 
-def batch_weight_quantization(model: nn.Module, reuse_buffers: bool = False) -> BatchedWeightQuantization:
+def batch_weight_quantization(model: nn.Module, reuse_buffers: bool = False, auto: bool = False) -> BatchedWeightQuantization:
     """Install the batched weight re-quantization on ``model`` (a forward pre-hook on the given module).
-    ``reuse_buffers``: see the module docstring (persistent output tensors + pre-packed launch)."""
-    return BatchedWeightQuantization(model, reuse_buffers)
+    ``reuse_buffers``: see the module docstring (persistent output tensors + pre-packed launch).
+    ``auto``: stand aside (per-layer calls, as without the hook) whenever the weights are not on a GPU or a trace /
+    compile is running -- the mode ``accelerate`` and ``pytorch_load_quantized_model`` install."""
+    return BatchedWeightQuantization(model, reuse_buffers, auto)

@@ -211,14 +211,56 @@ class PytorchActivationQuantizationHolder(torch.nn.Module):
         """``nn.Module.__call__`` costs ~2.5 us of Python before ``forward`` runs -- as much as the launch itself for
         a small activation.  When nothing that machinery serves is present (no hooks on this module, no global
         hooks, no compiled call, no torch.jit trace, a plain tensor argument) the result of ``Module.__call__`` IS
-        ``forward(inputs)``, so go there directly; anything else takes the full path."""
+        ``forward(inputs)``, so go there directly; anything else takes the full path.
+
+        For the affine activation quantizers even that test, ``forward`` and the quantizer's own ``__call__`` are one C
+        call (the compiled binding's ``HolderCall``: the same conditions checked on the dictionaries themselves, then
+        the quantizer's pre-packed launch); it answers NotImplemented whenever any of them fails."""
+        fast = self.__dict__.get("_fast_call")
+        if fast is not None and not args and not kwargs and not _is_compiling():
+            y = fast(inputs)
+            if y is not NotImplemented:
+                return y
         if (type(inputs) is not torch.Tensor or args or kwargs
                 or self._forward_hooks or self._forward_pre_hooks or self._backward_hooks or self._backward_pre_hooks
                 or _nn_module._global_forward_hooks or _nn_module._global_forward_pre_hooks
                 or _nn_module._global_backward_hooks or _nn_module._global_backward_pre_hooks
                 or self._compiled_call_impl is not None or torch._C._get_tracing_state() is not None):
             return super().__call__(inputs, *args, **kwargs)
-        return self.forward(inputs)
+        y = self.forward(inputs)
+        if inputs.is_cuda:                                   # (the quantizer's own call above re-made its plan if needed)
+            key = self.__dict__.get("_fast_key")
+            q = self.__dict__.get(ACTIVATION_HOLDER_QUANTIZER)
+            if key is None or key[0] is not q or key[1] is not getattr(q, "__dict__", {}).get("_plan"):
+                self._make_fast_call()
+        return y
+
+    def _make_fast_call(self):
+        """Build the one-call form for the quantizer in place now (False = not available: no compiled binding, a LUT or
+        foreign quantizer, a subclass with its own ``forward``).  Re-made whenever the C call reports a change and the
+        slow path runs: the quantizer was swapped or one of its parameters assigned."""
+        self.__dict__["_fast_call"] = None
+        q = self.__dict__.get(ACTIVATION_HOLDER_QUANTIZER)
+        plan = getattr(q, "__dict__", {}).get("_plan")
+        self.__dict__["_fast_key"] = (q, plan)    # what the C call was (or was not) built for: re-made when it changes
+        ok = (type(self).forward in (PytorchActivationQuantizationHolder.forward, _BypassableHolder.forward)
+              and type(self).__call__ is PytorchActivationQuantizationHolder.__call__
+              and hasattr(q, "_plan_attrs") and plan is not None and plan is not False)
+        if ok:
+            from mct_quantizers_amd.hip import ops
+            fast = ops._fast_mod()
+            if fast is not None and type(plan) is getattr(fast, "AffinePlan", None) and hasattr(fast, "HolderCall"):
+                hooks = (self._forward_hooks, self._forward_pre_hooks, self._backward_hooks, self._backward_pre_hooks,
+                         _nn_module._global_forward_hooks, _nn_module._global_forward_pre_hooks,
+                         _nn_module._global_backward_hooks, _nn_module._global_backward_pre_hooks)
+                self.__dict__["_fast_call"] = fast.HolderCall(self.__dict__, q, q.__dict__, plan, hooks,
+                                                              isinstance(self, _BypassableHolder))
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_fast_call", None)             # C object over this module's own dictionaries: rebuilt on first use
+        state.pop("_fast_key", None)
+        return state
 
     def capture_stream(self, example: torch.Tensor, depth: int = 16, mode: str = "auto"):
         """Extension (not in the reference): a fixed-shape stream of ``depth`` activation batches through this holder per

@@ -78,10 +78,12 @@ class ShardedWeightsQuantizer:
             pad = torch.zeros((self.rows_per_rank,) + tail, dtype=y_local.dtype, device=y_local.device)
         return out, pad
 
-    def all_gather(self, y_local: torch.Tensor, buffers=None) -> torch.Tensor:
+    def all_gather(self, y_local: torch.Tensor, buffers=None, force_collective: bool = False) -> torch.Tensor:
         """Concatenate every rank's row block along dim 0 (one collective; every rank gets the full tensor).
-        ``buffers``: the pair from ``gather_buffers`` (no allocation inside the call); default: allocate."""
-        if self.world == 1:
+        ``buffers``: the pair from ``gather_buffers`` (no allocation inside the call); default: allocate.
+        ``force_collective``: issue ``all_gather_into_tensor`` even in a group of ONE rank (the result is then a copy
+        of ``y_local``) -- the benchmark's way of running RCCL on device memory on a one-GPU machine."""
+        if self.world == 1 and not (force_collective and dist.is_initialized()):
             return y_local
         out, pad = buffers if buffers is not None else self.gather_buffers(y_local)
         if y_local.shape[0] != self.rows_per_rank:      # short last block: pad to the common size

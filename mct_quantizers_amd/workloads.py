@@ -154,3 +154,62 @@ def make_model_weights(name: str):
         thr = [float(v) for v in np.max(np.abs(x.reshape(shape[0], -1)), axis=1)]
         out.append((x, dict(num_bits=8, threshold=thr, per_channel=True, channel_axis=0)))
     return out
+
+
+# ---- a whole wrapped MODEL (what MCT exports: every convolution under a PytorchQuantizationWrapper, every activation
+# behind a holder; quantize_wrapper.py:212-258, activation_quantization_holder.py:43-53) -------------------------------
+
+LUT16 = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+
+
+def wrapped_resnet50(device="cuda", weights: str = "symmetric", holders: bool = True):
+    """ResNet-50 as an MCT export looks (batch norms folded into the convolutions): 53 wrapped convolutions + the wrapped
+    classifier, their weights from ``make_model_weights("resnet50")`` in forward order, 8-bit per-channel symmetric
+    weights quantizers (``weights="lut"``: 16-entry codebook LUT quantizers), an unsigned 8-bit activation holder behind
+    every ReLU.  Pure workload: random weights, no checkpoint."""
+    import torch
+    import torch.nn as nn
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    stock = iter(make_model_weights("resnet50"))
+
+    def wrap(layer):
+        x, kw = next(stock)
+        assert tuple(layer.weight.shape) == x.shape, (tuple(layer.weight.shape), x.shape)
+        with torch.no_grad():
+            layer.weight.copy_(torch.from_numpy(x))
+        layer = layer.to(device)
+        if weights == "lut":
+            q = Q.WeightsLUTSymmetricInferableQuantizer(num_bits=4, lut_values=LUT16, threshold=kw["threshold"],
+                                                        per_channel=True, channel_axis=0, input_rank=len(x.shape))
+        else:
+            q = Q.WeightsSymmetricInferableQuantizer(**kw)
+        return mq.PytorchQuantizationWrapper(layer, {"weight": q})
+
+    def act():
+        if not holders:
+            return nn.ReLU()
+        return nn.Sequential(nn.ReLU(), mq.PytorchActivationQuantizationHolder(
+            Q.ActivationSymmetricInferableQuantizer(num_bits=8, threshold=[8.0], signed=False)))
+
+    class Bottleneck(nn.Module):
+        def __init__(self, cin, width, stride, first):
+            super().__init__()
+            self.c1, self.a1 = wrap(nn.Conv2d(cin, width, 1, bias=False)), act()
+            self.c2, self.a2 = wrap(nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)), act()
+            self.c3 = wrap(nn.Conv2d(width, width * 4, 1, bias=False))
+            self.down = wrap(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False)) if first else None
+            self.a3 = act()
+
+        def forward(self, x):
+            y = self.c3(self.a2(self.c2(self.a1(self.c1(x)))))
+            return self.a3(y + (x if self.down is None else self.down(x)))
+
+    layers = [wrap(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)), act(), nn.MaxPool2d(3, 2, 1)]
+    cin = 64
+    for width, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for b in range(blocks):
+            layers.append(Bottleneck(cin, width, stride if b == 0 else 1, b == 0))
+            cin = width * 4
+    layers += [nn.AdaptiveAvgPool2d(1), nn.Flatten(), wrap(nn.Linear(2048, 1000, bias=False))]
+    return nn.Sequential(*layers).to(device).eval()

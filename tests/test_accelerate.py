@@ -1,0 +1,261 @@
+"""The drop-in gets the fast path: a model loaded through the reference's API (pytorch_load_quantized_model,
+reference pytorch/load_model.py:23-34; wrappers re-quantizing per forward, quantize_wrapper.py:228-240) issues ONE
+launch per storage type for all its wrapped weights on a GPU -- and is untouched on the CPU or with MCTQ_AUTO_BATCH=0.
+
+The GPU tests count the launches the library enqueued around a forward (mctq_launch_count, include/mctq_hip.h) and
+name the last one (mctq_last_launch); results are held to the per-layer path bit for bit and to the oracle."""
+import copy
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import mct_quantizers_amd as mq
+from mct_quantizers_amd import workloads
+from mct_quantizers_amd.pytorch import accelerate as acc
+from conftest import GOLDEN, bits_equal, first_mismatch
+
+Q = mq.pytorch_quantizers
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+def _small_model(device="cpu"):
+    torch.manual_seed(3)
+    conv = nn.Conv2d(3, 8, 3)
+    lin = nn.Linear(8, 5)
+    thr = [float(v) for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+    net = nn.Sequential()
+    net.add_module("conv", mq.PytorchQuantizationWrapper(conv, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)}))
+    net.add_module("act", mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-1.0], [3.0])))
+    net.add_module("pool", nn.AdaptiveAvgPool2d(1))
+    net.add_module("flat", nn.Flatten())
+    net.add_module("lin", mq.PytorchQuantizationWrapper(lin, {
+        "weight": Q.WeightsLUTSymmetricInferableQuantizer(3, [-100.0, -50.0, -10.0, 0.0, 10.0, 50.0, 100.0, 127.0], [1.0], False),
+        "bias": Q.WeightsUniformInferableQuantizer(8, [-1.0], [1.0], False)}))
+    return net.to(device)
+
+
+def _quantized_weights(model):
+    """What every wrapper installed on its layer in the last forward."""
+    out = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, mq.PytorchQuantizationWrapper):
+            for wname, _, _ in mod.get_weights_vars():
+                out[f"{name}.{wname}"] = getattr(mod.layer, wname).detach().cpu().numpy().copy()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host logic (CPU): the switch, idempotence, pickles, stand-aside behaviour
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_switch_parsing(monkeypatch):
+    monkeypatch.delenv("MCTQ_AUTO_BATCH", raising=False)
+    assert acc.auto_batch_enabled()
+    for off in ("0", "off", "false", "No", ""):
+        monkeypatch.setenv("MCTQ_AUTO_BATCH", off)
+        assert not acc.auto_batch_enabled()
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "1")
+    assert acc.auto_batch_enabled()
+
+
+def test_accelerate_is_idempotent_and_removable():
+    net = _small_model()
+    assert mq.accelerated(net) is None
+    assert mq.accelerate(net) is net
+    handle = mq.accelerated(net)
+    assert handle is not None and handle.auto and handle.reuse_buffers
+    assert mq.accelerate(net) is net and mq.accelerated(net) is handle
+    assert len(net._forward_pre_hooks) == 1
+    mq.decelerate(net)
+    assert mq.accelerated(net) is None and len(net._forward_pre_hooks) == 0 and len(net._forward_hooks) == 0
+    plain = nn.Sequential(nn.Linear(3, 3))
+    assert mq.accelerate(plain) is plain and mq.accelerated(plain) is None      # nothing to batch: nothing installed
+    with pytest.raises(TypeError):
+        mq.accelerate(lambda x: x)
+
+
+@pytest.mark.parametrize("switch", ["1", "0"])
+def test_loader_installs_by_the_switch_and_cpu_forward_is_unchanged(tmp_path, monkeypatch, switch):
+    """In the style of the reference's tests/pytorch_tests/test_pytorch_load_model.py: save the module, load it with
+    pytorch_load_quantized_model, same outputs."""
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", switch)
+    net = _small_model()
+    x = torch.randn(2, 3, 10, 10)
+    want = net(x)
+    path = str(tmp_path / "model.pth")
+    torch.save(net, path)
+    loaded = mq.pytorch_load_quantized_model(path)
+    assert (mq.accelerated(loaded) is not None) == (switch == "1")
+    got = loaded(x)
+    assert torch.equal(got, want)
+    if switch == "1":
+        assert mq.accelerated(loaded)._plan is None            # CPU weights: the hook stood aside
+        # a model saved WITH the hook installed loads, keeps one hook, and still works
+        torch.save(loaded, path)
+        again = mq.pytorch_load_quantized_model(path)
+        assert len(again._forward_pre_hooks) == 1 and mq.accelerated(again) is not None
+        assert torch.equal(again(x), want)
+        clone = copy.deepcopy(loaded)
+        assert mq.accelerated(clone) is not mq.accelerated(loaded) and mq.accelerated(clone).model is clone
+        assert torch.equal(clone(x), want)
+
+
+@pytest.mark.parametrize("switch", ["1", "0"])
+def test_reference_pickle_through_the_loader(monkeypatch, switch):
+    from mct_quantizers_amd import compat
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", switch)
+    io = np.load(os.path.join(GOLDEN, "ref_model_io.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = compat.load_reference_model(os.path.join(GOLDEN, "ref_model.pth"), map_location="cpu")
+    assert (mq.accelerated(model) is not None) == (switch == "1")
+    y = model(torch.from_numpy(io["x"])).detach().numpy()
+    assert bits_equal(y, io["y"]), first_mismatch(y, io["y"])
+
+
+def test_jit_trace_of_an_accelerated_model_records_the_reference_nodes():
+    net = mq.accelerate(_small_model())
+    x = torch.randn(1, 3, 10, 10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        traced = torch.jit.trace(net, x, check_trace=False)
+    kinds = {n.kind() for n in traced.graph.nodes()} | {n.kind() for n in traced.inlined_graph.nodes()}
+    assert any("fake_quantize_per_channel_affine" in k for k in kinds), kinds
+    assert torch.equal(traced(x), net(x))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: launches counted
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _forward_launches(model, x):
+    from mct_quantizers_amd.hip import native
+    torch.cuda.synchronize()
+    n0 = native.launch_count()
+    with torch.no_grad():
+        y = model(x)
+    return native.launch_count() - n0, y
+
+
+@pytest.mark.gpu
+def test_reference_pickle_loaded_with_nothing_but_the_reference_api_batches_its_weights(monkeypatch):
+    """ref_model.pth (written by the REFERENCE package) has three wrapped weights -- conv.weight (symmetric per channel),
+    lin.weight (LUT per tensor), lin.bias (uniform per tensor) -- and three holders.  Per layer: 6 launches per forward.
+    Loaded with the switch on: one affine table launch + one LUT table launch for the weights, 3 for the holders."""
+    from mct_quantizers_amd import compat
+    from mct_quantizers_amd.hip import native
+    io = np.load(os.path.join(GOLDEN, "ref_model_io.npz"))
+    x = torch.from_numpy(io["x"]).cuda()
+    results = {}
+    for switch in ("0", "1"):
+        monkeypatch.setenv("MCTQ_AUTO_BATCH", switch)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = compat.load_reference_model(os.path.join(GOLDEN, "ref_model.pth"), map_location="cuda")
+        _forward_launches(model, x)                                          # first forward builds the plan
+        n, y = _forward_launches(model, x)
+        results[switch] = (n, y.cpu().numpy(), _quantized_weights(model))
+        if switch == "1":
+            handle = mq.accelerated(model)
+            assert handle is not None and handle._plan is not None
+            n0 = native.launch_count()
+            assert handle.quantize_now() == 3
+            assert native.launch_count() - n0 == 2                           # 3 weights, 2 launches (affine table, LUT table)
+            assert "table" in native.last_launch(), native.last_launch()
+    assert results["0"][0] == 6 and results["1"][0] == 5, (results["0"][0], results["1"][0])
+    assert bits_equal(results["0"][1], results["1"][1])
+    for key, w in results["0"][2].items():
+        assert bits_equal(w, results["1"][2][key]), key
+    assert np.allclose(results["1"][1], io["y"], rtol=0, atol=2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", ["symmetric", "lut"])
+def test_wrapped_resnet50_saved_and_loaded_issues_one_weight_launch_per_forward(tmp_path, monkeypatch, weights):
+    from mct_quantizers_amd.hip import native
+    from oracle import oracle_call
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "1")
+    path = str(tmp_path / "resnet50.pth")
+    torch.save(workloads.wrapped_resnet50("cuda", weights=weights), path)
+    model = mq.pytorch_load_quantized_model(path)                            # the reference's API, nothing else
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    _forward_launches(model, x)
+    n_fast, y_fast = _forward_launches(model, x)
+    w_fast = _quantized_weights(model)
+    n_holders = sum(isinstance(m, mq.PytorchActivationQuantizationHolder) for m in model.modules())
+    assert n_holders == 49
+    assert n_fast == n_holders + 1, (n_fast, n_holders)                      # ONE launch for the 54 weights
+    handle = mq.accelerated(model)
+    n0 = native.launch_count()
+    assert handle.quantize_now() == 54 and native.launch_count() - n0 == 1
+    want_kernel = "batched_kernel<table>" if weights == "symmetric" else "batched_lut_kernel<table>"
+    assert want_kernel in native.last_launch(), native.last_launch()
+    mq.decelerate(model)
+    n_slow, y_slow = _forward_launches(model, x)
+    assert n_slow == n_holders + 54
+    assert torch.equal(y_fast, y_slow)
+    w_slow = _quantized_weights(model)
+    stock = workloads.make_model_weights("resnet50")
+    names = list(w_slow)
+    assert len(names) == 54
+    for k in (0, 1, 2, 4, 27, 52, 53):                                       # both paths == the oracle, per weight
+        xw, kw = stock[k]
+        if weights == "lut":
+            want = oracle_call("WeightsLUTSymmetricInferableQuantizer",
+                               dict(num_bits=4, lut_values=workloads.LUT16, threshold=kw["threshold"], per_channel=True,
+                                    channel_axis=0, input_rank=xw.ndim), xw)
+        else:
+            want = oracle_call("WeightsSymmetricInferableQuantizer", kw, xw)
+        assert bits_equal(w_fast[names[k]], want), (names[k], first_mismatch(w_fast[names[k]], want, xw))
+        assert bits_equal(w_slow[names[k]], want), names[k]
+
+
+@pytest.mark.gpu
+def test_model_moved_after_loading_and_weights_updated_between_forwards(tmp_path, monkeypatch):
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "1")
+    path = str(tmp_path / "m.pth")
+    torch.save(_small_model("cpu"), path)
+    model = mq.pytorch_load_quantized_model(path)                            # on the CPU: the hook stands aside
+    x = torch.randn(2, 3, 10, 10)
+    y_cpu = model(x)
+    assert mq.accelerated(model)._plan is None
+    model = model.cuda()
+    n, y = _forward_launches(model, x.cuda())
+    n, y = _forward_launches(model, x.cuda())
+    assert n == 3 and mq.accelerated(model)._plan is not None                # affine table + LUT table + 1 holder
+    assert np.allclose(y.cpu().numpy(), y_cpu.detach().numpy(), atol=1e-3)
+    before = _quantized_weights(model)
+    with torch.no_grad():
+        model.conv.weight.mul_(0.5)                                          # an optimizer step, in place
+    _forward_launches(model, x.cuda())
+    after = _quantized_weights(model)
+    assert not bits_equal(before["conv.weight"], after["conv.weight"])
+    ref = _small_model("cuda")
+    with torch.no_grad():
+        ref.conv.weight.mul_(0.5)
+        ref(x.cuda())
+    assert bits_equal(after["conv.weight"], _quantized_weights(ref)["conv.weight"])
+    model = model.cpu()                                                      # and back: per-layer calls again, no error
+    assert torch.equal(model(x), ref.cpu()(x))
+
+
+@pytest.mark.gpu
+def test_accelerate_with_example_inputs_captures_the_forward():
+    model = workloads.wrapped_resnet50("cuda")
+    x = torch.randn(1, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        want = model(x).clone()
+    mq.accelerate(model)
+    captured = mq.accelerate(model, example_inputs=(x,))
+    assert mq.accelerated(model) is None                                     # the capture brought its own batcher
+    got = captured(x)
+    assert torch.equal(got, want)
+    x2 = torch.randn(1, 3, 64, 64, device="cuda")
+    got2 = captured(x2).clone()
+    captured.release()
+    with torch.no_grad():
+        assert torch.equal(model(x2), got2)

@@ -12,7 +12,8 @@ import torch.multiprocessing as mp
 
 KEYS = {"workload", "scaling", "rows_per_rank", "compute_ms", "compute_elems_per_s", "allgather_ms",
         "allgather_recv_bytes_per_rank", "allgather_recv_gbs_per_rank", "compute_plus_allgather_elems_per_s",
-        "gathered_rows_match_local", "ranks", "allgather_gbs_per_link", "allgather_output"}
+        "gathered_rows_match_local", "ranks", "allgather_gbs_per_link", "allgather_output", "allgather_backend",
+        "allgather_device", "allgather_local_copy_gbs", "gathered_equals_reference_digest"}
 
 
 def _free_port():
