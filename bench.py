@@ -101,18 +101,32 @@ def parse():
                     help="config 3: batches per replay of the activation stream (pytorch/graphs.py: CapturedStream; one fused "
                          "batched launch per D batches).  0 = automatic (on for --batch <= 64, D = the largest divisor of "
                          "--steps that is <= 32 and <= steps / 2), -1 = off (one eager call per batch)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="STORAGE type of the tensors (arithmetic is float32 always): bf16 / f16 = SURVEY 8(f3), the affine "
+                         "kernels read and write 2 B per element (4 B/el algorithmic), the LUT kernels read 2 and write 4")
+    ap.add_argument("--e2e", action="store_true",
+                    help="with --config resnet50: a step is one FORWARD of a wrapped ResNet-50 loaded through "
+                         "pytorch_load_quantized_model (per-layer vs auto-batched vs captured; bench_e2e.py)")
+    ap.add_argument("--e2e-lut", action="store_true", help="--e2e with 16-entry LUT weights quantizers")
+    ap.add_argument("--e2e-side", type=int, default=224, help="--e2e: image side")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: dry run of the entry path over gloo (tests); not a measurement")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
+    return args
 
 
-def metric_label(config: str, wl, batched: int) -> str:
-    if config == "cfg2" and not batched:
+DTYPE_NAMES = {"f32": "fp32", "bf16": "bf16", "f16": "fp16"}
+
+
+def metric_label(config: str, wl, batched: int, dtype: str = "f32") -> str:
+    if config == "cfg2" and not batched and dtype == "f32":
         return BASELINE_METRIC
+    dn = DTYPE_NAMES[dtype]
     if config in ("resnet50", "linear16"):
-        return f"elems/s + achieved HBM GB/s, {wl.name} fp32, one batched launch per step"
+        return f"elems/s + achieved HBM GB/s, {wl.name} {dn}, one batched launch per step"
     tail = f", {batched} tensors per launch" if batched else ""
-    return f"elems/s + achieved HBM GB/s, {wl.name} {'x'.join(str(s) for s in wl.shape)} fp32{tail}"
+    return f"elems/s + achieved HBM GB/s, {wl.name} {'x'.join(str(s) for s in wl.shape)} {dn}{tail}"
 
 
 def graph_ok_for_calibration(args) -> bool:
@@ -175,6 +189,11 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (child process; nothing here has touched the GPU)
         sys.exit(bench_dist.self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+    if args.e2e:
+        if args.config != "resnet50" or args.gpus != 1:
+            raise SystemExit("--e2e goes with --config resnet50 at --gpus 1")
+        import bench_e2e
+        sys.exit(bench_e2e.main(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,6 +248,14 @@ def main():
         x_np = workloads.make_input(args.config, batch=args.batch)
         wl = workloads.make_workload(args.config, x_np)
         quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
+    tdtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    is_lut = "LUT" in wl.quantizer or "Lut" in wl.quantizer
+    if args.dtype != "f32":
+        if dry or args.graph or args.streams > 1:
+            raise SystemExit("--dtype bf16 / f16: eager or batched launches on the GPU only")
+        # algorithmic bytes: 16-bit in; the affine kernels write the input's type, the LUT kernels float32 (the reference's
+        # chain promotes once the float32 codebook enters, quantizer_utils.py:131-137)
+        wl.bytes_per_elem = 2 + (4 if is_lut else 2)
     tensors = max(1, args.batched)
     per_launch = 1                               # steps served by one launch (activation stream: D batches per replay)
     stream_on = (args.config == "cfg3" and not args.batched and not dry and not args.graph and args.streams == 1
@@ -240,7 +267,7 @@ def main():
     elems = wl.numel if model_mode else wl.numel * tensors
     alg_bytes = elems * wl.bytes_per_elem        # per STEP
     ring = args.ring or max(2, -(-(512 << 20) // (alg_bytes * per_launch)) + 1)
-    x0 = None if model_mode else torch.from_numpy(x_np).to(device)
+    x0 = None if model_mode else torch.from_numpy(x_np).to(device).to(tdtype)
     streams = None
     if stream_on:
         from mct_quantizers_amd.pytorch.graphs import capture_stream
@@ -255,7 +282,7 @@ def main():
         for _ in range(ring):
             items, ys_ = [], []
             for (xw, _), q in zip(weights, quantizers):
-                xi, scales, zps, axis, qmin, qmax = q.batch_item(torch.from_numpy(xw).to(device))
+                xi, scales, zps, axis, qmin, qmax = q.batch_item(torch.from_numpy(xw).to(device).to(tdtype))
                 y = torch.empty_like(xi)
                 items.append((xi, y, scales, zps, axis, qmin, qmax))
                 ys_.append(y)
@@ -362,7 +389,7 @@ def main():
     achieved_wall = alg_bytes / (wall_us * 1e-6) / 1e9
 
     result = {
-        "metric": metric_label(args.config, wl, args.batched),
+        "metric": metric_label(args.config, wl, args.batched, args.dtype),
         "value": value,
         "unit": "elems/s",
         "n_gpus": world,
@@ -373,16 +400,20 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,                                  # the tensors' STORAGE type; arithmetic is float32 (config.arithmetic)
         "data": "synthetic (portable splitmix64 generator, mct_quantizers_amd/workloads.py)",
         "config": {"workload": wl.name + (f", {tensors} tensors in one batched launch" if args.batched and not model_mode else
                                           ", one batched launch per step" if model_mode else ""),
                    "shape": list(wl.shape), "quantizer": wl.quantizer, "tensors_per_step": tensors,
+                   "storage": DTYPE_NAMES[args.dtype], "arithmetic": "fp32",
+                   "algorithmic_bytes_per_elem": wl.bytes_per_elem,
                    "per_gpu_elems": elems, "buffer_ring": ring, "cache_protocol": "cold" if ring > 1 else "warm",
                    "launch": ("hipGraph" if graph is not None else
-                              f"activation stream: {per_launch} batches per fused batched launch (pytorch/graphs.py "
-                              f"CapturedStream, mode {act_streams[0].mode}); a batch's result is ready when its group's "
-                              f"launch completes" if stream_on else "eager"),
+                              f"fused group of {per_launch} independent batches per launch (pytorch/graphs.py CapturedStream, mode "
+                              f"{act_streams[0].mode}): a THROUGHPUT mode for a producer that owns {per_launch} batches at once -- a "
+                              f"batch's result is ready when its group's launch completes; NOT what a holder does inside one "
+                              f"forward (reference activation_quantization_holder.py:43-53): that is eager_us_per_batch / eager_frac"
+                              if stream_on else "eager (one holder / quantizer call per batch)"),
                    "steps_per_launch": per_launch, "streams": args.streams,
                    "binding": "none (dry run)" if dry else ("compiled" if native.fast() is not None else "ctypes"),
                    "prewarm_s": round(prewarm_s, 3), "prewarm_steps": n_pre,
@@ -414,6 +445,34 @@ def main():
         dist.all_gather(got, t)
         result["per_rank_kernel_us"] = [float(v[0]) for v in got]
 
+    # ---- config 3: the EAGER per-call figure, always beside a fused-group line (outside the timed region) -------------
+    if args.config == "cfg3" and not dry and not args.batched:
+        try:
+            holder_e = mq.PytorchActivationQuantizationHolder(quantizer).to(device)
+            ring_e = max(2, -(-(512 << 20) // alg_bytes) + 1)
+            xs_e = [x0] + [x0.clone() for _ in range(min(ring_e, 64) - 1)]
+            for i in range(20):
+                holder_e(xs_e[i % len(xs_e)])
+            n_e = max(200, min(2000, args.steps))
+            torch.cuda.synchronize()
+            ee0, ee1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            h0 = time.perf_counter()
+            ee0.record()
+            for i in range(n_e):
+                holder_e(xs_e[i % len(xs_e)])
+            h1 = time.perf_counter()
+            ee1.record()
+            torch.cuda.synchronize()
+            e_us = ee0.elapsed_time(ee1) * 1e3 / n_e
+            result["eager_us_per_batch"] = e_us
+            result["eager_host_us_per_call"] = (h1 - h0) * 1e6 / n_e
+            result["eager_frac"] = alg_bytes / e_us / 1e3 / HBM_PEAK_GBS
+            result["eager_is"] = (f"{n_e} back-to-back holder(x) calls, one launch per batch, HIP events on the launch stream; "
+                                  f"host-bound when eager_host_us_per_call ~= eager_us_per_batch")
+            del xs_e
+        except Exception as e:  # noqa: BLE001
+            result["eager_us_per_batch"] = {"error": repr(e)[:200]}
+
     # ---- per-launch evidence pass (outside the timed region) ---------------------------------------------
     if args.evidence_launches > 0 and graph is None and streams is None and not dry:
         try:
@@ -439,6 +498,8 @@ def main():
                     key = f"{key}_batched{tensors}"
                 if stream_on:
                     key = f"{key}_stream{per_launch}"
+                if args.dtype != "f32":
+                    key = f"{key}_{args.dtype}"
                 rec = json.load(f).get(key)
             result["roofline"]["traffic_key"] = key
             if rec is None:
@@ -532,7 +593,7 @@ def main():
             result["extras_error"] = repr(e)[:200]
 
     # ---- default run at N = 1: the headline tensor 16 times in ONE batched launch (outside the judged region) -------
-    if (not dry and world == 1 and args.config == "cfg2" and not args.batched and not args.no_batched_extra
+    if (not dry and world == 1 and args.config == "cfg2" and args.dtype == "f32" and not args.batched and not args.no_batched_extra
             and graph is None and streams is None and hasattr(quantizer, "batch_item") and native.fast() is not None):
         try:
             T = 16
@@ -579,7 +640,7 @@ def main():
         # CPU baseline of the model workloads: ATen's CPU operator on every weight in turn, oracle-derived parameters
         from oracle import torch_cpu
         fs = [torch_cpu.prepare("WeightsSymmetricInferableQuantizer", kw) for _, kw in weights]
-        xcs = [torch.from_numpy(xw) for xw, _ in weights]
+        xcs = [torch.from_numpy(xw).to(tdtype) for xw, _ in weights]
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         wants = [f(x) for f, x in zip(fs, xcs)]
         same = all(bool(torch.equal(y.cpu(), w)) for y, w in zip(y_last, wants))
@@ -601,7 +662,7 @@ def main():
     elif rank == 0 and world == 1 and not args.no_cpu and not dry:
         from oracle import torch_cpu
         f = torch_cpu.prepare(wl.quantizer, wl.kwargs)
-        x_cpu = torch.from_numpy(x_np)
+        x_cpu = torch.from_numpy(x_np).to(tdtype)          # the same rounding to the storage type as on the device
         y_cpu = f(x_cpu)                                   # warm-up + parity reference
         if args.batched or stream_on:
             same = all(bool(torch.equal(y.cpu(), y_cpu)) for y in y_last[:2]) and \

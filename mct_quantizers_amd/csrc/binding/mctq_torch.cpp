@@ -397,7 +397,7 @@ PyTypeObject AffinePlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 // fast(x) -> tensor | NotImplemented: checks, in C, that none of that machinery is in use and that the objects the
 // launch state was derived from are still the ones in place --
 //   every dict in `hook dicts` is empty (the module's and torch's global forward / backward hook tables),
-//   holder.__dict__["_compiled_call_impl"] is None, holder.__dict__["activation_holder_quantizer"] is `quantizer`,
+//   holder.__dict__ has no "_compiled_call_impl" other than None, holder.__dict__["activation_holder_quantizer"] is `quantizer`,
 //   (check_bypass) holder.__dict__["quantization_bypass"] is False,
 //   quantizer.__dict__["_plan"] is `plan` (assigning to a public parameter of the quantizer drops its plan) --
 // and then makes the plan's call (which itself declines anything but a plain eager HIP tensor).
@@ -423,7 +423,9 @@ PyObject* holdercall_vectorcall(PyObject* self, PyObject* const* args, size_t na
   const Py_ssize_t nd = PyTuple_GET_SIZE(h->hook_dicts);
   for (Py_ssize_t i = 0; i < nd; ++i)
     if (PyDict_GET_SIZE(PyTuple_GET_ITEM(h->hook_dicts, i)) != 0) return not_implemented();
-  if (PyDict_GetItem(h->holder_dict, kw_compiled) != Py_None) return not_implemented();
+  // (a class attribute of nn.Module, None, until Module.compile() sets it on the instance)
+  PyObject* compiled = PyDict_GetItem(h->holder_dict, kw_compiled);
+  if (compiled != nullptr && compiled != Py_None) return not_implemented();
   if (PyDict_GetItem(h->holder_dict, kw_quantizer) != h->quantizer) return not_implemented();
   if (h->check_bypass && PyDict_GetItem(h->holder_dict, kw_bypass) != Py_False) return not_implemented();
   if (PyDict_GetItem(h->quantizer_dict, kw_plan) != h->plan) return not_implemented();

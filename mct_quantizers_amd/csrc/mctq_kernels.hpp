@@ -441,7 +441,11 @@ struct LutTableOp : LutCommon {
   __device__ __forceinline__ Prefetch prefetch() const {
     const f32x2* src = reinterpret_cast<const f32x2*>(table);
     Prefetch p;
-#ifdef MCTQ_ABLATE_STAGE            // timing experiment: no table traffic, no LDS writes, no barrier (results wrong)
+#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE != 3   // timing experiments (results wrong): 1 = no table traffic, no LDS
+    return p;                                                 // writes, no barrier; 2 = the barrier only; 3 = loads + LDS writes,
+#endif                                                        // no barrier; 4 = a quarter of the table (1 KB), barrier kept
+#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 4
+    if ((int)threadIdx.x * 4 <= entries) p.r[0] = src[threadIdx.x];
     return p;
 #endif
 #pragma unroll
@@ -453,14 +457,22 @@ struct LutTableOp : LutCommon {
   }
   __device__ __forceinline__ Book commit(const Prefetch& p, float* lds) const {
     f32x2* dst = reinterpret_cast<f32x2*>(lds);
-#ifdef MCTQ_ABLATE_STAGE
+#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 4
+    if ((int)threadIdx.x * 4 <= entries) dst[threadIdx.x] = p.r[0];
+    { __syncthreads(); Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
+#elif defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 1
     { Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
+#elif defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 2
+    { __syncthreads(); Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
 #endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = (int)threadIdx.x + i * kThreads;
       if (j <= entries) dst[j] = p.r[i];
     }
+#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 3
+    { Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
+#endif
     __syncthreads();
     Book b; b.tab = dst; b.nan_q = dst[entries].x;
     return b;
@@ -842,6 +854,49 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const TI* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------
+// rowsteps: rows that are a whole number of 256-lane-vector STEPS but fewer than four of them (float32 rows of 1024 /
+// 2048 / 3072 elements, 16-bit rows of 2048 / 4096 / 6144).  rows_kernel gives such rows one- or two-step tiles -- 16 or
+// 32 bytes in flight per lane; here a block takes U consecutive steps of the dense [rows][innerv] storage whatever row they
+// fall in (64 bytes in flight per lane, one contiguous 16 KiB read per block), and each step -- which lies inside ONE row --
+// gets that row's parameters by scalar loads, as in rows_kernel.
+// ------------------------------------------------------------------------------------------
+template <class Op, class TI, class TO, int U, int NT>
+__global__ __launch_bounds__(kThreads) void rowsteps_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,
+                                                            uint32_t steps_per_row, uint32_t total_steps, uint32_t channels,
+                                                            Op op) {
+  typedef IO<TI, TO> io;
+  const uint32_t s0 = blockIdx.x * U;
+  const int64_t first = (int64_t)s0 * kThreads + threadIdx.x;
+  const bool full = s0 + U <= total_steps;                   // wave-uniform
+  typename io::VI v[U];
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(xs + (first + u * kThreads) * io::N);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s0 + u < total_steps) v[u] = io::template load<NT>(xs + (first + u * kThreads) * io::N);
+  }
+  __builtin_amdgcn_sched_barrier(0);                         // loads first; the parameter fetches run under their latency
+  uint32_t row = s0 / steps_per_row, rem = s0 - row * steps_per_row;   // one scalar division per block
+  typename Op::Param p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (full || s0 + u < total_steps) p[u] = op.fetch(row >= channels ? row % channels : row);
+    if (++rem == steps_per_row) { rem = 0; ++row; }
+  }
+  const typename Op::Book book = typename Op::Book();
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (full || s0 + u < total_steps) {
+      typename io::VI one[1] = {v[u]};
+      typename io::VO res[1];
+      run_vectors<true, Op, TI, TO, 1>(op, one, res, p[u], book);
+      io::template store<NT>(ys + (first + u * kThreads) * io::N, res[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Heavy ops: persistent blocks.  The work is cut into tiles of 256*U lane-vectors (tiles never
 // cross a row); block b takes tiles b, b+grid, b+2*grid, ... so every CU finishes at the same time
 // (a one-block-per-row grid leaves the last round of blocks mostly empty), prefetches the next
@@ -1100,6 +1155,7 @@ inline void note(const char* shape, int unroll, int nt) {
   g_note.in_bytes = (int)sizeof(TI); g_note.out_bytes = (int)sizeof(TO);
   ++g_note.count;
 }
+extern int g_rowsteps;       // 1: short whole-step rows go to rowsteps_kernel (default); 0: rows_kernel as before
 extern int g_heavy_unroll;   // 0 = automatic
 extern int g_heavy_persistent;
 int fail_arg(const char* msg);
@@ -1304,6 +1360,19 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         const int64_t tiles = (innerv + per - 1) / per;
         const int64_t waste = tiles * per - innerv;
         if (best_waste < 0 || waste <= best_waste) { best_waste = waste; best_u = u; }
+      }
+      if constexpr (std::is_same<Op, AffineOp>::value) {
+        // rows of 1 .. 3 whole steps: four steps per block across row boundaries (rowsteps_kernel)
+        const int64_t total_steps = rows * (innerv / kThreads);
+        if (g_rowsteps && best_u < 4 && g_unroll >= 4 && innerv % kThreads == 0 && total_steps <= 0xffffffffLL) {
+          MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), false, {
+            constexpr int U = 4;
+            hipLaunchKernelGGL((rowsteps_kernel<Op, TI, TO, U, NT>), dim3((unsigned)((total_steps + U - 1) / U)), dim3(kThreads),
+                               0, st, x, y, (uint32_t)(innerv / kThreads), (uint32_t)total_steps, (uint32_t)channels, op);
+            note<Op, TI, TO>("rowsteps_kernel", U, NT);
+          });
+          return check_launch("rowsteps launch");
+        }
       }
       if (!(std::is_same<TI, float>::value && std::is_same<TO, float>::value) && best_u < 2) best_u = 2;   // built: U = 2, 4
       const int64_t per = (int64_t)kThreads * best_u;

@@ -159,7 +159,37 @@ def make_model_weights(name: str):
 # ---- a whole wrapped MODEL (what MCT exports: every convolution under a PytorchQuantizationWrapper, every activation
 # behind a holder; quantize_wrapper.py:212-258, activation_quantization_holder.py:43-53) -------------------------------
 
-LUT16 = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+LUT16 = CFG4_LUT
+
+
+def __getattr__(name):
+    # ``_Bottleneck`` is created on first use (torch is imported lazily in this module); un-pickling a saved model in a
+    # fresh process asks for it by name
+    if name == "_Bottleneck":
+        return _bottleneck_class()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+def _bottleneck_class():
+    """ResNet-50's bottleneck block over already wrapped convolutions; reachable as a module attribute so that
+    ``torch.save(model)`` can pickle it (MCT ships whole pickled modules, reference pytorch/load_model.py:23-34)."""
+    import torch.nn as nn
+    if "_Bottleneck" in globals():
+        return globals()["_Bottleneck"]
+
+    class Bottleneck(nn.Module):
+        def __init__(self, c1, a1, c2, a2, c3, down, a3):
+            super().__init__()
+            self.c1, self.a1, self.c2, self.a2, self.c3, self.down, self.a3 = c1, a1, c2, a2, c3, down, a3
+
+        def forward(self, x):
+            y = self.c3(self.a2(self.c2(self.a1(self.c1(x)))))
+            return self.a3(y + (x if self.down is None else self.down(x)))
+
+    Bottleneck.__name__ = Bottleneck.__qualname__ = "_Bottleneck"
+    Bottleneck.__module__ = __name__
+    globals()["_Bottleneck"] = Bottleneck
+    return Bottleneck
 
 
 def wrapped_resnet50(device="cuda", weights: str = "symmetric", holders: bool = True):
@@ -171,6 +201,7 @@ def wrapped_resnet50(device="cuda", weights: str = "symmetric", holders: bool = 
     import torch.nn as nn
     import mct_quantizers_amd as mq
     Q = mq.pytorch_quantizers
+    Bottleneck = _bottleneck_class()
     stock = iter(make_model_weights("resnet50"))
 
     def wrap(layer):
@@ -192,24 +223,19 @@ def wrapped_resnet50(device="cuda", weights: str = "symmetric", holders: bool = 
         return nn.Sequential(nn.ReLU(), mq.PytorchActivationQuantizationHolder(
             Q.ActivationSymmetricInferableQuantizer(num_bits=8, threshold=[8.0], signed=False)))
 
-    class Bottleneck(nn.Module):
-        def __init__(self, cin, width, stride, first):
-            super().__init__()
-            self.c1, self.a1 = wrap(nn.Conv2d(cin, width, 1, bias=False)), act()
-            self.c2, self.a2 = wrap(nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)), act()
-            self.c3 = wrap(nn.Conv2d(width, width * 4, 1, bias=False))
-            self.down = wrap(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False)) if first else None
-            self.a3 = act()
-
-        def forward(self, x):
-            y = self.c3(self.a2(self.c2(self.a1(self.c1(x)))))
-            return self.a3(y + (x if self.down is None else self.down(x)))
+    def block(cin, width, stride, first):
+        # construction order = forward order of make_model_weights: 1x1, 3x3, 1x1, downsample
+        c1, a1 = wrap(nn.Conv2d(cin, width, 1, bias=False)), act()
+        c2, a2 = wrap(nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)), act()
+        c3 = wrap(nn.Conv2d(width, width * 4, 1, bias=False))
+        down = wrap(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False)) if first else None
+        return Bottleneck(c1, a1, c2, a2, c3, down, act())
 
     layers = [wrap(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)), act(), nn.MaxPool2d(3, 2, 1)]
     cin = 64
     for width, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
         for b in range(blocks):
-            layers.append(Bottleneck(cin, width, stride if b == 0 else 1, b == 0))
+            layers.append(block(cin, width, stride if b == 0 else 1, b == 0))
             cin = width * 4
     layers += [nn.AdaptiveAvgPool2d(1), nn.Flatten(), wrap(nn.Linear(2048, 1000, bias=False))]
     return nn.Sequential(*layers).to(device).eval()
