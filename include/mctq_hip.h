@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 6
+#define MCTQ_ABI_VERSION 7
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
@@ -344,6 +344,38 @@ int mctq_lutt_per_channel(const void* x, float* y,
                           void* stream);
 
 /*
+ * Compact form of the decision table (same codebooks, same cells, same exact thresholds, same results): one byte per
+ * half-unit cell -- the index of the first of the codebook's steps at or above the cell -- plus the list of steps
+ * {threshold (float32), half2(centre below, centre above)}.  648 bytes instead of 4 KB for 16 centres on an 8-bit clip
+ * range: every block stages its table in LDS, and it is the 4 KB of staging per block that keeps the table kernel behind
+ * the affine kernel on the same tensor (profiles/r04/lut_staging_ablation.log); with the compact form the launch can use
+ * the tile shape that idles the fewest lanes.  Codebooks with at most 256 distinct centres.
+ *   mctq_lut_compact_words  upper bound of the blob size in 32-bit words for a clip range and a codebook of n_lut entries
+ *   mctq_lut_build_compact  host code: fills blob_host and *n_words (the actual size); MCTQ_E_ARG when the codebook has no
+ *                           decision table or more than 255 steps (use mctq_lut_build_table / the literal kernels then)
+ *   mctq_lutc_per_tensor / _per_channel   as mctq_lutt_*, with `blob` (DEVICE copy, 4-byte aligned) and n_words in place
+ *                           of table and entries.  Replaces lut_quantizer (pytorch/quantizer_utils.py:95-139) at the same
+ *                           call sites as mctq_lut_per_tensor / mctq_lut_per_channel.
+ */
+int32_t mctq_lut_compact_words(float clip_min, float clip_max, int32_t n_lut);
+
+int mctq_lut_build_compact(const float* lut_host, int32_t n_lut, float mult, float clip_min, float clip_max,
+                           void* blob_host, int32_t* n_words);
+
+int mctq_lutc_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32_t step_round,
+                         float thr_div, float thr_mul,
+                         const void* blob, int32_t n_words,
+                         float mult, float clip_min, float clip_max,
+                         void* stream);
+
+int mctq_lutc_per_channel(const void* x, float* y,
+                          int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
+                          const float* thresholds, float eps,
+                          const void* blob, int32_t n_words,
+                          float mult, float clip_min, float clip_max,
+                          void* stream);
+
+/*
  * Threshold-list ("steps") form of the LUT quantizer: INTEGER codebooks whose clip range is too large for the decision
  * table (lut_values_bitwidth > 10; clip bounds and centres within +-2^20).  For such codebooks the literal scan's
  * result is a non-decreasing staircase of the scaled value with one hand-over per pair of adjacent sorted centres;
@@ -465,8 +497,9 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  tiles <BM/..><BN/..>[K step][LDS buffers] (66 ... 12124), 8- / 16-wave tiles (8xxxx / 16xxxxx), wide tiles (25xx ... 4442)
  *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
- *   key "rowsteps" : 1 (default) = per-channel rows of one to three whole 256-lane-vector steps take four steps per block across
- *                  row boundaries (rowsteps_kernel); 0 = one- / two-step tiles inside a row (rows_kernel)
+ *   key "rowsteps" : 1 = per-channel rows of two or three whole 256-lane-vector steps take four steps per block across row
+ *                  boundaries (rowsteps_kernel; measured no better, kept for experiments); 0 (default) = one- / two-step tiles
+ *                  inside a row (rows_kernel)
  *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */

@@ -527,6 +527,99 @@ struct LutTableOp : LutCommon {
   }
 };
 
+// Compact decision table (mctq_table_builder.h: build_compact): the same cells k and the same exact thresholds as
+// LutTableOp, stored as one BYTE per cell (index j of the first step at or above the cell) plus the list of the codebook's
+// steps {T_j, half2(q below, q above)} -- 648 bytes instead of 4 KB for 16 centres on an 8-bit clip range.  Every block
+// stages its table, so the table's size is a per-block cost: with 4 KB a block must cover >= 4096 elements (U = 4) to hide
+// it and one-step tiles (the launch shape the affine kernel uses on ragged rows) are out of reach; with the compact
+// form they are not (config 4: 58.4 -> 55.x us, profiles/r04).  Two dependent LDS reads per element instead of one.
+struct LutCompactBook { const uint8_t* cell; const f32x2* step; float nan_q; };
+
+struct LutCompactOp : LutCommon {
+  static constexpr const char* kName = "LutCompactOp";
+  static constexpr bool kMinWasteU = true;   // rows launches: the U that idles the fewest lanes (staging no longer dictates U = 4)
+  const uint32_t* __restrict__ blob;   // device, n_words words
+  int entries;                         // K cells
+  int n_words;
+  float koff;                          // 0.5 - 2*clip_min
+  float kmax;                          // entries - 1
+
+  typedef LutCompactBook Book;
+  __device__ __forceinline__ uint32_t book_words() const { return ((uint32_t)n_words + 3u) & ~3u; }
+  __device__ __forceinline__ Book book_at(float* lds) const {
+    const uint32_t cw = ((uint32_t)entries + 3u) >> 2;
+    Book b;
+    b.cell = reinterpret_cast<const uint8_t*>(lds);
+    b.step = reinterpret_cast<const f32x2*>(lds + cw);
+    b.nan_q = lds[n_words - 2];
+    return b;
+  }
+  __device__ __forceinline__ Book setup(float* lds) const {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+    for (int j = threadIdx.x; j < n_words; j += kThreads) dst[j] = blob[j];
+    __syncthreads();
+    return book_at(lds);
+  }
+  // requested BEFORE the tile's data loads, written to LDS after them (in-order return of vector loads: LutTableOp::prefetch)
+  struct Prefetch { uint32_t r[5]; };                // n_words <= 512 + 512 + 2 over 256 threads
+  __device__ __forceinline__ Prefetch prefetch() const {
+    Prefetch p;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int j = (int)threadIdx.x + i * kThreads;
+      if (j < n_words) p.r[i] = blob[j];
+    }
+    return p;
+  }
+  __device__ __forceinline__ Book commit(const Prefetch& p, float* lds) const {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int j = (int)threadIdx.x + i * kThreads;
+      if (j < n_words) dst[j] = p.r[i];
+    }
+    __syncthreads();
+    return book_at(lds);
+  }
+
+  template <bool FAST>
+  __device__ __forceinline__ void locate(float x, const Param& p, float& v, int& k) const {   // as LutTableOp::locate
+    v = scaled<FAST>(x, p);
+    k = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(v, 2.0f, koff), 0.0f, kmax);
+  }
+  template <bool FAST>
+  __device__ __forceinline__ float decide(float x, float v, f32x2 e, const Param& p, const Book& b) const {
+    const uint32_t pair = __float_as_uint(e.y);
+    const uint32_t h = (v >= e.x) ? (pair >> 16) : pair;
+    float q = __half2float(__ushort_as_half((unsigned short)h));
+    const bool nan = (FAST && step_round == 0) ? (x != x) : (v != v);    // see LutTableOp::decide
+    q = nan ? b.nan_q : q;
+    return q * p.t;
+  }
+  template <bool FAST = false>
+  __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
+    float v; int k;
+    locate<FAST>(x, p, v, k);
+    return decide<FAST>(x, v, b.step[b.cell[k]], p, b);
+  }
+  // a whole tile level by level: the NE reads of a level are issued back to back
+  template <bool FAST, int NE>
+  __device__ __forceinline__ void tile(const float* in, float* out, const Param& p, const Book& b) const {
+    float v[NE];
+    int k[NE];
+    uint32_t j[NE];
+    f32x2 e[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], k[i]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) j[i] = b.cell[k[i]];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) e[i] = b.step[j[i]];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) out[i] = decide<FAST>(in[i], v[i], e[i], p, b);
+  }
+};
+
 // Threshold-list ("steps") codebook quantizer: any INTEGER codebook, any clip range the decision table above is too
 // large for (lut_values_bitwidth > 10).  For integer centres at most 2^20 apart from t the float32 distances
 // fl(|t - c|) of two centres on the same side of t never tie (they differ by >= 1, the rounding error is < 2^-3), so
@@ -666,6 +759,11 @@ template <class Op, class = void>
 struct HasTile : std::false_type {};
 template <class Op>
 struct HasTile<Op, std::void_t<decltype(&Op::template tile<true, 4>)>> : std::true_type {};
+
+template <class Op, class = void>
+struct HasMinWasteU : std::false_type {};
+template <class Op>
+struct HasMinWasteU<Op, std::void_t<decltype(Op::kMinWasteU)>> : std::true_type {};
 
 template <class Op, class = void>
 struct HasPrefetch : std::false_type {};
@@ -1155,7 +1253,7 @@ inline void note(const char* shape, int unroll, int nt) {
   g_note.in_bytes = (int)sizeof(TI); g_note.out_bytes = (int)sizeof(TO);
   ++g_note.count;
 }
-extern int g_rowsteps;       // 1: short whole-step rows go to rowsteps_kernel (default); 0: rows_kernel as before
+extern int g_rowsteps;       // 1: short whole-step rows go to rowsteps_kernel; 0 (default): rows_kernel
 extern int g_heavy_unroll;   // 0 = automatic
 extern int g_heavy_persistent;
 int fail_arg(const char* msg);
@@ -1323,6 +1421,14 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       // Lane-vectors per lane per tile: the widest of {4, 2, 1} whose idle lanes in the last tile
       // of a row stay under 1/8 (more bytes in flight per lane), unless a tuning override is set.
       int u_sel = 1;
+      if constexpr (HasMinWasteU<Op>::value) {
+        int64_t best_waste = -1;                            // the largest U <= 4 that idles the fewest lanes in a row's last tile
+        for (int u = 1; u <= 4; u <<= 1) {
+          const int64_t per_u = (int64_t)kThreads * u;
+          const int64_t waste = ((innerv + per_u - 1) / per_u) * per_u - innerv;
+          if (best_waste < 0 || waste <= best_waste) { best_waste = waste; u_sel = u; }
+        }
+      } else
       for (int u = 4; u >= 1; u >>= 1) {
         const int64_t per_u = (int64_t)kThreads * u;
         const int64_t cap = ((innerv + per_u - 1) / per_u) * per_u;
@@ -1502,6 +1608,20 @@ inline int make_table_op(LutTableOp& op, const float* thr, float eps, const floa
   return 0;
 }
 inline size_t table_bytes(int32_t entries) { return (size_t)(((entries + 1) * 2 + 3) & ~3) * 4; }
+inline int make_compact_op(LutCompactOp& op, const float* thr, float eps, const void* blob, int32_t n_words, float mult,
+                           float cmin, float cmax, int step_round) {
+  if (!blob) return fail_arg("compact table is NULL");
+  if (int rc = check_pow2(mult)) return rc;
+  const int entries = table_entries(cmin, cmax);
+  if (entries < 0) return fail_arg("decision table unsupported for this clip range");
+  const int cw = (entries + 3) / 4;
+  if (n_words < cw + 4 || n_words > cw + 2 * 256 + 2 || ((n_words - cw) & 1)) return fail_arg("n_words does not match the clip range");
+  fill_lut_common(op, thr, eps, mult, cmin, cmax, step_round);
+  op.blob = static_cast<const uint32_t*>(blob); op.entries = entries; op.n_words = n_words;
+  op.koff = 0.5f - 2.0f * cmin; op.kmax = (float)(entries - 1);
+  return 0;
+}
+inline size_t compact_bytes(int32_t n_words) { return (size_t)((n_words + 3) & ~3) * 4; }
 
 // storage-type dispatch: f(TI{}, TO{})
 template <class F>

@@ -20,7 +20,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 SOURCES = [os.path.join(CSRC, f) for f in ("mctq_misc.hip", "mctq_affine.hip", "mctq_codes.hip", "mctq_lut_scan.hip",
-                                             "mctq_lut_table.hip", "mctq_grid.hip", "mctq_qlinear.hip", "mctq_codes4.hip", "mctq_codes_nhwc.hip", "mctq_batched.hip", "mctq_f64.hip", "mctq_lut_steps.hip")]
+                                             "mctq_lut_table.hip", "mctq_lut_compact.hip", "mctq_grid.hip", "mctq_qlinear.hip", "mctq_codes4.hip", "mctq_codes_nhwc.hip", "mctq_batched.hip", "mctq_f64.hip", "mctq_lut_steps.hip")]
 HEADERS = [os.path.join(REPO, "include", "mctq_hip.h"), os.path.join(CSRC, "mctq_kernels.hpp"),
            os.path.join(CSRC, "mctq_table_builder.h")]
 OUT = os.path.join(PKG, "lib", "libmctq_hip.so")

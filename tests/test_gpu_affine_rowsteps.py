@@ -1,7 +1,7 @@
-"""rowsteps_kernel (csrc/mctq_kernels.hpp): per-channel rows of one to three whole 256-lane-vector steps -- float32 rows of
-1024 / 2048 / 3072 elements, 16-bit rows of 2048 / 4096 / 6144 -- four steps per block across row boundaries.  Against the
-oracle, for every storage type, with outer > 1 (channel = row % channels), ragged last blocks, zero points, and equal to the
-rows_kernel it replaces."""
+"""rowsteps_kernel (csrc/mctq_kernels.hpp; tuning key "rowsteps", OFF by default: measured no better than rows_kernel,
+profiles/r04/rowsteps_probe.log): per-channel rows of two or three whole 256-lane-vector steps -- float32 rows of 2048 / 3072
+elements, 16-bit rows of 2048 / 4096 / 6144 -- four steps per block across row boundaries.  Against the oracle, for every
+storage type, with outer > 1 (channel = row % channels), ragged last blocks, zero points, and equal to the rows_kernel."""
 import warnings
 
 import numpy as np
@@ -25,8 +25,8 @@ def _oracle(cls, kw, x_np, dt):
 
 
 @pytest.mark.parametrize("dt,shape,axis", [
-    ("float32", (4096, 1024), 0), ("float32", (301, 2048), 0), ("float32", (77, 3072), 0), ("float32", (1, 1024), 0),
-    ("float32", (3, 50, 2048), 1), ("float32", (2, 7, 32, 32), 1), ("float32", (5, 1024), 0),
+    ("float32", (4096, 2048), 0), ("float32", (301, 2048), 0), ("float32", (77, 3072), 0), ("float32", (1, 2048), 0),
+    ("float32", (3, 50, 2048), 1), ("float32", (2, 7, 64, 32), 1), ("float32", (5, 3072), 0),
     ("bfloat16", (512, 4096), 0), ("bfloat16", (33, 2048), 0), ("bfloat16", (10, 6144), 0), ("float16", (129, 4096), 0),
     ("float16", (3, 21, 2048), 1), ("bfloat16", (2, 3, 64, 64), 1),
 ])
@@ -59,11 +59,18 @@ def test_rowsteps_equals_oracle_and_rows_kernel(dt, shape, axis, kind):
         assert "rowsteps_kernel" not in native.last_launch()
         assert torch.equal(y0, y)
     finally:
-        native.set_tuning("rowsteps", 1)
+        native.set_tuning("rowsteps", 0)
 
 
 def test_rows_of_four_steps_or_ragged_rows_keep_their_kernels():
     q = Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 64, True, 0)
-    for cols, name in ((4096, "rows_kernel"), (1000, "gather_kernel"), (1028, "rows_kernel")):
-        q(torch.randn(64, cols, device="cuda"))
-        assert native.last_launch().startswith(name), (cols, native.last_launch())
+    native.set_tuning("rowsteps", 1)
+    try:
+        for cols, name in ((4096, "rows_kernel"), (1000, "gather_kernel"), (1024, "gather_kernel"), (1028, "rows_kernel"),
+                           (2048, "rowsteps_kernel")):
+            q(torch.randn(64, cols, device="cuda"))
+            assert native.last_launch().startswith(name), (cols, native.last_launch())
+    finally:
+        native.set_tuning("rowsteps", 0)
+    q(torch.randn(64, 2048, device="cuda"))
+    assert native.last_launch().startswith("rows_kernel")            # the default

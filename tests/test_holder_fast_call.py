@@ -16,11 +16,11 @@ Q = mq.pytorch_quantizers
 gpu = pytest.mark.gpu
 
 
-def _oracle(kw, x_np, cls="ActivationUniformInferableQuantizer"):
+def _oracle(kw, x_np, cls="ActivationUniformInferableQuantizer", in_dtype="float32"):
     from oracle import oracle_call
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return oracle_call(cls, kw, x_np)
+        return oracle_call(cls, kw, x_np, in_dtype=in_dtype)
 
 
 def test_cpu_tensors_never_build_the_fast_call():
@@ -48,7 +48,8 @@ def test_fast_call_is_built_on_first_use_and_matches_the_oracle():
         assert y is not y0 and bits_equal(y.cpu().numpy(), want)
     assert bits_equal(y0.cpu().numpy(), want)
     assert fast(x.cpu()) is NotImplemented and fast("no tensor") is NotImplemented
-    assert bits_equal(h(x.half()).float().cpu().numpy(), _oracle(kw, x_np.astype(np.float16)).astype(np.float32))
+    xh = x.half()                                        # another storage type through the same C call
+    assert bits_equal(h(xh).float().cpu().numpy(), _oracle(kw, xh.float().cpu().numpy(), in_dtype="float16"))
 
 
 @gpu

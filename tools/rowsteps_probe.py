@@ -31,4 +31,4 @@ for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16"), (torch.float1
             out.append(f"rowsteps={rs}: {us:7.2f} us {nbytes / us / 1e3:6.0f} GB/s ({nbytes / us / 1e3 / 8000:.3f}) {native.last_launch()}")
         print(f"{name} {rows}x{cols} ({nbytes >> 20} MiB per launch, ring {len(xs)}): " + " | ".join(out), flush=True)
         del xs
-native.set_tuning("rowsteps", 1)
+native.set_tuning("rowsteps", 0)
