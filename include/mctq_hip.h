@@ -347,9 +347,9 @@ int mctq_lutt_per_channel(const void* x, float* y,
  * Compact form of the decision table (same codebooks, same cells, same exact thresholds, same results): one byte per
  * half-unit cell -- the index of the first of the codebook's steps at or above the cell -- plus the list of steps
  * {threshold (float32), half2(centre below, centre above)}.  648 bytes instead of 4 KB for 16 centres on an 8-bit clip
- * range: every block stages its table in LDS, and it is the 4 KB of staging per block that keeps the table kernel behind
- * the affine kernel on the same tensor (profiles/r04/lut_staging_ablation.log); with the compact form the launch can use
- * the tile shape that idles the fewest lanes.  Codebooks with at most 256 distinct centres.
+ * range, two dependent LDS reads per element instead of one.  An experiment on what the per-block staging of the table
+ * costs (profiles/r04/cfg4_lut_experiments.md): equal to the decision-table kernels under the cold benchmark protocol, so
+ * the package's quantizers use it only with MCTQ_COMPACT_LUT=1.  Codebooks with at most 256 distinct centres.
  *   mctq_lut_compact_words  upper bound of the blob size in 32-bit words for a clip range and a codebook of n_lut entries
  *   mctq_lut_build_compact  host code: fills blob_host and *n_words (the actual size); MCTQ_E_ARG when the codebook has no
  *                           decision table or more than 255 steps (use mctq_lut_build_table / the literal kernels then)

@@ -529,15 +529,16 @@ struct LutTableOp : LutCommon {
 
 // Compact decision table (mctq_table_builder.h: build_compact): the same cells k and the same exact thresholds as
 // LutTableOp, stored as one BYTE per cell (index j of the first step at or above the cell) plus the list of the codebook's
-// steps {T_j, half2(q below, q above)} -- 648 bytes instead of 4 KB for 16 centres on an 8-bit clip range.  Every block
-// stages its table, so the table's size is a per-block cost: with 4 KB a block must cover >= 4096 elements (U = 4) to hide
-// it and one-step tiles (the launch shape the affine kernel uses on ragged rows) are out of reach; with the compact
-// form they are not (config 4: 58.4 -> 55.x us, profiles/r04).  Two dependent LDS reads per element instead of one.
+// steps {T_j, half2(q below, q above)} -- 648 bytes instead of 4 KB for 16 centres on an 8-bit clip range; two dependent
+// LDS reads per element instead of one.  Built to test whether the 4 KB staged by every block is what keeps the table
+// kernel behind the affine one on config 4.  Measured (profiles/r04/cfg4_lut_experiments.md): under bench.py's cold,
+// sustained protocol the two forms are equal at U = 4 (58.6-59.2 vs 58.9 us) and one-step tiles, which the small table makes
+// affordable and which win 3 us in short half-warm runs, LOSE 3 us there -- so the decision table stays the default and this
+// op is selected by MCTQ_COMPACT_LUT=1 only.
 struct LutCompactBook { const uint8_t* cell; const f32x2* step; float nan_q; };
 
 struct LutCompactOp : LutCommon {
   static constexpr const char* kName = "LutCompactOp";
-  static constexpr bool kMinWasteU = true;   // rows launches: the U that idles the fewest lanes (staging no longer dictates U = 4)
   const uint32_t* __restrict__ blob;   // device, n_words words
   int entries;                         // K cells
   int n_words;
@@ -759,11 +760,6 @@ template <class Op, class = void>
 struct HasTile : std::false_type {};
 template <class Op>
 struct HasTile<Op, std::void_t<decltype(&Op::template tile<true, 4>)>> : std::true_type {};
-
-template <class Op, class = void>
-struct HasMinWasteU : std::false_type {};
-template <class Op>
-struct HasMinWasteU<Op, std::void_t<decltype(Op::kMinWasteU)>> : std::true_type {};
 
 template <class Op, class = void>
 struct HasPrefetch : std::false_type {};
@@ -1421,14 +1417,6 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       // Lane-vectors per lane per tile: the widest of {4, 2, 1} whose idle lanes in the last tile
       // of a row stay under 1/8 (more bytes in flight per lane), unless a tuning override is set.
       int u_sel = 1;
-      if constexpr (HasMinWasteU<Op>::value) {
-        int64_t best_waste = -1;                            // the largest U <= 4 that idles the fewest lanes in a row's last tile
-        for (int u = 1; u <= 4; u <<= 1) {
-          const int64_t per_u = (int64_t)kThreads * u;
-          const int64_t waste = ((innerv + per_u - 1) / per_u) * per_u - innerv;
-          if (best_waste < 0 || waste <= best_waste) { best_waste = waste; u_sel = u; }
-        }
-      } else
       for (int u = 4; u >= 1; u >>= 1) {
         const int64_t per_u = (int64_t)kThreads * u;
         const int64_t cap = ((innerv + per_u - 1) / per_u) * per_u;

@@ -553,15 +553,17 @@ def make_lut_table(lut_values, mult: float, cmin: float, cmax: float, device):
     if table is None:
         return None
     t = torch.from_numpy(table).to(device)
-    # the same table in its compact form rides on the tensor object: single-tensor launches take it (648 bytes staged per
-    # block instead of 4 KB), the batched table launches keep the full form
+    # (MCTQ_COMPACT_LUT=1) the same table in its compact form rides on the tensor object: single-tensor launches take it,
+    # the batched table launches keep the full form
     compact = native.build_lut_compact(lut_values, mult, cmin, cmax) if USE_COMPACT_LUT else None
     if compact is not None:
         t._mctq_compact = torch.from_numpy(compact).to(device)
     return t
 
 
-USE_COMPACT_LUT = os.environ.get("MCTQ_COMPACT_LUT", "1") not in ("", "0")     # 0: every launch stages the full decision table
+# 1: single-tensor LUT launches stage the compact form of the decision table (648 B instead of 4 KB per block).  Off by
+# default: measured equal to the full table under bench.py's cold protocol (profiles/r04/cfg4_lut_experiments.md)
+USE_COMPACT_LUT = os.environ.get("MCTQ_COMPACT_LUT", "0") not in ("", "0")
 
 
 def _compact_of(table, x):

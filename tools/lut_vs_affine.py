@@ -1,5 +1,7 @@
 """The config-4 tensor (4096 x 11008 float32) through the LUT decision-table kernel and, same tensor and launch grid
-family, through the affine kernel: N launches each, cold ring.  Run plain for timings, or under
+family, through the affine kernel: N launches each, cold ring of inputs AND outputs (the outputs of the last `ring` launches
+stay alive, as in bench.py: a dropped output would hand the next launch the same buffer, whose lines then sit in the 256 MiB
+Infinity Cache -- MCTQ_PROBE_WARM_OUT=1 gives that half-warm protocol, which round 4's first ablations were taken under).  Run plain for timings, or under
 `rocprofv3 --kernel-trace --pmc ...` (tools/gpu_r04_lut_pmc.sh) for per-kernel counters.
     python tools/lut_vs_affine.py [launches] [heavy_unroll]"""
 import os, sys, time
@@ -26,7 +28,12 @@ while time.perf_counter() - t0 < 0.5:
 for name, q in (("lut", qlut), ("affine", qa), ("lut", qlut), ("affine", qa)):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for i in range(n): q(xs[i % ring])
+    keep = [None] * ring
+    warm_out = os.environ.get("MCTQ_PROBE_WARM_OUT", "0") == "1"
+    for i in range(n):
+        y = q(xs[i % ring])
+        if not warm_out: keep[i % ring] = y
     e1.record(); torch.cuda.synchronize()
+    del keep, y
     us = e0.elapsed_time(e1) * 1e3 / n
     print(f"{name:7s} {us:7.2f} us  {nbytes / us / 1e3:6.0f} GB/s  frac {nbytes / us / 1e3 / 8000:.3f}  {native.last_launch()}", flush=True)
