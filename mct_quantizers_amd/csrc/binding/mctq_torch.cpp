@@ -52,7 +52,8 @@ inline int dtype_code(c10::ScalarType t) {
 
 // A plain eager HIP tensor the kernels can take as it is?  (Parameter is allowed: weights arrive as one.)
 inline const at::Tensor* eligible(PyObject* obj, int* dt) {
-  if (!THPVariable_Check(obj)) return nullptr;
+  // exact types only (torch.Tensor, nn.Parameter): no subclass, no __torch_function__ -- and no isinstance() call through
+  // the tensor metaclass on the hot path
   PyTypeObject* tp = Py_TYPE(obj);
   if (tp != (PyTypeObject*)THPVariableClass && tp != (PyTypeObject*)ParameterClass) return nullptr;
   const at::Tensor& x = THPVariable_Unpack(obj);

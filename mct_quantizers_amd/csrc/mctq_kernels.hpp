@@ -28,7 +28,7 @@
 //                 per block, which is the default for every op.
 // The LUT ops stage their codebook table in LDS after the block's data loads are in flight.
 //
-// MCTQ_ABLATE_* / MCTQ_AFFINE_HEAVY are timing-experiment switches (tools/build_ablate.sh); they are
+// MCTQ_ABLATE_* / MCTQ_AFFINE_HEAVY are timing-experiment switches (tools/build_variant.py); they are
 // never defined in the shipped build.
 //
 // Storage types: float32, float16, bfloat16 in; the affine ops write the input type (as ATen

@@ -589,32 +589,6 @@ def test_model_with_lut_and_affine_weights_batches_both_in_plan_mode():
 
 
 @pytest.mark.gpu
-def test_plain_python_bench_gpus_2_on_the_gpu_box():
-    """`python bench.py --gpus 2` as the driver launched BENCH in round 2 (no launcher, no RANK): the script starts
-    torch.distributed.run on itself and rank 0 prints ONE line.  The box has one GPU, so both ranks share it
-    (MCTQ_BENCH_WRAP_DEVICES) and the control plane is gloo (two RCCL ranks cannot share a device): everything of the
-    N > 1 path except the RCCL collectives themselves runs on real kernels."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from conftest import REPO
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MCTQ_BENCH_WRAP_DEVICES="1", MCTQ_BENCH_FORCE_GLOO="1")
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-seconds", "0.1",
-                        "--evidence-launches", "0"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["control_plane"] == "gloo"
-    assert len(d["per_rank_kernel_us"]) == 2 and all(v > 5 for v in d["per_rank_kernel_us"])
-    # (two processes time-slicing ONE GPU: the rate is not a measurement, only sanity)
-    assert d["value"] > 1e9 and d["scaling"] == "weak" and "rows_kernel" in d["roofline"]["kernel"]
-    assert d["ranks_seen"] == 2
-
-
-@pytest.mark.gpu
 def test_captured_forward_with_lut_and_affine_weights_replays_the_batched_launches():
     """capture_forward (one hipGraph for the whole forward) on a model whose wrappers mix affine and LUT weights quantizers:
     both table launches are capture-legal (no allocation, no upload once the plan is warm); replays follow in-place

@@ -1,0 +1,461 @@
+"""GPU parity of the affine quantizers beyond the golden / raw-ABI cases of test_gpu_parity.py: float64 tensors (ATen's
+double arithmetic), the tensor-qparams entry point, every 16-bit input value, config 3 at every batch size against the
+reference's digests, fuzz over bit widths / signs / classes against ATen's CPU operator, launch-state invalidation when a
+public attribute is assigned, ATen's error behaviour.  All against the oracle / reference fixtures / ATen CPU."""
+import hashlib
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bits_equal, finite_equal, first_mismatch, load_json
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mct_quantizers_amd.hip import native
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return native.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def _make(cls, kwargs):
+    import mct_quantizers_amd as mq
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return getattr(mq.pytorch_quantizers, cls)(**kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# float64
+# ---------------------------------------------------------------------------------------------
+
+def test_float64_golden_cases_via_quantizer_classes(lib):
+    """41 (kwargs, float64 input) -> output cases produced by the reference: dtype, strides and every bit."""
+    meta = load_json("cases_f64.json")
+    arrays = np.load(os.path.join(GOLDEN, "cases_f64.npz"))
+    assert len(meta["cases"]) >= 40
+    for c in meta["cases"]:
+        x_np, want = arrays[c["id"] + "_x"], arrays[c["id"] + "_y"]
+        x = _dev(x_np)
+        if c["memory_format"] == "channels_last":
+            x = x.contiguous(memory_format=torch.channels_last)
+        y = _make(c["cls"], c["kwargs"])(x)
+        assert y.is_cuda and y.shape == x.shape and str(y.dtype) == "torch." + c["out_dtype"], c["id"]
+        got = y.cpu().numpy()
+        assert got.dtype == want.dtype and np.array_equal(_bits(got), _bits(want)), \
+            f'{c["id"]} {c["cls"]} {c["shape"]}: {(got != want).sum()} of {got.size} differ'
+
+
+def test_float64_raw_abi_against_oracle_all_layouts(lib):
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for outer, C, inner in ((1, 1, 4099), (3, 5, 7), (2, 6, 64), (1, 4, 2048), (5, 3, 1), (1, 1, 1), (2, 2, 3)):
+        n = outer * C * inner
+        s = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+        z = rng.integers(-4, 5, size=C).astype(np.int32)
+        x = rng.standard_normal(n) * 3.0
+        sd, zd = _dev(s), _dev(z)                                # keep the device tables alive across the launch
+        for offset in (0, 1):                                   # 16-byte aligned and not
+            xb = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+            xb[offset:offset + n] = _dev(x)
+            yb = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+            rc = lib.mctq_fq_per_channel(xb[offset:].data_ptr(), yb[offset:].data_ptr(), outer, C, inner, native.DT_F64,
+                                         sd.data_ptr(), zd.data_ptr(), -8, 7, st)
+            assert rc == 0, native.load().mctq_last_error()
+            want = O.fake_quant_affine_f64(x.reshape(outer, C, inner), s, z, -8, 7, axis=1).reshape(-1)
+            got = yb[offset:offset + n].cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(want)), (outer, C, inner, offset)
+            assert float(yb[offset + n:].abs().sum()) == 0 and float(yb[:offset].abs().sum()) == 0   # no stray writes
+    # per tensor: float qparams and device qparams give the float32-product flavour
+    x = rng.standard_normal(1000) * 3.0
+    xd, yd = _dev(x), torch.empty(1000, dtype=torch.float64, device="cuda")
+    want = O.fake_quant_affine_f64(x, [0.0371], [3], 0, 255)
+    assert lib.mctq_fq_per_tensor(xd.data_ptr(), yd.data_ptr(), 1000, native.DT_F64, 0.0371, 3, 0, 255, st) == 0
+    assert np.array_equal(_bits(yd.cpu().numpy()), _bits(want))
+    sc, zp = _dev(np.float32([0.0371])), _dev(np.int32([3]))
+    yd.zero_()
+    assert lib.mctq_fq_per_tensor_tqp(xd.data_ptr(), yd.data_ptr(), 1000, native.DT_F64, sc.data_ptr(), zp.data_ptr(), 0, 255, st) == 0
+    assert np.array_equal(_bits(yd.cpu().numpy()), _bits(want))
+
+
+# ---------------------------------------------------------------------------------------------
+# tensor-qparams entry point, fx routing of traced reference quantizers
+# ---------------------------------------------------------------------------------------------
+
+def test_tensor_qparams_entry_against_oracle(lib):
+    from mct_quantizers_amd.hip import ops
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(31)
+    for n in (1, 3, 1023, 1024, 4096 + 5, 1 << 20):
+        x_np = (rng.standard_normal(n) * 2).astype(np.float32)
+        s, z = np.float32([0.0173]), np.int32([-2])
+        want = O.fake_quant_affine(x_np, s, z, -128, 127)
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            x = torch.from_numpy(x_np).to(dt).cuda()
+            w = O.narrow(O.fake_quant_affine(x.float().cpu().numpy(), s, z, -128, 127), str(dt).replace("torch.", ""))
+            for got in (ops.fq_per_tensor_tqp(x, _dev(s), _dev(z), -128, 127),
+                        ops._hip_fq_per_tensor_tqp(x, _dev(s), _dev(z), -128, 127),
+                        torch.ops.mctq_amd.fq_per_tensor_tqp(x, _dev(s), _dev(z), -128, 127)):
+                assert got.dtype == dt and bits_equal(got.float().cpu().numpy(), w), (n, dt)
+        assert bits_equal(ops.fq_per_tensor_tqp(_dev(x_np), _dev(s), _dev(z), -128, 127).cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        ops.fq_per_tensor_tqp(_dev(np.float32([1, 2])), torch.tensor([0.1]), _dev(np.int32([0])), -8, 7)   # CPU scale
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3 at the other batch sizes SURVEY §8(d) names
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 64, 256])
+def test_config3_full_size_digests_for_every_batch_size(lib, n):
+    from mct_quantizers_amd import workloads
+    rec = load_json("full_sha.json")["configs"][f"cfg3_n{n}"]
+    x_np = workloads.make_input("cfg3", batch=n)
+    assert hashlib.sha256(x_np.tobytes()).hexdigest() == rec["x_sha256"]
+    wl = workloads.make_workload("cfg3", x_np)
+    y = _make(wl.quantizer, wl.kwargs)(_dev(x_np)).cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest() == rec["y_sha256"]
+
+
+# ---------------------------------------------------------------------------------------------
+# launch state follows the public attributes (the reference reads them on every call)
+# ---------------------------------------------------------------------------------------------
+
+def test_public_attribute_changes_take_effect(lib):
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    x = torch.randn(3, 64, device="cuda")
+    q = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
+    a = q(x)
+    q.scale = q.scale * 2
+    b = q(x)
+    assert torch.equal(b, torch.fake_quantize_per_tensor_affine(x, q.scale, q.zero_point, 0, 255)) and not torch.equal(a, b)
+    q.zero_point = 100
+    assert torch.equal(q(x), torch.fake_quantize_per_tensor_affine(x, q.scale, 100, 0, 255))
+    qs = Q.ActivationSymmetricInferableQuantizer(8, [2.0], True)
+    qs.scales = 0.05
+    assert torch.equal(qs(x), torch.fake_quantize_per_tensor_affine(x, 0.05, 0, -128, 127))
+    w = torch.randn(3, 64, device="cuda")
+    qw = Q.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0, 3.0], True, 0)
+    base = qw(w.clone())
+    qw.zero_points[0] = 5                                           # in-place edit of the device tensor
+    got = qw(w.clone())
+    want = torch.fake_quantize_per_channel_affine(w, qw.scales, qw.zero_points, 0, -128, 127)
+    assert torch.equal(got, want) and not torch.equal(got, base)
+    qw.scales = qw.scales * 0.5                                     # replaced tensor
+    assert torch.equal(qw(w.clone()), torch.fake_quantize_per_channel_affine(w, qw.scales, qw.zero_points, 0, -128, 127))
+    qt = Q.WeightsUniformInferableQuantizer(8, [-1.0], [1.0], False)
+    qt.scales.mul_(2.0)
+    assert torch.equal(qt(w.clone()), torch.fake_quantize_per_tensor_affine(w, qt.scales, qt.zero_points, 0, 255))
+    import copy
+    import pickle
+    for obj in (q, qs, qw, qt):
+        clone = pickle.loads(pickle.dumps(obj))
+        assert torch.equal(clone(w.clone()), obj(w.clone())) and torch.equal(copy.deepcopy(obj)(w.clone()), obj(w.clone()))
+    # clamp domains beyond the kernels' float32 bounds are accepted, as in the reference, and run ATen's operator on the GPU
+    wide = Q.ActivationSymmetricInferableQuantizer(30, [2.0], True)
+    big = torch.randn(3, 64, device="cuda") * 1e5
+    assert torch.equal(wide(big), torch.fake_quantize_per_tensor_affine(big, wide.scales, 0, -2 ** 29, 2 ** 29 - 1))
+    ww = Q.WeightsSymmetricInferableQuantizer(28, [1.0, 2.0, 3.0], True, 0)
+    assert torch.equal(ww(big.clone()), torch.fake_quantize_per_channel_affine(big, ww.scales, ww.zero_points, 0, -2 ** 27, 2 ** 27 - 1))
+
+
+def test_parameters_on_another_device_raise_cleanly(lib):
+    from mct_quantizers_amd.hip import ops
+    x = torch.randn(4, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="same device"):
+        ops.fq_per_channel(x, torch.ones(4), torch.zeros(4, dtype=torch.int32), 0, -8, 7)
+    with pytest.raises(RuntimeError, match="same device"):
+        ops.fq_codes(x, torch.ones(4), torch.zeros(4, dtype=torch.int32), 0, -8, 7)
+    with pytest.raises(RuntimeError, match="same device"):
+        ops.lut_per_channel(x, torch.tensor([0.0, 1.0]), torch.ones(4, device="cuda"), 1e-8, 0, 128.0, -128.0, 127.0)
+
+
+def test_fuzz_float64_tensor_qparams_and_batched_against_aten_cpu(lib):
+    """Seeded fuzz over ranks, shapes, axes, permuted storage and ALL FOUR storage types (incl. float64), for the
+    per-channel quantizers, the per-tensor weights quantizers (tensor qparams) and the activation quantizers; every
+    dense case is also pushed through the batched launch and must give the same bits.  Reference: ATen's CPU
+    operators on the same tensor (what the reference package executes)."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "77")))
+    pending = []
+    for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "140"))):
+        rank = int(rng.integers(1, 5))
+        shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 64])) for _ in range(rank)]
+        if rng.random() < 0.3:
+            shape[int(rng.integers(0, rank))] = int(rng.choice([257, 1024, 1030, 4096, 8192]))
+        if int(np.prod(shape, dtype=np.int64)) > (1 << 24):
+            continue
+        axis = int(rng.integers(0, rank))
+        dt = [torch.float32, torch.float64, torch.float64, torch.float16, torch.bfloat16][int(rng.integers(0, 5))]
+        bits = int(rng.choice([2, 4, 8]))
+        x = torch.from_numpy(rng.standard_normal(shape) * 3).to(dt)
+        perm = list(rng.permutation(rank))
+        x = x.permute(perm).contiguous().permute(list(np.argsort(perm)))
+        C = x.shape[axis]
+        kind = int(rng.integers(0, 4))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == 0:
+                q = Q.WeightsSymmetricInferableQuantizer(bits, [float(v) for v in rng.uniform(0.2, 6.0, size=C)], True, axis)
+                ref = lambda t, q=q, axis=axis: torch.fake_quantize_per_channel_affine(   # noqa: E731
+                    t, q.scales.cpu(), q.zero_points.cpu(), axis, q.min_quantized_domain, q.max_quantized_domain)
+            elif kind == 1:
+                lo = [float(v) for v in rng.uniform(-4.0, -0.1, size=C)]
+                hi = [float(v) for v in rng.uniform(0.1, 5.0, size=C)]
+                q = Q.WeightsUniformInferableQuantizer(bits, lo, hi, True, axis)
+                ref = lambda t, q=q, axis=axis, bits=bits: torch.fake_quantize_per_channel_affine(   # noqa: E731
+                    t, q.scales.cpu(), q.zero_points.cpu(), axis, 0, 2 ** bits - 1)
+            elif kind == 2:
+                q = Q.WeightsUniformInferableQuantizer(bits, [float(rng.uniform(-3, -0.1))], [float(rng.uniform(0.1, 4))], False)
+                ref = lambda t, q=q, bits=bits: torch.fake_quantize_per_tensor_affine(   # noqa: E731  (tensor qparams)
+                    t, q.scales.cpu(), q.zero_points.cpu(), 0, 2 ** bits - 1)
+            else:
+                q = Q.ActivationSymmetricInferableQuantizer(bits, [float(rng.uniform(0.5, 5))], bool(rng.integers(0, 2)))
+                ref = lambda t, q=q: torch.fake_quantize_per_tensor_affine(   # noqa: E731
+                    t, q.scales, q.zero_points, q.min_quantized_domain, q.max_quantized_domain)
+        want = ref(x.clone())
+        xg = x.cuda()
+        got = q(xg)
+        info = (case, tuple(x.shape), x.stride(), axis, dt, kind)
+        view = torch.int64 if dt == torch.float64 else torch.int32
+        conv = (lambda t: t) if dt == torch.float64 else (lambda t: t.float())
+        assert got.dtype == want.dtype and got.shape == want.shape and got.stride() == xg.stride(), info
+        assert torch.equal(conv(got.cpu()).contiguous().view(view), conv(want).contiguous().view(view)), info
+        if kind < 3:
+            pending.append((q.batch_item(xg), got, info))
+        if len(pending) >= 9 or (pending and case % 37 == 36):
+            outs = ops.fq_batched([p[0] for p in pending])
+            for y, (_, single, inf) in zip(outs, pending):
+                assert y.dtype == single.dtype and y.stride() == single.stride() and torch.equal(y, single), ("batched", inf)
+            pending = []
+
+
+def test_per_tensor_argument_errors_match_aten(lib):
+    """ATen validates the host-known per-tensor qparams before launching; same exception type and message here,
+    through both bindings."""
+    from mct_quantizers_amd.hip import native, ops
+    x = torch.randn(16, device="cuda")
+    for args in ((0.1, 300, 0, 255), (0.1, -1, 0, 255), (0.1, 0, 5, 3)):
+        with pytest.raises(RuntimeError) as want:
+            torch.fake_quantize_per_tensor_affine(x, *args)
+        msg = str(want.value).splitlines()[0]
+        fns = [ops.fq_per_tensor, ops._hip_fq_per_tensor] + ([native.fast().fq_per_tensor] if native.fast() is not None else [])
+        for f in fns:
+            with pytest.raises(RuntimeError) as got:
+                f(x, *args)
+            assert str(got.value).splitlines()[0] == msg, (args, f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_every_16_bit_input_value_affine_and_lut(lib, dtype):
+    """ALL 65 536 bit patterns of a float16 / bfloat16 tensor (finite ones inside the parity domain, plus NaN / inf
+    handling checked separately) through the per-tensor and per-channel affine kernels against ATen's CPU operators,
+    and through the LUT quantizers (decision table AND literal scan, weights and activation flavours) against the
+    oracle."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native, ops
+    from oracle import mctq_oracle as O
+    Q = mq.pytorch_quantizers
+    name = str(dtype).replace("torch.", "")
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(dtype)
+    finite = torch.isfinite(x.float())
+    # affine: parity domain |x / s| < 2^31 -> keep every finite value whose quotient is in range for the scale used
+    for scale, zp, qmin, qmax in ((0.0371, 17, 0, 255), (2.0 ** -7, 0, -128, 127), (3.0, -2, -8, 7)):
+        ok = finite & ((x.float().abs() / scale) < 2.0 ** 31)
+        xs = x[ok]
+        want = torch.fake_quantize_per_tensor_affine(xs, scale, zp, qmin, qmax)
+        got = ops.fq_per_tensor(xs.cuda(), scale, zp, qmin, qmax)
+        assert got.dtype == dtype and torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (name, scale)
+        # per channel: the same values laid out as 3 channels with different scales
+        xc = xs[: (xs.numel() // 24) * 24].reshape(3, -1)
+        sc = torch.tensor([scale, scale * 1.7, scale * 0.31], dtype=torch.float32)
+        zc = torch.tensor([zp, qmin, qmax], dtype=torch.int32)
+        okc = (xc.float().abs() / sc[:, None]) < 2.0 ** 31
+        xc = torch.where(okc, xc, torch.zeros_like(xc))
+        want = torch.fake_quantize_per_channel_affine(xc, sc, zc, 0, qmin, qmax)
+        got = ops.fq_per_channel(xc.cuda(), sc.cuda(), zc.cuda(), 0, qmin, qmax)
+        assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (name, scale, "per channel")
+    # saturation outside the domain: +inf -> qmax, -inf / NaN -> qmin (documented divergence from the CPU's UB)
+    special = torch.tensor([float("inf"), float("-inf"), float("nan")]).to(dtype).cuda()
+    y = ops.fq_per_tensor(special, 0.5, 0, -8, 7).float().cpu()
+    assert y.tolist() == [3.5, -4.0, -4.0]
+    # LUT: every finite value; decision table and literal scan; activation (Python-float threshold, per-step rounding
+    # in the tensor's type) and weights (float32 tensor threshold, promoted chain)
+    lut = [-128.0, -96.0, -64.0, -40.0, -24.0, -12.0, -5.0, 0.0, 5.0, 12.0, 24.0, 40.0, 64.0, 96.0, 120.0, 127.0]
+    xf = x[finite]
+    xw = xf.float().numpy()
+    code = native.DT_F16 if dtype == torch.float16 else native.DT_BF16
+    lut_d = torch.tensor(lut, device="cuda")
+    for thr in (2.0, 0.5):
+        qa = Q.ActivationLutPOTInferableQuantizer(4, lut, [thr], True)
+        want = O.lut_quantize(xw, lut, thr, True, 8, 1e-8, step_dtype=name)
+        got = qa(xf.cuda())
+        assert got.dtype == torch.float32 and bits_equal(got.cpu().numpy(), want), (name, thr, "table", first_mismatch(got.cpu().numpy(), want, xw))
+        div = float(torch.tensor([thr + 1e-8], dtype=torch.float64).to(dtype).item())
+        got = ops._hip_lut_per_tensor(xf.cuda(), lut_d, div, thr, 128.0, -128.0, 127.0, None, code)
+        assert bits_equal(got.cpu().numpy(), want), (name, thr, "scan", first_mismatch(got.cpu().numpy(), want, xw))
+        qw = Q.WeightsLUTSymmetricInferableQuantizer(4, lut, [thr], False)
+        want = O.lut_quantize(xw, lut, np.float32([thr]), True, 8, 1e-8)
+        got = qw(xf.cuda())
+        assert bits_equal(got.cpu().numpy(), want), (name, thr, "weights", first_mismatch(got.cpu().numpy(), want, xw))
+
+
+def test_float64_large_random_and_tie_inputs_against_aten_cpu(lib):
+    """2^22 doubles per case -- random mantissas over 40 binades, exact ties of the double product and their one-ulp
+    neighbours -- through the float64 kernels against ATen's CPU operators (per tensor with float and with tensor
+    qparams, per channel along both axes)."""
+    from mct_quantizers_amd.hip import ops
+    rng = np.random.default_rng(97)
+    n = 1 << 22
+    for scale, zp, qmin, qmax in ((0.0371, 17, 0, 255), (2.0 ** -7, 0, -128, 127), (1.0 / 3.0, -3, -8, 7)):
+        sf = np.float32(scale)
+        inv = np.float64(np.float32(1.0) / sf)
+        x = rng.standard_normal(n) * np.exp2(rng.integers(-20, 20, size=n))
+        k = rng.integers(qmin - 4, qmax + 5, size=n // 4).astype(np.float64) - zp + 0.5
+        ties = k / inv
+        x[: n // 4] = np.where(rng.random(n // 4) < 0.34, ties, np.where(rng.random(n // 4) < 0.5, np.nextafter(ties, np.inf), np.nextafter(ties, -np.inf)))
+        x = x[np.abs(x * inv) < 2.0 ** 31]
+        xt = torch.from_numpy(x)
+        want = torch.fake_quantize_per_tensor_affine(xt, float(sf), zp, qmin, qmax)
+        got = ops.fq_per_tensor(xt.cuda(), float(sf), zp, qmin, qmax)
+        assert got.dtype == torch.float64 and torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), scale
+        st, zt = torch.tensor([sf]), torch.tensor([zp], dtype=torch.int32)
+        want = torch.fake_quantize_per_tensor_affine(xt, st, zt, qmin, qmax)
+        got = ops.fq_per_tensor_tqp(xt.cuda(), st.cuda(), zt.cuda(), qmin, qmax)
+        assert torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), (scale, "tensor qparams")
+        m = (x.size // 96) * 96
+        for shape, axis in (((3, m // 3), 0), ((m // 32, 32), 1)):
+            xc = xt[:m].reshape(shape)
+            C = shape[axis]
+            sc = torch.from_numpy((sf * rng.uniform(0.5, 2.0, size=C)).astype(np.float32))
+            zc = torch.from_numpy(rng.integers(qmin, qmax + 1, size=C).astype(np.int32))
+            bs = [1, 1]; bs[axis] = -1
+            okc = (xc.abs() * (1.0 / sc.double()).reshape(bs)) < 2.0 ** 31
+            xc = torch.where(okc, xc, torch.zeros_like(xc))
+            want = torch.fake_quantize_per_channel_affine(xc, sc, zc, axis, qmin, qmax)
+            got = ops.fq_per_channel(xc.cuda(), sc.cuda(), zc.cuda(), axis, qmin, qmax)
+            assert torch.equal(got.cpu().view(torch.int64), want.view(torch.int64)), (scale, shape, axis)
+
+
+def test_versioned_reuse_is_not_fooled_by_a_recycled_address(lib):
+    """The caching allocator hands a freed block to the next tensor of that size: same address, same shape, same
+    version counter, different values.  The cache must key on the tensor OBJECT."""
+    import mct_quantizers_amd as mq
+    q = mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0, 2.0, 3.0, 4.0], True, 0)
+    q.enable_versioned_reuse()
+    a = torch.randn(4, 1024, device="cuda")
+    ptr = a.data_ptr()
+    ya = q(a)
+    assert q(a) is ya
+    del a
+    b = torch.randn(4, 1024, device="cuda")
+    if b.data_ptr() != ptr:
+        pytest.skip("the allocator did not recycle the block")
+    yb = q(b)
+    assert yb is not ya and torch.equal(yb, torch.fake_quantize_per_channel_affine(b, q.scales, q.zero_points, 0, -128, 127))
+
+
+def test_fuzz_affine_bit_widths_signs_and_every_class_against_aten_cpu(lib):
+    """Seeded fuzz over num_bits 1..16, all six affine classes (per tensor and per channel, signed and unsigned), storage
+    types and permuted layouts: the HIP result equals ATen's CPU operator on the same tensor with the same parameters."""
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "99")))
+    for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "150"))):
+        rank = int(rng.integers(1, 5))
+        shape = [int(rng.choice([1, 2, 3, 5, 8, 16, 33, 64])) for _ in range(rank)]
+        if rng.random() < 0.25:
+            shape[int(rng.integers(0, rank))] = int(rng.choice([257, 1024, 1030, 4096]))
+        if int(np.prod(shape, dtype=np.int64)) > (1 << 22):
+            continue
+        axis = int(rng.integers(0, rank))
+        C = shape[axis]
+        bits = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16]))
+        dt = [torch.float32, torch.float32, torch.float16, torch.bfloat16, torch.float64][int(rng.integers(0, 5))]
+        scale_mag = float(rng.choice([1e-3, 0.1, 1.0, 30.0]))
+        x = (torch.from_numpy(rng.standard_normal(shape).astype(np.float32)) * scale_mag * 2).to(dt)
+        perm = list(rng.permutation(rank))
+        x = x.permute(perm).contiguous().permute(list(np.argsort(perm)))
+        kind = int(rng.integers(0, 8))
+        pc = bool(rng.integers(0, 2))
+        n = C if pc else 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == 0:
+                q = Q.WeightsSymmetricInferableQuantizer(bits, [float(v) for v in rng.uniform(0.2, 4.0, n) * scale_mag], pc, axis if pc else None)
+            elif kind == 1:
+                q = Q.WeightsPOTInferableQuantizer(bits, [float(2.0 ** e) for e in rng.integers(-6, 5, n)], pc, axis if pc else None)
+            elif kind == 2:
+                lo = [float(v) for v in rng.uniform(-4.0, 0.5, n) * scale_mag]
+                hi = [float(a + d) for a, d in zip(lo, rng.uniform(0.2, 6.0, n) * scale_mag)]
+                q = Q.WeightsUniformInferableQuantizer(bits, lo, hi, pc, axis if pc else None)
+            elif kind == 3:
+                q = Q.ActivationSymmetricInferableQuantizer(bits, [float(rng.uniform(0.2, 4.0) * scale_mag)], bool(rng.integers(0, 2)))
+            elif kind == 4:
+                q = Q.ActivationPOTInferableQuantizer(bits, [float(2.0 ** rng.integers(-6, 5))], bool(rng.integers(0, 2)))
+            else:
+                lo = float(rng.uniform(-4.0, 0.5) * scale_mag)
+                q = Q.ActivationUniformInferableQuantizer(bits, [lo], [lo + float(rng.uniform(0.2, 6.0) * scale_mag)])
+        if kind <= 2:
+            s, z = q.scales.cpu(), q.zero_points.cpu()
+            if pc:
+                ref = torch.fake_quantize_per_channel_affine(x.clone(), s, z, axis, q.min_quantized_domain, q.max_quantized_domain)
+            else:
+                ref = torch.fake_quantize_per_tensor_affine(x.clone(), s, z, q.min_quantized_domain, q.max_quantized_domain)
+        elif kind <= 4:
+            ref = torch.fake_quantize_per_tensor_affine(x.clone(), q.scales, q.zero_points, q.min_quantized_domain, q.max_quantized_domain)
+        else:
+            ref = torch.fake_quantize_per_tensor_affine(x.clone(), q.scale, q.zero_point, q.min_quantized_domain, q.max_quantized_domain)
+        got = q(x.cuda())
+        info = (case, tuple(x.shape), x.stride(), axis, dt, kind, bits, pc)
+        assert got.dtype == ref.dtype and got.shape == ref.shape and got.stride() == ref.stride(), info
+        same = torch.equal(got.cpu().double().view(torch.int64), ref.double().view(torch.int64))
+        assert same, (info, first_mismatch(got.cpu().double().numpy(), ref.double().numpy(), x.double().numpy()))
+
+
+def test_error_behaviour_follows_aten_for_axis_zero_points_and_tensor_qparams(lib):
+    """What ATen raises (type and message) for an axis out of range, a negative axis and out-of-range per-channel zero
+    points, and what it accepts: tensor qparams longer than one element (element 0 is used)."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import ops
+    Q = mq.pytorch_quantizers
+    x = torch.randn(4, 3, device="cuda")
+    s, z = torch.tensor([0.1, 0.2, 0.3], device="cuda"), torch.zeros(3, dtype=torch.int32, device="cuda")
+    for fn in (lambda a: torch.fake_quantize_per_channel_affine(x, s, z, a, -128, 127), lambda a: ops.fq_per_channel(x, s, z, a, -128, 127)):
+        with pytest.raises(IndexError, match=r"Dimension out of range \(expected to be in range of \[-2, 1\], but got 2\)"):
+            fn(2)
+        with pytest.raises(RuntimeError, match="`axis` must be between 0 and number of dimensions of input"):
+            fn(-1)
+    want = torch.fake_quantize_per_tensor_affine(x, s[:2], z[:2], -128, 127)            # ATen reads element 0
+    assert torch.equal(ops.fq_per_tensor_tqp(x, s[:2], z[:2], -128, 127), want)
+    q = Q.WeightsUniformInferableQuantizer(8, [-1.0, -2.0, -0.5], [1.0, 1.0, 2.0], True, 1)
+    q(x.clone())
+    q.zero_points = torch.tensor([0, 300, 0], dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="`zero_point` must be between `quant_min` and `quant_max`."):
+        q(x.clone())
+    with pytest.raises(RuntimeError, match="`zero_point` must be between `quant_min` and `quant_max`."):
+        torch.fake_quantize_per_channel_affine(x, q.scales, q.zero_points, 1, 0, 255)

@@ -23,12 +23,17 @@ for mode in ("per_layer", "auto_batched"):
         if mode == "per_layer":
             h, t = wall(lambda: [q(w) for m in wrappers for _, w, q in m.get_weights_vars()])
             print(f"   54 quantizer calls alone: host {h:.0f} us, incl. drain {t:.0f} us")
-            h, t = wall(lambda: [m.set_quantize_weights({n: w for n, w, _ in m.get_weights_vars()}) for m in wrappers])
-            print(f"   54 set_quantize_weights alone: host {h:.0f} us")
+            layers = [(m.layer, x) for m in wrappers]
         else:
             hnd = mq.accelerated(model)
             h, t = wall(hnd.quantize_now)
             print(f"   handle.quantize_now(): host {h:.0f} us, incl. drain {t:.0f} us")
+        # the same forward with the quantizer work removed entirely (weights as they are): what is left is torch + MIOpen
+        saved = [(m, m._weights_vars) for m in wrappers]
+        for m in wrappers: m._weights_vars = []
+        h0, t0 = wall(lambda: model(x), 60)
+        for m, v in saved: m._weights_vars = v
+        print(f"   forward WITHOUT any weight re-quantization: host {h0:.0f} us, incl. drain {t0:.0f} us", flush=True)
         pr = cProfile.Profile(); pr.enable()
         for _ in range(30): model(x)
         torch.cuda.synchronize(); pr.disable()

@@ -5,7 +5,7 @@
 #        FETCH_SIZE, WRITE_SIZE                      HBM-side traffic (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
 #        SQ stall split, TCC EA stall counters       who waits for what (cfg2 only)
 # Raw per-dispatch CSVs land in gpurun_out/pmc/<config>/; tools/pmc_summarize.py (run in the build container
-# afterwards) turns them into profiles/pmc_traffic.json + profiles/r03/*.csv, keyed by the kernel VARIANT that the
+# afterwards, MCTQ_ROUND=r04) turns them into profiles/pmc_traffic.json + profiles/<round>/*.csv, keyed by the kernel VARIANT that the
 # very same bench run reports (mctq_last_launch) and the git head.
 mkdir -p gpurun_out/pmc; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 cd /tmp
@@ -32,6 +32,11 @@ run_cfg cfg3_n64_eager --config cfg3 --batch 64 --stream-depth -1
 run_cfg cfg3_n8 --config cfg3 --batch 8
 run_cfg cfg4 --config cfg4 --steps 300
 run_cfg cfg5 --config cfg5 --steps 300
+# 16-bit storage: the headline shape and config 5 as bfloat16, config 4 (LUT: 2 B in, 4 B out)
+run_cfg cfg2_bf16 --dtype bf16
+run_cfg cfg2_f16 --dtype f16
+run_cfg cfg5_bf16 --config cfg5 --dtype bf16 --steps 300
+run_cfg cfg4_bf16 --config cfg4 --dtype bf16 --steps 300
 # stall counters of the headline kernel and of the batched launch: one pass per group (8 SQ slots, 4 TCC slots)
 stall_passes() {   # name, bench args...
   local name=$1; shift
@@ -53,4 +58,4 @@ stall_passes() {   # name, bench args...
 stall_passes cfg2
 stall_passes cfg2_batched16 --batched 16 --steps 30 --warmup 5
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
-for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
+for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5 cfg2_bf16 cfg2_f16 cfg5_bf16 cfg4_bf16; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done

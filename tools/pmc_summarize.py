@@ -7,7 +7,7 @@ taken at.  bench.py emits roofline.traffic only when its own variant string equa
 import csv, json, os, shutil, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "pmc")
-DST = os.path.join(REPO, "profiles", os.environ.get("MCTQ_ROUND", "r03"))
+DST = os.path.join(REPO, "profiles", os.environ.get("MCTQ_ROUND", "r04"))
 os.makedirs(DST, exist_ok=True)
 head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
 
