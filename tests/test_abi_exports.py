@@ -187,3 +187,31 @@ def test_compiled_binding_builds_loads_and_declines_cpu_tensors():
         mod.BatchPlan([(x, x, s, None, 0, -8, 7)])            # a plan needs HIP tensors
     with pytest.raises(TypeError):
         mod.AffinePlan(0.1, 0)
+
+
+def test_a_stale_binary_is_rebuilt_whatever_its_modification_time(tmp_path, monkeypatch):
+    """The build decision is a content hash (hip/build.py): a source whose text changed while its mtime did not -- or a
+    binary that is newer than sources it was not built from -- must count as stale, and the loader must refuse it."""
+    import shutil
+    from mct_quantizers_amd.hip import build, native
+    build.build()
+    assert not build.needs_build()
+    assert build.embedded_id(build.OUT) == build.tree_build_id() == native.load().mctq_build_id().decode()
+    src = build.SOURCES[0]
+    copy = str(tmp_path / os.path.basename(src))
+    shutil.copy2(src, copy)
+    st = os.stat(copy)
+    with open(copy, "a") as f:
+        f.write("\n// a kernel constant edited\n")
+    os.utime(copy, (st.st_atime, st.st_mtime))                 # the modification time is what it was
+    assert os.stat(copy).st_mtime == st.st_mtime
+    monkeypatch.setattr(build, "SOURCES", [copy] + build.SOURCES[1:])
+    assert build.tree_build_id() != build.embedded_id(build.OUT)
+    assert build.needs_build() and build.binding_needs_build()  # the binding's id covers the library's
+    with pytest.raises(native.NativeLibraryError, match="built from other sources"):
+        native._check_build_id(build.OUT, build.embedded_id(build.OUT), "tree_build_id")
+    monkeypatch.undo()
+    assert not build.needs_build()
+    # a flag change is a source change too
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DX=1"])
+    assert build.needs_build()
