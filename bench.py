@@ -87,10 +87,13 @@ def parse():
     ap.add_argument("--nt", type=int, default=None)
     ap.add_argument("--unroll", type=int, default=None)
     ap.add_argument("--heavy-unroll", type=int, default=None)
+    ap.add_argument("--rowsteps", type=int, default=None, help="tuning key rowsteps (include/mctq_hip.h): 1 = rowsteps_kernel for short whole-step rows")
     ap.add_argument("--heavy-persistent", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batched-extra", action="store_true", help="skip the batched_16x4096 object of the default run")
+    ap.add_argument("--no-eager-extra", action="store_true",
+                    help="config 3: skip the eager per-call figure (profiler passes: only the judged kernel's dispatches)")
     ap.add_argument("--gather", action="store_true", help="run the sharded config-5 + all-gather leg even at N = 1 (needs torchrun)")
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
     ap.add_argument("--extras", action="store_true",
@@ -225,7 +228,7 @@ def main():
     from mct_quantizers_amd.hip import native
     if not dry:
         native.load()
-        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll),
+        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll), ("rowsteps", args.rowsteps),
                          ("heavy_persistent", args.heavy_persistent)):
             if val is not None:
                 native.set_tuning(key, val)
@@ -446,7 +449,7 @@ def main():
         result["per_rank_kernel_us"] = [float(v[0]) for v in got]
 
     # ---- config 3: the EAGER per-call figure, always beside a fused-group line (outside the timed region) -------------
-    if args.config == "cfg3" and not dry and not args.batched:
+    if args.config == "cfg3" and not dry and not args.batched and not args.no_eager_extra:
         try:
             holder_e = mq.PytorchActivationQuantizationHolder(quantizer).to(device)
             ring_e = max(2, -(-(512 << 20) // alg_bytes) + 1)

@@ -497,9 +497,9 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  tiles <BM/..><BN/..>[K step][LDS buffers] (66 ... 12124), 8- / 16-wave tiles (8xxxx / 16xxxxx), wide tiles (25xx ... 4442)
  *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
- *   key "rowsteps" : 1 = per-channel rows of two or three whole 256-lane-vector steps take four steps per block across row
- *                  boundaries (rowsteps_kernel; measured no better, kept for experiments); 0 (default) = one- / two-step tiles
- *                  inside a row (rows_kernel)
+ *   key "rowsteps" : per-channel rows of two or three whole 256-lane-vector steps: 0 = one- / two-step tiles inside a row
+ *                  (rows_kernel), 1 = four steps per block across row boundaries (rowsteps_kernel), 2 (default) = rowsteps_kernel
+ *                  when its grid is one round of resident blocks, where it measured 5-10 % faster (64 MiB launches)
  *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */

@@ -1249,7 +1249,7 @@ inline void note(const char* shape, int unroll, int nt) {
   g_note.in_bytes = (int)sizeof(TI); g_note.out_bytes = (int)sizeof(TO);
   ++g_note.count;
 }
-extern int g_rowsteps;       // 1: short whole-step rows go to rowsteps_kernel; 0 (default): rows_kernel
+extern int g_rowsteps;       // short whole-step rows: 0 rows_kernel, 1 rowsteps_kernel, 2 (default) rowsteps_kernel when its grid is one round
 extern int g_heavy_unroll;   // 0 = automatic
 extern int g_heavy_persistent;
 int fail_arg(const char* msg);
@@ -1458,7 +1458,14 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       if constexpr (std::is_same<Op, AffineOp>::value) {
         // rows of 1 .. 3 whole steps: four steps per block across row boundaries (rowsteps_kernel)
         const int64_t total_steps = rows * (innerv / kThreads);
-        if (g_rowsteps && best_u < 4 && g_unroll >= 4 && innerv % kThreads == 0 && total_steps <= 0xffffffffLL) {
+        // Measured (profiles/r04/rowsteps_probe_sustained.log, 30 shapes x 3 storage types): four steps per block beat
+        // rows_kernel's one- / two-step tiles by 5-10 % exactly when the four-step grid is ONE round of resident blocks
+        // (8 per CU: 64 MiB launches such as 4096 x 4096 bfloat16 or 4096 x 2048 float32) and lose 3-8 % otherwise
+        // (half a round, or several rounds).  Mode 2 (default) takes it in that window only.
+        const int64_t rs_blocks = (total_steps + 3) / 4, round = 8LL * cu_count();
+        const bool one_round = rs_blocks <= round && rs_blocks * 4 >= round * 3;
+        if ((g_rowsteps == 1 || (g_rowsteps == 2 && one_round)) && best_u < 4 && g_unroll >= 4 && innerv % kThreads == 0 &&
+            total_steps <= 0xffffffffLL) {
           MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), false, {
             constexpr int U = 4;
             hipLaunchKernelGGL((rowsteps_kernel<Op, TI, TO, U, NT>), dim3((unsigned)((total_steps + U - 1) / U)), dim3(kThreads),

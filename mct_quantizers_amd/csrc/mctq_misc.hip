@@ -10,7 +10,7 @@ int g_nt = 1;
 int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggregate L2 stay cached for their consumer
 int g_unroll = 4;
 int g_heavy_unroll = 0;
-int g_rowsteps = 0;           // measured: no better than rows_kernel on large tensors (profiles/r04/rowsteps_probe.log)
+int g_rowsteps = 2;           // 2: rowsteps_kernel only where it measured faster (see launch_channels)
 int g_ql_variant = 0;
 int g_ql_band = 0;
 int g_ql_stagger = 0;         // tiled consumer kernel: half of the waves copy after multiplying (experiment: no gain)
@@ -117,7 +117,7 @@ int mctq_set_tuning(const char* key, int32_t value) {
     return 0;
   }
   if (!strcmp(key, "rowsteps")) {
-    if (value != 0 && value != 1) return fail_arg("rowsteps must be 0 or 1");
+    if (value != 0 && value != 1 && value != 2) return fail_arg("rowsteps must be 0, 1 or 2");
     g_rowsteps = value;
     return 0;
   }

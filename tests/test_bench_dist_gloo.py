@@ -93,7 +93,7 @@ def test_plain_python_bench_gpus_2_launches_itself_and_emits_the_multi_rank_line
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["value"] > 0
-    assert out["config"]["ranks_seen"] == 2 and out["config"]["control_plane"] == "gloo" and "dry_run" in out
+    assert out["ranks_seen"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["control_plane"] == "gloo" and "dry_run" in out
     assert len(out["per_rank_kernel_us"]) == 2
     leg = out["sharded_cfg5"]
     assert leg["gathered_rows_match_local"] is True and leg["ranks"] == 2

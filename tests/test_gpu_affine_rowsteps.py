@@ -1,5 +1,5 @@
-"""rowsteps_kernel (csrc/mctq_kernels.hpp; tuning key "rowsteps", OFF by default: measured no better than rows_kernel,
-profiles/r04/rowsteps_probe.log): per-channel rows of two or three whole 256-lane-vector steps -- float32 rows of 2048 / 3072
+"""rowsteps_kernel (csrc/mctq_kernels.hpp; tuning key "rowsteps": by default taken only where it measured faster -- a grid of
+one round of blocks, profiles/r04/rowsteps_probe_sustained.log): per-channel rows of two or three whole 256-lane-vector steps -- float32 rows of 2048 / 3072
 elements, 16-bit rows of 2048 / 4096 / 6144 -- four steps per block across row boundaries.  Against the oracle, for every
 storage type, with outer > 1 (channel = row % channels), ragged last blocks, zero points, and equal to the rows_kernel."""
 import warnings
@@ -59,7 +59,7 @@ def test_rowsteps_equals_oracle_and_rows_kernel(dt, shape, axis, kind):
         assert "rowsteps_kernel" not in native.last_launch()
         assert torch.equal(y0, y)
     finally:
-        native.set_tuning("rowsteps", 0)
+        native.set_tuning("rowsteps", 2)
 
 
 def test_rows_of_four_steps_or_ragged_rows_keep_their_kernels():
@@ -70,6 +70,11 @@ def test_rows_of_four_steps_or_ragged_rows_keep_their_kernels():
             q(torch.randn(64, cols, device="cuda"))
             assert native.last_launch().startswith(name), (cols, native.last_launch())
     finally:
-        native.set_tuning("rowsteps", 0)
+        native.set_tuning("rowsteps", 2)
     q(torch.randn(64, 2048, device="cuda"))
-    assert native.last_launch().startswith("rows_kernel")            # the default
+    assert native.last_launch().startswith("rows_kernel")            # the default: 32 four-step blocks are no full round
+    q4 = Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 4096, True, 0)
+    q4(torch.randn(4096, 4096, device="cuda").bfloat16())            # 8192 steps = 2048 blocks = one round of 8 per CU
+    assert native.last_launch().startswith("rowsteps_kernel"), native.last_launch()
+    q4(torch.randn(4096, 4096, device="cuda"))
+    assert native.last_launch().startswith("rows_kernel")

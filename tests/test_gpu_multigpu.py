@@ -69,6 +69,12 @@ def test_bench_multi_process_leg_runs_over_rccl_on_one_gpu(lib):
     for key in ("compute_ms", "compute_elems_per_s", "allgather_ms", "allgather_recv_bytes_per_rank", "compute_plus_allgather_elems_per_s", "gathered_rows_match_local"):
         assert key in leg, leg
     assert leg["gathered_rows_match_local"] is True and leg["rows_per_rank"] == 8192
+    # the collective itself ran over RCCL on HIP memory (a group of one rank: the result is RCCL's copy of the shard, a
+    # different buffer) and the re-assembled tensor is the reference's config-5 output
+    assert leg["allgather_backend"] == "nccl" and leg["allgather_device"].startswith("cuda"), leg
+    assert leg["allgather_ms"] > 0 and leg["allgather_local_copy_gbs"] > 100, leg
+    assert leg["gathered_equals_reference_digest"] is True
+    assert d["ranks_seen"] == 1
 
 
 @pytest.mark.parametrize("world", [2, 8, 3])

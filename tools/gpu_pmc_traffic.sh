@@ -10,18 +10,19 @@
 mkdir -p gpurun_out/pmc; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -o -E "\b(SQ_[A-Z_0-9]+|TCC_[A-Z_0-9]+|TCP_[A-Z_0-9]+|GRBM_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE)\b" | sort -u > $R/gpurun_out/pmc/available_counters.txt
-run_cfg() {   # name, bench args...
+run_cfg() {   # name, bench args...   (MCTQ_PMC_ONLY="cfg2_bf16 cfg2_f16": only those configurations)
   local name=$1; shift
+  if [ -n "$MCTQ_PMC_ONLY" ] && ! echo " $MCTQ_PMC_ONLY " | grep -q " $name "; then return; fi
   local out=$R/gpurun_out/pmc/$name; mkdir -p $out
   rm -rf /tmp/prof_$name
   # the stats pass runs the judged command as it is (at N = 1 the default run also carries the batched_16x4096 object)
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --no-cpu --evidence-launches 0 "$@" > $out/bench_stats.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --no-cpu --no-eager-extra --evidence-launches 0 "$@" > $out/bench_stats.log 2>&1
   find /tmp/prof_$name -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
   for pass in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${name}_$pass
-    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --no-batched-extra --no-eager-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
     f=$(find /tmp/pmc_${name}_$pass -name "*counter_collection.csv" | head -1)
-    if [ -n "$f" ]; then head -1 $f > $out/$pass.csv; grep -E "mctq::" $f | tail -120 >> $out/$pass.csv; fi
+    if [ -n "$f" ]; then head -1 $f > $out/$pass.csv; grep -E "mctq" $f | tail -120 >> $out/$pass.csv; fi
   done
 }
 run_cfg cfg2
@@ -40,6 +41,7 @@ run_cfg cfg4_bf16 --config cfg4 --dtype bf16 --steps 300
 # stall counters of the headline kernel and of the batched launch: one pass per group (8 SQ slots, 4 TCC slots)
 stall_passes() {   # name, bench args...
   local name=$1; shift
+  if [ -n "$MCTQ_PMC_ONLY" ] && ! echo " $MCTQ_PMC_ONLY " | grep -q " $name "; then return; fi
   local out=$R/gpurun_out/pmc/$name
   local i=0
   for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -52,7 +54,7 @@ stall_passes() {   # name, bench args...
     i=$((i+1)); rm -rf /tmp/pmc_stall_${name}_$i
     timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_${name}_$i -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 "$@" > $out/bench_stall_$i.log 2>&1
     f=$(find /tmp/pmc_stall_${name}_$i -name "*counter_collection.csv" | head -1)
-    if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq::" $f | tail -400 >> $out/stall_$i.csv; else echo "$name group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
+    if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq" $f | tail -400 >> $out/stall_$i.csv; else echo "$name group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
   done
 }
 stall_passes cfg2

@@ -31,6 +31,9 @@ for cfg in sorted(os.listdir(SRC)):
     d = os.path.join(SRC, cfg)
     if not os.path.isdir(d) or not os.path.exists(os.path.join(d, "FETCH_SIZE.csv")):
         continue
+    if sum(1 for _ in open(os.path.join(d, "FETCH_SIZE.csv"))) < 2:
+        print(cfg, "no counter rows (skipped)")
+        continue
     line = bench_line(os.path.join(d, "bench_FETCH_SIZE.log")) or {}
     line_w = bench_line(os.path.join(d, "bench_WRITE_SIZE.log")) or {}
     variant = line.get("roofline", {}).get("kernel")
