@@ -13,8 +13,11 @@ REF = "/root/reference/tests/pytorch_tests"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists only in the build container")
-def test_reference_pytorch_suite_passes_against_this_package(tmp_path):
+@pytest.mark.parametrize("auto_batch", ["1", "0"])
+def test_reference_pytorch_suite_passes_against_this_package(tmp_path, auto_batch):
+    """With the loader's one-launch-per-forward hook on (the default) and off (MCTQ_AUTO_BATCH=0)."""
     env = dict(os.environ)
+    env["MCTQ_AUTO_BATCH"] = auto_batch
     env["PYTHONPATH"] = ""                                   # the real mct_quantizers must NOT be importable
     env["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = "1"           # its save/load tests predate torch's weights_only default
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "run_reference_tests.py")],

@@ -1,7 +1,7 @@
 #!/bin/bash
 # refresh the per-config bench lines committed under profiles/<round>/
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_gpu_r02.py -m gpu -q -k "capture or fuzz" > gpurun_out/pytest_sel.log 2>&1; echo "rc=$?" >> gpurun_out/pytest_sel.log
+timeout 300 python -m pytest tests -m gpu -q -k "capture or fuzz" > gpurun_out/pytest_sel.log 2>&1; echo "rc=$?" >> gpurun_out/pytest_sel.log
 : > gpurun_out/bench_all_configs.jsonl
 for c in cfg1 cfg2 cfg4 cfg5; do timeout 300 python bench.py --no-cpu --config $c --steps 200 2>/dev/null | grep "^{" >> gpurun_out/bench_all_configs.jsonl; done
 for n in 1 8 64 256; do timeout 300 python bench.py --no-cpu --config cfg3 --batch $n --steps 500 2>/dev/null | grep "^{" >> gpurun_out/bench_all_configs.jsonl; done
