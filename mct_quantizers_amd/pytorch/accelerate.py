@@ -15,8 +15,8 @@ quantized weight a wrapper installs on its layer is the same tensor object on ev
 reference installs a fresh tensor; values are identical.  ``decelerate(model)`` removes the hook.
 
 ``accelerate(model, example_inputs=(x,))`` additionally captures the whole forward -- weight re-quantization, layers,
-activation holders -- into one hipGraph (``pytorch/graphs.py``) and returns the replaying callable; that freezes shapes and
-returns static output buffers, so it is never done implicitly.
+activation holders -- into one hipGraph (``pytorch/graphs.py``) and returns the replaying callable (inputs of another shape
+run the eager forward); that returns static output buffers, so it is never done implicitly.
 """
 from __future__ import annotations
 
@@ -54,7 +54,7 @@ def accelerate(model: nn.Module, example_inputs: Optional[Sequence[torch.Tensor]
     if example_inputs is not None:
         from mct_quantizers_amd.pytorch.graphs import capture_forward
         decelerate(model)                                  # the captured forward brings its own (non-auto) batcher
-        return capture_forward(model, *example_inputs)
+        return capture_forward(model, *example_inputs, strict=False)     # other shapes: the eager forward, not an error
     if model.__dict__.get(_KEY) is None and _has_wrapped_weights(model):
         from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
         model.__dict__[_KEY] = batch_weight_quantization(model, reuse_buffers=True, auto=True)

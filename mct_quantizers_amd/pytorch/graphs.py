@@ -27,7 +27,9 @@ class CapturedForward:
     """``captured(x, ...)`` copies the inputs into the graph's static buffers, replays, and returns the static outputs
     (valid until the next call; ``.clone()`` what must outlive it)."""
 
-    def __init__(self, model: nn.Module, example_inputs: Tuple[torch.Tensor, ...], batch_weights: bool, warmup: int):
+    def __init__(self, model: nn.Module, example_inputs: Tuple[torch.Tensor, ...], batch_weights: bool, warmup: int,
+                 strict: bool = True):
+        self.strict = strict
         if not example_inputs or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
             raise TypeError("capture_forward takes GPU tensors as example inputs")
         self.model = model
@@ -47,12 +49,23 @@ class CapturedForward:
             self._static_out = model(*self._static_in)
         model.train(was_training)
 
+    def fits(self, inputs) -> bool:
+        return (self.graph is not None and len(inputs) == len(self._static_in)
+                and all(isinstance(src, torch.Tensor) and src.shape == dst.shape and src.dtype == dst.dtype
+                        and src.device == dst.device for dst, src in zip(self._static_in, inputs)))
+
     def __call__(self, *inputs: torch.Tensor):
-        if len(inputs) != len(self._static_in):
-            raise TypeError(f"captured with {len(self._static_in)} inputs, called with {len(inputs)}")
+        if not self.fits(inputs):
+            if self.strict:
+                if len(inputs) != len(self._static_in):
+                    raise TypeError(f"captured with {len(self._static_in)} inputs, called with {len(inputs)}")
+                for dst, src in zip(self._static_in, inputs):
+                    if src.shape != dst.shape or src.dtype != dst.dtype:
+                        raise ValueError(f"captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
+            # another shape / dtype / device (or a released graph): the eager forward, batched weights included
+            with torch.no_grad():
+                return self.model(*inputs)
         for dst, src in zip(self._static_in, inputs):
-            if src.shape != dst.shape or src.dtype != dst.dtype:
-                raise ValueError(f"captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
             dst.copy_(src)
         self.graph.replay()
         return self._static_out
@@ -66,10 +79,11 @@ class CapturedForward:
 
 
 def capture_forward(model: nn.Module, *example_inputs: torch.Tensor, batch_weights: bool = True,
-                    warmup: int = 3) -> CapturedForward:
+                    warmup: int = 3, strict: bool = True) -> CapturedForward:
     """Capture ``model(*example_inputs)`` (inference, no grad) into one hipGraph and return the replaying callable.
-    ``batch_weights``: re-quantize all wrapped weights in one launch inside the graph (``pytorch/batching.py``)."""
-    return CapturedForward(model, example_inputs, batch_weights, warmup)
+    ``batch_weights``: re-quantize all wrapped weights in one launch inside the graph (``pytorch/batching.py``).
+    ``strict=False``: inputs of another shape / dtype / device run the eager forward instead of raising."""
+    return CapturedForward(model, example_inputs, batch_weights, warmup, strict)
 
 
 class CapturedStream:

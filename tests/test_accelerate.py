@@ -261,6 +261,39 @@ def test_accelerate_with_example_inputs_captures_the_forward():
     assert torch.allclose(got, want, rtol=0, atol=0.25)                      # (convolution kernels: see the test above)
     x2 = torch.randn(1, 3, 64, 64, device="cuda")
     got2 = captured(x2).clone()
+    x3 = torch.randn(2, 3, 32, 32, device="cuda")                            # another shape: the eager forward, no error
+    with torch.no_grad():
+        assert torch.allclose(captured(x3), model(x3), rtol=0, atol=0.25) and captured(x3).shape == (2, 1000)
     captured.release()
     with torch.no_grad():
         assert torch.allclose(model(x2), got2, rtol=0, atol=0.25)
+
+
+@pytest.mark.gpu
+def test_accelerated_model_follows_casts_and_compiles(monkeypatch):
+    """model.half() after the plan was built: the plan notices and is rebuilt (16-bit weights, same launch count);
+    torch.compile of an accelerated model: the hook stands aside, the graph holds the library ops, same result."""
+    model = mq.accelerate(_small_model("cuda"))
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+    _forward_launches(model, x)
+    n32, y32 = _forward_launches(model, x)
+    model = model.half()
+    _forward_launches(model, x.half())
+    n16, y16 = _forward_launches(model, x.half())
+    assert n16 == n32 == 3 and y16.dtype == torch.float16
+    ref = _small_model("cuda").half()
+    with torch.no_grad():
+        want = ref(x.half())
+    assert torch.equal(_quantized(model, "conv.weight"), _quantized(ref, "conv.weight"))
+    assert torch.allclose(y16.float(), want.float(), atol=2e-2)
+    model = mq.accelerate(_small_model("cuda"))
+    with torch.no_grad():
+        eager = model(x)
+        compiled = torch.compile(model, fullgraph=False)
+        got = compiled(x)
+    assert torch.allclose(got, eager, atol=1e-5)
+
+
+def _quantized(model, key):
+    name, wname = key.rsplit(".", 1)
+    return getattr(dict(model.named_modules())[name].layer, wname).detach()

@@ -278,7 +278,8 @@ def test_fuzz_lut_quantizers_shapes_axes_layouts_dtypes_and_codebook_widths(lib)
             w = O.lut_quantize(x.numpy(), lut, thr_o, signed, B, 1e-8, per_channel=(kind == 0),
                                channel_axis=(axis if kind == 0 else None))
             assert bits_equal(got.cpu().numpy(), w), info
-    assert {"LutTableOp", "LutStepsOp"} <= seen, seen
+    table = "LutCompactOp" if os.environ.get("MCTQ_COMPACT_LUT", "0") not in ("", "0") else "LutTableOp"    # soak runs with the compact form
+    assert {table, "LutStepsOp"} <= seen, seen
 
 
 def test_half_activation_lut_clip_bounds_follow_the_tensor_type(lib):
@@ -316,7 +317,7 @@ def test_half_activation_lut_clip_bounds_follow_the_tensor_type(lib):
         kw = c["kwargs"]
         assert bits_equal(y32.cpu().numpy(), O.lut_quantize(x32, kw["lut_values"], kw["threshold"][0], kw["signed"],
                                                             kw["lut_values_bitwidth"], 1e-8))
-    assert kinds <= {"LutTableOp", "LutStepsOp", "LutCellsOp"} and kinds, kinds
+    assert kinds <= {"LutTableOp", "LutCompactOp", "LutStepsOp", "LutCellsOp"} and kinds, kinds
 
 
 def test_lut_quantizers_follow_attribute_assignment(lib):
