@@ -107,6 +107,7 @@ def main(args) -> int:
     q_us = q_ms * 1e3
     equal = {k: bool(torch.equal(outs["per_layer"], v)) for k, v in outs.items()}
     max_diff = {k: float((outs["per_layer"] - v).abs().max()) for k, v in outs.items()}
+    rel_l2 = {k: float((outs["per_layer"] - v).norm() / outs["per_layer"].norm()) for k, v in outs.items()}
     weights_equal = len(qws["per_layer"]) == 54 and all(bool(torch.equal(a, b)) for a, b in zip(qws["per_layer"], qws["auto_batched"]))
 
     result = {
@@ -127,6 +128,7 @@ def main(args) -> int:
         "speedup_captured_over_per_layer": modes["per_layer"]["ms_per_forward"] / modes["captured"]["ms_per_forward"],
         "quantized_weights_bit_equal_per_layer_vs_auto_batched": weights_equal,
         "logits_bit_equal_to_per_layer": equal, "logits_max_abs_diff_to_per_layer": max_diff,
+        "logits_relative_l2_diff_to_per_layer": rel_l2,
         "logits_note": "the quantizers' outputs are bit-equal between the modes; the convolutions around them (MIOpen) can answer "
                        "with another last bit when a bit-equal weight lives in another buffer (profiles/r04/conv_determinism_probe.log), "
                        "which later quantizers amplify to a flipped step -- logits are compared for information only",
@@ -171,7 +173,7 @@ def main(args) -> int:
             result["parity_error"] = "quantized weights differ from the CPU oracle"
     if not weights_equal:
         result["parity_error"] = "quantized weights differ between the per-layer and the batched path"
-    elif max(max_diff.values()) > 0.5:
-        result["parity_error"] = f"logits differ between modes by {max(max_diff.values()):.3g}"
+    elif max(rel_l2.values()) > 0.05:
+        result["parity_error"] = f"logits differ between modes by {max(rel_l2.values()):.3g} (relative L2)"
     print(json.dumps(result), flush=True)
     return 3 if result.get("parity_error") else 0

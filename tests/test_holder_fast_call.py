@@ -23,6 +23,13 @@ def _oracle(kw, x_np, cls="ActivationUniformInferableQuantizer", in_dtype="float
         return oracle_call(cls, kw, x_np, in_dtype=in_dtype)
 
 
+@pytest.fixture
+def compiled_binding():
+    from mct_quantizers_amd.hip import native
+    if native.fast() is None:
+        pytest.skip("compiled binding not in use (MCTQ_BINDING=ctypes / MCTQ_ROCTX=1): holders take the Python path")
+
+
 def test_cpu_tensors_never_build_the_fast_call():
     h = mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1]))
     x = torch.randn(2, 3, 8, 8)
@@ -34,7 +41,7 @@ def test_cpu_tensors_never_build_the_fast_call():
 
 
 @gpu
-def test_fast_call_is_built_on_first_use_and_matches_the_oracle():
+def test_fast_call_is_built_on_first_use_and_matches_the_oracle(compiled_binding):
     kw = dict(num_bits=8, min_range=[-2.5], max_range=[3.1])
     h = mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(**kw))
     x_np = (np.random.default_rng(0).standard_normal((2, 3, 32, 32)) * 2).astype(np.float32)
@@ -53,7 +60,7 @@ def test_fast_call_is_built_on_first_use_and_matches_the_oracle():
 
 
 @gpu
-def test_fast_call_follows_parameter_assignment_and_quantizer_swap():
+def test_fast_call_follows_parameter_assignment_and_quantizer_swap(compiled_binding):
     kw = dict(num_bits=8, min_range=[-2.5], max_range=[3.1])
     q = Q.ActivationUniformInferableQuantizer(**kw)
     h = mq.PytorchActivationQuantizationHolder(q)
@@ -71,7 +78,7 @@ def test_fast_call_follows_parameter_assignment_and_quantizer_swap():
 
 
 @gpu
-def test_hooks_bypass_and_traces_take_the_module_path():
+def test_hooks_bypass_and_traces_take_the_module_path(compiled_binding):
     q = Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1])
     h = mq.PytorchFLNActivationQuantizationHolder(q, quantization_bypass=False)
     x = torch.randn(2, 3, 16, 16, device="cuda")
