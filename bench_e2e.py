@@ -8,6 +8,7 @@ pytorch/activation_quantization_holder.py:43-53).  It is saved with ``torch.save
 
   per_layer      MCTQ_AUTO_BATCH=0: one quantizer launch per wrapped weight per forward, as the reference does
   auto_batched   the default: the loader installed ``accelerate`` -- ONE table launch for all 54 weights per forward
+  auto_captured  MCTQ_AUTO_CAPTURE=1 at load time: ``model(x)`` itself replays its forward from a hipGraph (weights by one eager launch)
   captured       ``mq.accelerate(model, example_inputs=(x,))``: the whole forward replayed from one hipGraph
 
 All three re-quantize the weights from their current float values on every forward.  Outputs are compared bit for bit
@@ -94,6 +95,20 @@ def main(args) -> int:
                 q_ms = _timeit(handle.quantize_now, max(steps, 100), 10)[1]
                 kernel = native.last_launch()
                 w_model = model
+    # MCTQ_AUTO_CAPTURE=1: the loaded model replays its own forward (graph per input signature, outputs cloned)
+    os.environ["MCTQ_AUTO_CAPTURE"] = "1"
+    try:
+        auto_cap = load("1")
+    finally:
+        del os.environ["MCTQ_AUTO_CAPTURE"]
+    with torch.no_grad():
+        auto_cap(x); auto_cap(x)
+        n_ac, y_ac = launches(auto_cap)
+        wall_ms, dev_ms = _timeit(lambda: auto_cap(x), steps, warmup)
+    modes["auto_captured"] = {"ms_per_forward": wall_ms, "ms_per_forward_events": dev_ms, "quantizer_launches_per_forward": n_ac,
+                              "what": "MCTQ_AUTO_CAPTURE=1: model(x) runs its hooks eagerly (one weight launch) and replays the forward "
+                                      "behind them from a hipGraph; outputs are clones"}
+    outs["auto_captured"] = y_ac.clone()
     captured = mq.accelerate(load("0"), example_inputs=(x,))
     y_cap = captured(x).clone()
     wall_ms, dev_ms = _timeit(lambda: captured(x), steps, warmup)

@@ -14,7 +14,11 @@ What changes for the caller (the documented identity caveat of ``batch_weight_qu
 quantized weight a wrapper installs on its layer is the same tensor object on every forward, rewritten in place, where the
 reference installs a fresh tensor; values are identical.  ``decelerate(model)`` removes the hook.
 
-``accelerate(model, example_inputs=(x,))`` additionally captures the whole forward -- weight re-quantization, layers,
+``accelerate(model, capture=True)`` (``MCTQ_AUTO_CAPTURE=1`` for loaded models; default off) additionally lets the model
+replay its forward from one hipGraph per input signature, captured at the signature's second occurrence (``AutoCapture``):
+outputs are clones, everything that cannot be replayed runs eagerly.
+
+``accelerate(model, example_inputs=(x,))`` captures the whole forward right away -- weight re-quantization, layers,
 activation holders -- into one hipGraph (``pytorch/graphs.py``) and returns the replaying callable (inputs of another shape
 run the eager forward); that returns static output buffers, so it is never done implicitly.
 """
@@ -46,23 +50,32 @@ def accelerated(model: nn.Module):
     return model.__dict__.get(_KEY)
 
 
-def accelerate(model: nn.Module, example_inputs: Optional[Sequence[torch.Tensor]] = None):
+def accelerate(model: nn.Module, example_inputs: Optional[Sequence[torch.Tensor]] = None, capture: bool = False):
     """Install the one-launch-per-forward weight re-quantization on ``model`` (idempotent) and return the model; with
-    ``example_inputs`` capture the whole forward into one hipGraph as well and return the replaying callable."""
+    ``example_inputs`` capture the whole forward into one hipGraph as well and return the replaying callable; with
+    ``capture=True`` let the model itself replay its forward from a hipGraph per input signature (``AutoCapture``)."""
     if not isinstance(model, nn.Module):
         raise TypeError("accelerate() takes a torch.nn.Module")
+    if capture and example_inputs is None:
+        return auto_capture(model)
     if example_inputs is not None:
         from mct_quantizers_amd.pytorch.graphs import capture_forward
         decelerate(model)                                  # the captured forward brings its own (non-auto) batcher
         return capture_forward(model, *example_inputs, strict=False)     # other shapes: the eager forward, not an error
     if model.__dict__.get(_KEY) is None and _has_wrapped_weights(model):
-        from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
-        model.__dict__[_KEY] = batch_weight_quantization(model, reuse_buffers=True, auto=True)
+        from mct_quantizers_amd.pytorch.batching import BatchedWeightQuantization, batch_weight_quantization
+        # a batcher the caller installed by hand (batch_weight_quantization / capture_forward) already does the work
+        if not any(isinstance(getattr(h, "__self__", None), BatchedWeightQuantization)
+                   for h in model._forward_pre_hooks.values()):
+            model.__dict__[_KEY] = batch_weight_quantization(model, reuse_buffers=True, auto=True)
     return model
 
 
 def decelerate(model: nn.Module) -> nn.Module:
     """Remove what ``accelerate`` installed: every wrapper calls its own quantizer again."""
+    cap = model.__dict__.pop("_mctq_auto_capture", None)
+    if cap is not None:
+        cap.release()
     handle = model.__dict__.pop(_KEY, None)
     if handle is not None:
         handle.remove()
@@ -72,5 +85,129 @@ def decelerate(model: nn.Module) -> nn.Module:
 def accelerate_loaded(obj):
     """What the loaders call on the object ``torch.load`` gave them."""
     if auto_batch_enabled() and isinstance(obj, nn.Module):
-        accelerate(obj)
+        accelerate(obj, capture=auto_capture_enabled())
     return obj
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the forward replayed from a hipGraph without the caller doing anything: accelerate(model, capture=True) / MCTQ_AUTO_CAPTURE=1
+# ---------------------------------------------------------------------------------------------------------------------
+
+def auto_capture_enabled() -> bool:
+    """``MCTQ_AUTO_CAPTURE`` (default OFF): loaded models also get ``accelerate(model, capture=True)``."""
+    return os.environ.get("MCTQ_AUTO_CAPTURE", "0").strip().lower() not in ("0", "off", "false", "no", "")
+
+
+class AutoCapture:
+    """``model.forward`` replaced (on the instance) by a dispatcher that replays the ORIGINAL forward from one hipGraph per
+    input signature.  At batch 1 an eager forward of a wrapped ResNet-50 spends 2.5 ms in torch's dispatch for 1 ms of GPU
+    work (profiles/r04/bench_e2e_resnet50.json): the replay removes that.
+
+    What is replayed is the forward BEHIND the module's hooks: ``model(x)`` still runs its forward pre-hooks eagerly -- among
+    them the batched re-quantization of all wrapped weights into their persistent buffers (``accelerate``), so weight updates
+    are followed exactly as in eager mode -- and then, instead of the Python forward, the graph that reads those buffers.
+
+    A signature (shapes, dtypes, devices of the positional tensor arguments) is captured at its SECOND occurrence; anything
+    else runs eagerly: keyword arguments, non-tensor or CPU arguments, training mode, grad-requiring inputs with grad
+    enabled, an active trace / compile, a model whose weights are not served by the pre-packed plan.  Outputs are CLONES of
+    the graph's static buffers (the caller may keep them).  A rebuilt plan (changed quantizer parameters, ``model.half()``)
+    or ``release()`` drops the graphs."""
+
+    def __init__(self, model: nn.Module, max_graphs: int = 8):
+        self.model = model
+        self.max_graphs = max_graphs
+        self._orig = model.forward                      # the class's forward, bound
+        self._graphs = {}                               # signature -> (graph, static inputs, static outputs, plan identity)
+        self._seen = {}                                 # signature -> occurrences before capture (or -1: never capture)
+        self._busy = False
+        model.forward = self._dispatch                  # instance attribute: nn.Module._call_impl calls self.forward
+
+    def __getstate__(self):                             # pickled with the model (torch.save): graphs stay behind
+        return {"model": self.model, "max_graphs": self.max_graphs}
+
+    def __setstate__(self, state):
+        self.model, self.max_graphs = state["model"], state["max_graphs"]
+        self._orig = type(self.model).forward.__get__(self.model)
+        self._graphs, self._seen, self._busy = {}, {}, False
+
+    def _signature(self, args, kwargs):
+        if kwargs or not args or self._busy or self.model.training:
+            return None
+        if torch.jit.is_tracing() or torch.compiler.is_compiling():
+            return None
+        grad = torch.is_grad_enabled()
+        sig = []
+        for a in args:
+            if type(a) is not torch.Tensor or not a.is_cuda or (grad and a.requires_grad):
+                return None
+            sig.append((tuple(a.shape), a.dtype, a.device.index))
+        handle = accelerated(self.model)
+        if handle is None or handle._plan is None:      # the graph reads the plan's persistent weight buffers
+            return None
+        return tuple(sig)
+
+    def _dispatch(self, *args, **kwargs):
+        sig = self._signature(args, kwargs)
+        if sig is None:
+            return self._orig(*args, **kwargs)
+        plan = accelerated(self.model)._plan
+        hit = self._graphs.get(sig)
+        if hit is not None and hit[3] is not plan:      # the weights moved to other buffers: every graph is stale
+            self._graphs.clear()
+            hit = None
+        if hit is None:
+            n = self._seen.get(sig, 0)
+            if n < 0 or len(self._graphs) >= self.max_graphs:
+                return self._orig(*args)
+            self._seen[sig] = n + 1
+            if n == 0:                                  # first occurrence: eager (warms the allocator and lazy state too)
+                return self._orig(*args)
+            hit = self._capture(sig, args, plan)
+            if hit is None:
+                return self._orig(*args)
+        graph, static_in, static_out, _ = hit
+        for dst, src in zip(static_in, args):
+            dst.copy_(src)
+        graph.replay()
+        return torch.utils._pytree.tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) else t, static_out)
+
+    def _capture(self, sig, args, plan):
+        self._busy = True
+        try:
+            static_in = tuple(a.detach().clone() for a in args)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    self._orig(*static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                static_out = self._orig(*static_in)
+            hit = (graph, static_in, static_out, plan)
+            self._graphs[sig] = hit
+            return hit
+        except Exception:                               # noqa: BLE001 -- not capturable (data-dependent control flow, ...): eager
+            self._seen[sig] = -1
+            torch.cuda.synchronize()
+            return None
+        finally:
+            self._busy = False
+
+    def release(self):
+        """Drop the graphs and give the model its own forward back."""
+        self._graphs.clear()
+        if self.model.__dict__.get("forward") is not None:
+            del self.model.__dict__["forward"]
+
+
+_CAPTURE_KEY = "_mctq_auto_capture"
+
+
+def auto_capture(model: nn.Module) -> nn.Module:
+    """``accelerate(model)`` + replay of the forward from one hipGraph per input signature (``AutoCapture``); idempotent."""
+    accelerate(model)
+    if model.__dict__.get(_CAPTURE_KEY) is None and accelerated(model) is not None:
+        model.__dict__[_CAPTURE_KEY] = AutoCapture(model)
+    return model

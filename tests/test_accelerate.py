@@ -72,6 +72,10 @@ def test_accelerate_is_idempotent_and_removable():
     assert len(net._forward_pre_hooks) == 1
     mq.decelerate(net)
     assert mq.accelerated(net) is None and len(net._forward_pre_hooks) == 0 and len(net._forward_hooks) == 0
+    manual = _small_model()                                  # a batcher installed by hand is not doubled
+    h = mq.batch_weight_quantization(manual, reuse_buffers=True)
+    assert mq.accelerate(manual) is manual and mq.accelerated(manual) is None and len(manual._forward_pre_hooks) == 1
+    h.remove()
     plain = nn.Sequential(nn.Linear(3, 3))
     assert mq.accelerate(plain) is plain and mq.accelerated(plain) is None      # nothing to batch: nothing installed
     with pytest.raises(TypeError):
@@ -324,3 +328,81 @@ def test_accelerated_model_follows_casts_and_compiles(monkeypatch, compiled_bind
 def _quantized(model, key):
     name, wname = key.rsplit(".", 1)
     return getattr(dict(model.named_modules())[name].layer, wname).detach()
+
+
+def test_auto_capture_on_cpu_is_a_pass_through_that_pickles_and_comes_off(tmp_path, monkeypatch):
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "1")
+    monkeypatch.setenv("MCTQ_AUTO_CAPTURE", "1")
+    net = _small_model()
+    x = torch.randn(2, 3, 10, 10)
+    want = net(x)
+    path = str(tmp_path / "m.pth")
+    torch.save(net, path)
+    loaded = mq.pytorch_load_quantized_model(path)
+    cap = loaded.__dict__.get("_mctq_auto_capture")
+    assert cap is not None and loaded.__dict__["forward"].__self__ is cap
+    assert torch.equal(loaded(x), want) and torch.equal(loaded(x), want) and not cap._graphs     # CPU tensors: eager
+    torch.save(loaded, path)                                                  # graphs and plans stay behind
+    again = mq.pytorch_load_quantized_model(path)
+    assert torch.equal(again(x), want) and again.__dict__["forward"].__self__ is again.__dict__["_mctq_auto_capture"]
+    mq.decelerate(loaded)
+    assert "forward" not in loaded.__dict__ and mq.accelerated(loaded) is None and torch.equal(loaded(x), want)
+    monkeypatch.setenv("MCTQ_AUTO_CAPTURE", "0")
+    assert "_mctq_auto_capture" in mq.pytorch_load_quantized_model(path).__dict__             # a capture saved with the model is kept
+
+
+@pytest.mark.gpu
+def test_auto_capture_replays_the_forward_and_follows_weights_shapes_and_modes(compiled_binding):
+    model = mq.accelerate(_small_model("cuda"), capture=True)
+    cap = model.__dict__["_mctq_auto_capture"]
+    ref = _small_model("cuda")
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+    with torch.no_grad():
+        want = ref(x)
+        y1 = model(x)                                        # first occurrence: eager
+        assert not cap._graphs
+        y2 = model(x)                                        # second: captured, replayed
+        assert len(cap._graphs) == 1
+        y3 = model(x)
+    assert torch.allclose(y1, want, atol=1e-5) and torch.allclose(y2, want, atol=1e-5) and torch.equal(y2, y3)
+    assert y2.data_ptr() != y3.data_ptr()                    # clones, not the graph's static buffer
+    with torch.no_grad():
+        model.conv.weight.mul_(0.5); ref.conv.weight.mul_(0.5)               # an in-place weight update is followed
+        assert torch.allclose(model(x), ref(x), atol=1e-5)
+        assert bits_equal(_quantized(model, "conv.weight").cpu().numpy(), _quantized(ref, "conv.weight").cpu().numpy())
+        x2 = torch.randn(5, 3, 12, 12, device="cuda")                        # another signature: its own graph at its 2nd call
+        model(x2)
+        assert torch.allclose(model(x2), ref(x2), atol=1e-5) and len(cap._graphs) == 2
+        n_graphs = len(cap._graphs)
+        model.train()
+        assert torch.allclose(model(x), ref(x), atol=1e-5)                   # training mode: eager
+        model.eval()
+    xg = x.clone().requires_grad_(True)                      # grad-requiring input with grad enabled: eager, differentiable
+    out = model(xg)
+    assert out.requires_grad and len(cap._graphs) == n_graphs
+    model.conv.weights_quantizers["weight"].scales = model.conv.weights_quantizers["weight"].scales * 2   # plan rebuilt
+    ref.conv.weights_quantizers["weight"].scales = ref.conv.weights_quantizers["weight"].scales * 2
+    with torch.no_grad():
+        assert torch.allclose(model(x), ref(x), atol=1e-5)                   # stale graphs dropped, eager ...
+        assert torch.allclose(model(x), ref(x), atol=1e-5) and len(cap._graphs) == 1     # ... and captured anew
+    mq.decelerate(model)
+    with torch.no_grad():
+        assert torch.allclose(model(x), ref(x), atol=1e-5) and "forward" not in model.__dict__
+
+
+@pytest.mark.gpu
+def test_auto_capture_of_the_wrapped_resnet50(compiled_binding, tmp_path, monkeypatch):
+    monkeypatch.setenv("MCTQ_AUTO_CAPTURE", "1")
+    path = str(tmp_path / "r50.pth")
+    torch.save(workloads.wrapped_resnet50("cuda"), path)
+    model = mq.pytorch_load_quantized_model(path)
+    monkeypatch.setenv("MCTQ_AUTO_CAPTURE", "0")
+    eager = mq.pytorch_load_quantized_model(path)
+    x = torch.randn(1, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        want = eager(x)
+        model(x)
+        n, got = _forward_launches(model, x)                 # the replayed forward: only the weight launch is issued eagerly
+    assert n == 1 and _logits_close(got, want)
+    w_cap, w_eager = _quantized_weights(model), _quantized_weights(eager)
+    assert all(bits_equal(w_cap[k], w_eager[k]) for k in w_eager)
