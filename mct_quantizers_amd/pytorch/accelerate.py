@@ -177,18 +177,25 @@ class AutoCapture:
             static_in = tuple(a.detach().clone() for a in args)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            handle = accelerated(self.model)
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):
+                    handle.reopen()                      # the wrappers take the plan's persistent tensors, as under the hook
                     self._orig(*static_in)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            handle.reopen()
             with torch.cuda.graph(graph), torch.no_grad():
                 static_out = self._orig(*static_in)
+            if accelerated(self.model)._plan is not plan:
+                raise RuntimeError("the plan changed during capture")
             hit = (graph, static_in, static_out, plan)
             self._graphs[sig] = hit
             return hit
         except Exception:                               # noqa: BLE001 -- not capturable (data-dependent control flow, ...): eager
+            if os.environ.get("MCTQ_CAPTURE_DEBUG"):
+                raise
             self._seen[sig] = -1
             torch.cuda.synchronize()
             return None

@@ -203,6 +203,15 @@ class BatchedWeightQuantization:
         cell[1] = True
         return len(entries)
 
+    def reopen(self) -> bool:
+        """The tensors of the last launch count as fresh once more (no launch): for a caller that runs the model's forward
+        again behind the hook that filled them -- ``accelerate.AutoCapture`` warming up and capturing.  False without a plan."""
+        if self._plan is None:
+            return False
+        self._cell[0] += 1
+        self._cell[1] = True
+        return True
+
     def _before_forward(self, module, args):
         self.quantize_now()
         return None

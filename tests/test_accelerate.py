@@ -353,9 +353,9 @@ def test_auto_capture_on_cpu_is_a_pass_through_that_pickles_and_comes_off(tmp_pa
 
 @pytest.mark.gpu
 def test_auto_capture_replays_the_forward_and_follows_weights_shapes_and_modes(compiled_binding):
-    model = mq.accelerate(_small_model("cuda"), capture=True)
+    model = mq.accelerate(_small_model("cuda").eval(), capture=True)
     cap = model.__dict__["_mctq_auto_capture"]
-    ref = _small_model("cuda")
+    ref = _small_model("cuda").eval()
     x = torch.randn(2, 3, 10, 10, device="cuda")
     with torch.no_grad():
         want = ref(x)
@@ -401,8 +401,9 @@ def test_auto_capture_of_the_wrapped_resnet50(compiled_binding, tmp_path, monkey
     x = torch.randn(1, 3, 64, 64, device="cuda")
     with torch.no_grad():
         want = eager(x)
-        model(x)
-        n, got = _forward_launches(model, x)                 # the replayed forward: only the weight launch is issued eagerly
+        model(x)                                             # first occurrence: eager
+        model(x)                                             # second: captured
+        n, got = _forward_launches(model, x)                 # replayed: only the weight launch is issued eagerly
     assert n == 1 and _logits_close(got, want)
     w_cap, w_eager = _quantized_weights(model), _quantized_weights(eager)
     assert all(bits_equal(w_cap[k], w_eager[k]) for k in w_eager)
