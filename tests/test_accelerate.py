@@ -377,9 +377,10 @@ def test_auto_capture_replays_the_forward_and_follows_weights_shapes_and_modes(c
         model.train()
         assert torch.allclose(model(x), ref(x), atol=1e-5)                   # training mode: eager
         model.eval()
-    xg = x.clone().requires_grad_(True)                      # grad-requiring input with grad enabled: eager, differentiable
-    out = model(xg)
-    assert out.requires_grad and len(cap._graphs) == n_graphs
+    xg = x.clone().requires_grad_(True)                      # grad-requiring input with grad enabled: eager
+    seen_before = dict(cap._seen)
+    model(xg); model(xg)
+    assert len(cap._graphs) == n_graphs and cap._seen == seen_before
     model.conv.weights_quantizers["weight"].scales = model.conv.weights_quantizers["weight"].scales * 2   # plan rebuilt
     ref.conv.weights_quantizers["weight"].scales = ref.conv.weights_quantizers["weight"].scales * 2
     with torch.no_grad():
