@@ -110,13 +110,16 @@ class AutoCapture:
     A signature (shapes, dtypes, devices of the positional tensor arguments) is captured at its SECOND occurrence; anything
     else runs eagerly: keyword arguments, non-tensor or CPU arguments, training mode, grad-requiring inputs with grad
     enabled, an active trace / compile, a model whose weights are not served by the pre-packed plan.  Outputs are CLONES of
-    the graph's static buffers (the caller may keep them).  A rebuilt plan (changed quantizer parameters, ``model.half()``)
-    or ``release()`` drops the graphs."""
+    the graph's static buffers (the caller may keep them).  A rebuilt plan (changed weights-quantizer parameters,
+    ``model.half()``), a hook registered on a sub-module, a swapped or re-parameterised activation quantizer, a toggled
+    ``quantization_bypass`` (``_fingerprint``) or ``release()`` drop the graphs; what a replay cannot follow is a change of
+    the module tree itself or of Python state the forward reads that none of these cover."""
 
     def __init__(self, model: nn.Module, max_graphs: int = 8):
         self.model = model
         self.max_graphs = max_graphs
         self._orig = model.forward                      # the class's forward, bound
+        self._state = None                              # _fingerprint() at the first capture
         self._graphs = {}                               # signature -> (graph, static inputs, static outputs, plan identity)
         self._seen = {}                                 # signature -> occurrences before capture (or -1: never capture)
         self._busy = False
@@ -128,7 +131,25 @@ class AutoCapture:
     def __setstate__(self, state):
         self.model, self.max_graphs = state["model"], state["max_graphs"]
         self._orig = type(self.model).forward.__get__(self.model)
-        self._graphs, self._seen, self._busy = {}, {}, False
+        self._graphs, self._seen, self._busy, self._state = {}, {}, False, None
+
+    def _fingerprint(self):
+        """Python-level state a replay would otherwise freeze: hooks on any sub-module (they do not fire during a replay),
+        every holder's quantizer object, its launch state (assigning to a public parameter drops it) and bypass switch.
+        ~20 us for a ResNet-50; compared on every call, a difference drops the graphs."""
+        mods = self.__dict__.get("_mods")
+        if mods is None:
+            from mct_quantizers_amd.pytorch.containers import PytorchActivationQuantizationHolder
+            allm = [m for m in self.model.modules() if m is not self.model]
+            mods = self.__dict__["_mods"] = (allm, [m for m in allm if isinstance(m, PytorchActivationQuantizationHolder)])
+        hooks = 0
+        for m in mods[0]:
+            hooks += len(m._forward_hooks) + len(m._forward_pre_hooks)
+        state = [hooks]
+        for h in mods[1]:
+            q = h.__dict__.get("activation_holder_quantizer")
+            state.append((id(q), id(getattr(q, "__dict__", {}).get("_plan")), bool(h.__dict__.get("quantization_bypass"))))
+        return tuple(state)
 
     def _signature(self, args, kwargs):
         if kwargs or not args or self._busy or self.model.training:
@@ -152,9 +173,11 @@ class AutoCapture:
             return self._orig(*args, **kwargs)
         plan = accelerated(self.model)._plan
         hit = self._graphs.get(sig)
-        if hit is not None and hit[3] is not plan:      # the weights moved to other buffers: every graph is stale
-            self._graphs.clear()
-            hit = None
+        if self._graphs:
+            if next(iter(self._graphs.values()))[3] is not plan or self._fingerprint() != self._state:
+                self._graphs.clear()                    # the weights moved to other buffers / Python-level state changed
+                self._seen.clear()
+                hit = None
         if hit is None:
             n = self._seen.get(sig, 0)
             if n < 0 or len(self._graphs) >= self.max_graphs:
@@ -191,6 +214,8 @@ class AutoCapture:
             if accelerated(self.model)._plan is not plan:
                 raise RuntimeError("the plan changed during capture")
             hit = (graph, static_in, static_out, plan)
+            if not self._graphs:
+                self._state = self._fingerprint()       # taken AFTER the capture: the eager calls re-made the launch states
             self._graphs[sig] = hit
             return hit
         except Exception:                               # noqa: BLE001 -- not capturable (data-dependent control flow, ...): eager

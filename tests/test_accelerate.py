@@ -386,6 +386,19 @@ def test_auto_capture_replays_the_forward_and_follows_weights_shapes_and_modes(c
     with torch.no_grad():
         assert torch.allclose(model(x), ref(x), atol=1e-5)                   # stale graphs dropped, eager ...
         assert torch.allclose(model(x), ref(x), atol=1e-5) and len(cap._graphs) == 1     # ... and captured anew
+        # Python-level state a replay would freeze: a hook on a sub-module, an activation quantizer's parameter
+        seen = []
+        hk = model.act.register_forward_hook(lambda m, i, o: seen.append(1))
+        model(x)
+        assert seen == [1] and not cap._graphs                                 # dropped: the hook fired in an eager forward
+        hk.remove()
+        model(x); model(x)
+        assert len(cap._graphs) == 1
+        model.act.activation_holder_quantizer.scale = 0.25
+        ref.act.activation_holder_quantizer.scale = 0.25
+        assert torch.allclose(model(x), ref(x), atol=1e-5) and not cap._graphs
+        model(x)
+        assert torch.allclose(model(x), ref(x), atol=1e-5) and len(cap._graphs) == 1
     mq.decelerate(model)
     with torch.no_grad():
         assert torch.allclose(model(x), ref(x), atol=1e-5) and "forward" not in model.__dict__
