@@ -108,8 +108,9 @@ class AutoCapture:
     are followed exactly as in eager mode -- and then, instead of the Python forward, the graph that reads those buffers.
 
     A signature (shapes, dtypes, devices of the positional tensor arguments) is captured at its SECOND occurrence; anything
-    else runs eagerly: keyword arguments, non-tensor or CPU arguments, training mode, grad-requiring inputs with grad
-    enabled, an active trace / compile, a model whose weights are not served by the pre-packed plan.  Outputs are CLONES of
+    else runs eagerly: keyword arguments, non-tensor or CPU arguments, training mode, grad mode on while an input or any
+    parameter of the model requires grad (a replay builds no autograd graph: use ``torch.no_grad()`` for inference), an
+    active trace / compile, a model whose weights are not served by the pre-packed plan.  Outputs are CLONES of
     the graph's static buffers (the caller may keep them).  A rebuilt plan (changed weights-quantizer parameters,
     ``model.half()``), a hook registered on a sub-module, a swapped or re-parameterised activation quantizer, a toggled
     ``quantization_bypass`` (``_fingerprint``) or ``release()`` drop the graphs; what a replay cannot follow is a change of
@@ -118,7 +119,8 @@ class AutoCapture:
     def __init__(self, model: nn.Module, max_graphs: int = 8):
         self.model = model
         self.max_graphs = max_graphs
-        self._orig = model.forward                      # the class's forward, bound
+        self._prev = model.__dict__.get("forward")      # an instance-level forward somebody else put there (restored by release)
+        self._orig = model.forward                      # the class's forward, bound (or that override)
         self._state = None                              # _fingerprint() at the first capture
         self._graphs = {}                               # signature -> (graph, static inputs, static outputs, plan identity)
         self._seen = {}                                 # signature -> occurrences before capture (or -1: never capture)
@@ -126,11 +128,11 @@ class AutoCapture:
         model.forward = self._dispatch                  # instance attribute: nn.Module._call_impl calls self.forward
 
     def __getstate__(self):                             # pickled with the model (torch.save): graphs stay behind
-        return {"model": self.model, "max_graphs": self.max_graphs}
+        return {"model": self.model, "max_graphs": self.max_graphs, "_prev": self.__dict__.get("_prev")}
 
     def __setstate__(self, state):
-        self.model, self.max_graphs = state["model"], state["max_graphs"]
-        self._orig = type(self.model).forward.__get__(self.model)
+        self.model, self.max_graphs, self._prev = state["model"], state["max_graphs"], state.get("_prev")
+        self._orig = self._prev if self._prev is not None else type(self.model).forward.__get__(self.model)
         self._graphs, self._seen, self._busy, self._state = {}, {}, False, None
 
     def _fingerprint(self):
@@ -157,6 +159,13 @@ class AutoCapture:
         if torch.jit.is_tracing() or torch.compiler.is_compiling():
             return None
         grad = torch.is_grad_enabled()
+        if grad:                                        # a replay builds no autograd graph: only when nothing could ask for one
+            params = self.__dict__.get("_params")
+            if params is None:
+                params = self.__dict__["_params"] = list(self.model.parameters())
+            for p in params:
+                if p.requires_grad:
+                    return None
         sig = []
         for a in args:
             if type(a) is not torch.Tensor or not a.is_cuda or (grad and a.requires_grad):
@@ -232,6 +241,8 @@ class AutoCapture:
         self._graphs.clear()
         if self.model.__dict__.get("forward") is not None:
             del self.model.__dict__["forward"]
+        if self.__dict__.get("_prev") is not None:
+            self.model.__dict__["forward"] = self._prev
 
 
 _CAPTURE_KEY = "_mctq_auto_capture"

@@ -381,6 +381,16 @@ def test_auto_capture_replays_the_forward_and_follows_weights_shapes_and_modes(c
     seen_before = dict(cap._seen)
     model(xg); model(xg)
     assert len(cap._graphs) == n_graphs and cap._seen == seen_before
+    x9 = torch.randn(3, 3, 9, 9, device="cuda")              # grad mode on and the model has a parameter that requires grad
+    assert model.lin.bias.requires_grad is False             # (the weights quantizers switched theirs off, as the reference's)
+    extra = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+    model.register_parameter("extra", extra); cap.__dict__.pop("_params", None)
+    model(x9); model(x9)
+    assert (((3, 3, 9, 9), torch.float32, 0),) not in cap._graphs           # no replay: it would build no autograd graph
+    with torch.no_grad():
+        model(x9); model(x9)
+    assert (((3, 3, 9, 9), torch.float32, 0),) in cap._graphs
+    del model._parameters["extra"]; cap.__dict__.pop("_params", None)
     model.conv.weights_quantizers["weight"].scales = model.conv.weights_quantizers["weight"].scales * 2   # plan rebuilt
     ref.conv.weights_quantizers["weight"].scales = ref.conv.weights_quantizers["weight"].scales * 2
     with torch.no_grad():
