@@ -431,3 +431,100 @@ def test_auto_capture_of_the_wrapped_resnet50(compiled_binding, tmp_path, monkey
     assert n == 1 and _logits_close(got, want)
     w_cap, w_eager = _quantized_weights(model), _quantized_weights(eager)
     assert all(bits_equal(w_cap[k], w_eager[k]) for k in w_eager)
+
+
+def _random_wrapped_model(rng, device="cuda"):
+    """A random stack of wrapped Linear / Conv2d layers (+ holders) with random weights quantizers of every class."""
+    lut16 = workloads.LUT16
+    layers, feat = [], int(rng.integers(3, 9))
+    conv_part = bool(rng.integers(0, 2))
+    cin = feat
+    if conv_part:
+        for _ in range(int(rng.integers(1, 4))):
+            cout, k = int(rng.integers(2, 20)), int(rng.choice([1, 3]))
+            conv = nn.Conv2d(cin, cout, k, padding=k // 2, bias=bool(rng.integers(0, 2)))
+            layers.append(("conv", conv))
+            cin = cout
+        layers.append(("pool", None))
+    width = cin
+    for _ in range(int(rng.integers(1, 5))):
+        out = int(rng.integers(1, 70))
+        layers.append(("lin", nn.Linear(width, out, bias=bool(rng.integers(0, 2)))))
+        width = out
+    mods = []
+    for kind, layer in layers:
+        if kind == "pool":
+            mods += [nn.AdaptiveAvgPool2d(1), nn.Flatten()]
+            continue
+        w = layer.weight.detach()
+        c = w.shape[0]
+        choice = int(rng.integers(0, 7))
+        bits = int(rng.integers(2, 9))
+        if choice == 0:
+            q = Q.WeightsSymmetricInferableQuantizer(bits, [float(v) + 1e-3 for v in w.abs().amax(dim=tuple(range(1, w.dim())))], True, 0)
+        elif choice == 1:
+            q = Q.WeightsSymmetricInferableQuantizer(bits, [float(w.abs().max()) + 1e-3], False)
+        elif choice == 2:
+            q = Q.WeightsPOTInferableQuantizer(bits, [float(2.0 ** int(rng.integers(-3, 2)))] * c, True, 0)
+        elif choice == 3:
+            lo = [float(v) - 1e-2 for v in w.amin(dim=tuple(range(1, w.dim())))]
+            hi = [float(v) + 1e-2 for v in w.amax(dim=tuple(range(1, w.dim())))]
+            q = Q.WeightsUniformInferableQuantizer(bits, lo, hi, True, 0)
+        elif choice == 4:
+            q = Q.WeightsUniformInferableQuantizer(bits, [-1.0], [1.5], False)
+        elif choice == 5:
+            q = Q.WeightsLUTSymmetricInferableQuantizer(4, lut16, [float(v) + 1e-3 for v in w.abs().amax(dim=tuple(range(1, w.dim())))],
+                                                        True, 0, w.dim())
+        else:
+            q = Q.WeightsLUTPOTInferableQuantizer(4, lut16, [float(2.0 ** int(rng.integers(-2, 2)))], False)
+        quantizers = {"weight": q}
+        if layer.bias is not None and rng.integers(0, 2):
+            quantizers["bias"] = Q.WeightsSymmetricInferableQuantizer(8, [float(layer.bias.detach().abs().max()) + 1e-3], False)
+        mods.append(mq.PytorchQuantizationWrapper(layer, quantizers))
+        if rng.integers(0, 3):
+            mods += [nn.ReLU(), mq.PytorchActivationQuantizationHolder(Q.ActivationSymmetricInferableQuantizer(8, [8.0], False))]
+    model = nn.Sequential(*mods).to(device).eval()
+    shape = (int(rng.integers(1, 4)), feat, 7, 7) if conv_part else (int(rng.integers(1, 5)), feat)
+    return model, shape
+
+
+@pytest.mark.gpu
+def test_fuzz_accelerated_and_auto_captured_random_models_against_the_per_layer_path(compiled_binding):
+    """Random wrapped models (every weights-quantizer class, per tensor / per channel, biases with and without their own
+    quantizer): saved, loaded with the hook on (default), then with MCTQ_AUTO_CAPTURE -- every quantized weight bit-equal
+    to the per-layer path, outputs equal up to the layers' own arithmetic.  MCTQ_FUZZ_SEED / MCTQ_FUZZ_CASES for soak runs."""
+    import copy
+    import warnings as _w
+    rng = np.random.default_rng(4200 + int(os.environ.get("MCTQ_FUZZ_SEED", "0")))
+    for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "25"))):
+        with _w.catch_warnings():
+            _w.simplefilter("ignore")
+            model, shape = _random_wrapped_model(rng)
+        x = torch.randn(*shape, device="cuda")
+        fast = copy.deepcopy(model)
+        cap = copy.deepcopy(model)
+        mq.accelerate(fast)
+        mq.accelerate(cap, capture=True)
+        with torch.no_grad():
+            want = model(x)
+            w_ref = _quantized_weights(model)
+            for m in (fast, cap):
+                for _ in range(3):
+                    got = m(x)
+                assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-4, atol=1e-4), (case, float((got - want).abs().max()))
+                w = _quantized_weights(m)
+                for key in w_ref:
+                    assert bits_equal(w[key], w_ref[key]), (case, key)
+            # in-place weight updates are followed by both
+            for m in (model, fast, cap):
+                for p in m.parameters():
+                    p.mul_(0.75)
+            want = model(x)
+            w_ref = _quantized_weights(model)
+            for m in (fast, cap):
+                got = m(x)
+                assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), case
+                w = _quantized_weights(m)
+                for key in w_ref:
+                    assert bits_equal(w[key], w_ref[key]), (case, key, "after update")
+        assert cap.__dict__["_mctq_auto_capture"]._graphs or mq.accelerated(cap)._plan is None, case
