@@ -953,6 +953,12 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const TI* __restrict__ x
 // 32 bytes in flight per lane; here a block takes U consecutive steps of the dense [rows][innerv] storage whatever row they
 // fall in (64 bytes in flight per lane, one contiguous 16 KiB read per block), and each step -- which lies inside ONE row --
 // gets that row's parameters by scalar loads, as in rows_kernel.
+// The kernel is sensitive to its instruction schedule in ways that did not transfer between shapes
+// (profiles/r04/rowsteps_forced.log): sharing one parameter fetch between the steps of a row (uniform branch) cost the
+// 4096 x 4096 bfloat16 launch 11.84 -> 12.6 us; compiling the all-steps-present path separately from the guarded one (what
+// one_tile does, and what helps this kernel when it is FORCED onto config 2: 23.5 -> 22.8 us, still behind rows_kernel's
+// 22.3) cost it 11.84 -> 12.8-13.0 us; eight steps per block on config 2 / 5 (one round of blocks) 22.2 / 94 us against
+// rows_kernel's 22.3 / 83.  The form below is the one the dispatcher's window was measured with.
 // ------------------------------------------------------------------------------------------
 template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void rowsteps_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,
