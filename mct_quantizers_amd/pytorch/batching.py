@@ -99,11 +99,24 @@ class BatchedWeightQuantization:
             wrappers = self.__dict__["_wrappers"]
         if not wrappers:
             return False
+        dev = None
         for m in wrappers:
             vars_ = m._weights_vars
-            if vars_ and not (isinstance(vars_[0][1], torch.Tensor) and vars_[0][1].is_cuda):
+            if not vars_:
+                continue
+            d = self._gpu_of(vars_[0][1])
+            if d is None:
+                return False
+            if dev is None:
+                dev = d
+            elif d != dev:                            # a model spread over several GPUs: one launch cannot serve it
                 return False
         return True
+
+    @staticmethod
+    def _gpu_of(weight):
+        """The GPU a weight lives on, or None (CPU tensor, not a tensor)."""
+        return weight.device if isinstance(weight, torch.Tensor) and weight.is_cuda else None
 
     @staticmethod
     def _watch(quantizer):

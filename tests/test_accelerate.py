@@ -121,6 +121,19 @@ def test_reference_pickle_through_the_loader(monkeypatch, switch):
     assert bits_equal(y, io["y"]), first_mismatch(y, io["y"])
 
 
+def test_hook_stands_aside_for_a_model_spread_over_devices():
+    """Weights on different GPUs (model parallelism): one launch cannot serve them -- the per-layer calls stay in charge.
+    (No second GPU here: the device of each wrapper's weight is what `_gpu_of` reports.)"""
+    net = mq.accelerate(_small_model())
+    handle = mq.accelerated(net)
+    assert handle._auto_applies() is False                                   # CPU weights
+    devices = iter([torch.device("cuda", 0), torch.device("cuda", 1)])
+    handle._gpu_of = lambda w: next(devices)
+    assert handle._auto_applies() is False                                   # two wrappers, two GPUs
+    handle._gpu_of = lambda w: torch.device("cuda", 0)
+    assert handle._auto_applies() is True
+
+
 def test_jit_trace_of_an_accelerated_model_records_the_reference_nodes():
     net = mq.accelerate(_small_model())
     x = torch.randn(1, 3, 10, 10)
