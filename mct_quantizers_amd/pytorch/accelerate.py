@@ -198,10 +198,17 @@ class AutoCapture:
             if hit is None:
                 return self._orig(*args)
         graph, static_in, static_out, _ = hit
-        for dst, src in zip(static_in, args):
-            dst.copy_(src)
-        graph.replay()
-        return torch.utils._pytree.tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) else t, static_out)
+        try:
+            for dst, src in zip(static_in, args):
+                dst.copy_(src)
+            graph.replay()
+            return torch.utils._pytree.tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) else t, static_out)
+        except Exception:                               # noqa: BLE001 -- a replay that cannot run: this signature stays eager
+            if os.environ.get("MCTQ_CAPTURE_DEBUG"):
+                raise
+            self._graphs.pop(sig, None)
+            self._seen[sig] = -1
+            return self._orig(*args)
 
     def _capture(self, sig, args, plan):
         self._busy = True

@@ -64,6 +64,7 @@ class BatchedWeightQuantization:
         state["_plan"] = None
         state["_wrappers"] = None
         state["_cell"] = [0, False]
+        state.pop("_auto_failed", None)
         return state
 
     def _entries(self, with_lut: bool = False) -> List[Tuple[PytorchQuantizationWrapper, str, torch.Tensor, object]]:
@@ -226,7 +227,25 @@ class BatchedWeightQuantization:
         return True
 
     def _before_forward(self, module, args):
-        self.quantize_now()
+        if not self.auto:
+            self.quantize_now()
+            return None
+        # auto mode was installed on a model nobody asked to batch: whatever goes wrong here must not become the forward's
+        # problem -- the per-layer calls are always there (and raise what the reference would raise, if anything)
+        if self.__dict__.get("_auto_failed"):
+            return None
+        try:
+            self.quantize_now()
+        except Exception as e:  # noqa: BLE001
+            self.__dict__["_auto_failed"] = True
+            self._cell[1] = False
+            try:
+                self._drop_plan()
+            except Exception:  # noqa: BLE001
+                pass
+            from mct_quantizers_amd.logger import Logger
+            Logger.warning(f"mct_quantizers_amd: the one-launch weight re-quantization stood down for this model "
+                           f"({type(e).__name__}: {e}); every wrapper calls its own quantizer (MCTQ_AUTO_BATCH=0 silences this)")
         return None
 
     def _after_forward(self, module, args, output):

@@ -134,6 +134,24 @@ def test_hook_stands_aside_for_a_model_spread_over_devices():
     assert handle._auto_applies() is True
 
 
+def test_an_error_inside_the_auto_hook_never_reaches_the_forward(caplog):
+    net = mq.accelerate(_small_model())
+    handle = mq.accelerated(net)
+    x = torch.randn(2, 3, 10, 10)
+    want = net(x)
+
+    def boom():
+        raise RuntimeError("synthetic")
+    handle.quantize_now = boom
+    assert torch.equal(net(x), want) and handle.__dict__.get("_auto_failed") is True      # stood down, forward unchanged
+    assert torch.equal(net(x), want)
+    manual = _small_model()                                  # a batcher installed BY HAND keeps raising: the caller asked for it
+    h = mq.batch_weight_quantization(manual, reuse_buffers=True)
+    h.quantize_now = boom
+    with pytest.raises(RuntimeError, match="synthetic"):
+        manual(x)
+
+
 def test_jit_trace_of_an_accelerated_model_records_the_reference_nodes():
     net = mq.accelerate(_small_model())
     x = torch.randn(1, 3, 10, 10)
