@@ -225,7 +225,8 @@ class AutoCapture:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             handle.reopen()
-            with torch.cuda.graph(graph), torch.no_grad():
+            from mct_quantizers_amd.pytorch.graphs import no_gc_while_capturing
+            with no_gc_while_capturing(), torch.cuda.graph(graph), torch.no_grad():
                 static_out = self._orig(*static_in)
             if accelerated(self.model)._plan is not plan:
                 raise RuntimeError("the plan changed during capture")

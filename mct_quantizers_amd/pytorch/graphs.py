@@ -14,6 +14,8 @@ exactly as in eager mode.  Shapes, dtypes and the module structure are frozen at
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 from typing import Callable, List, Sequence, Tuple
 
 import torch
@@ -21,6 +23,22 @@ import torch.nn as nn
 
 from mct_quantizers_amd.hip import ops
 from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+
+
+@contextlib.contextmanager
+def no_gc_while_capturing():
+    """Stream capture forbids most runtime calls, and the cyclic garbage collector may run at any allocation: if it then
+    frees an object whose destructor makes such a call -- an older hipGraph with its memory pool, dropped together with a
+    model it formed a reference cycle with -- the process aborts (seen in a fuzz that builds and drops captured models:
+    "Fatal Python error: Aborted ... Garbage-collecting" inside ``torch.cuda.graph``).  ``torch.cuda.graph`` collects BEFORE it
+    begins; this keeps the collector off until the capture has ended."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class CapturedForward:
@@ -45,7 +63,7 @@ class CapturedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with no_gc_while_capturing(), torch.cuda.graph(self.graph), torch.no_grad():
             self._static_out = model(*self._static_in)
         model.train(was_training)
 
@@ -158,7 +176,7 @@ class CapturedStream:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with no_gc_while_capturing(), torch.cuda.graph(self.graph), torch.no_grad():
             root = torch.cuda.current_stream()
             branches = [torch.cuda.Stream() for _ in range(self.lanes)] if self.lanes > 1 else [root]
             for b in branches:
