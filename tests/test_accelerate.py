@@ -464,6 +464,16 @@ def test_auto_capture_of_the_wrapped_resnet50(compiled_binding, tmp_path, monkey
     assert all(bits_equal(w_cap[k], w_eager[k]) for k in w_eager)
 
 
+def _quantized_weights_any(model):
+    """As _quantized_weights, tensors in their own type (16-bit weights)."""
+    out = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, mq.PytorchQuantizationWrapper):
+            for wname, _, _ in mod.get_weights_vars():
+                out[f"{name}.{wname}"] = getattr(mod.layer, wname).detach().clone()
+    return out
+
+
 def _random_wrapped_model(rng, device="cuda"):
     """A random stack of wrapped Linear / Conv2d layers (+ holders) with random weights quantizers of every class."""
     lut16 = workloads.LUT16
@@ -512,8 +522,19 @@ def _random_wrapped_model(rng, device="cuda"):
         if layer.bias is not None and rng.integers(0, 2):
             quantizers["bias"] = Q.WeightsSymmetricInferableQuantizer(8, [float(layer.bias.detach().abs().max()) + 1e-3], False)
         mods.append(mq.PytorchQuantizationWrapper(layer, quantizers))
-        if rng.integers(0, 3):
+        pick = int(rng.integers(0, 7))
+        if pick == 1:
             mods += [nn.ReLU(), mq.PytorchActivationQuantizationHolder(Q.ActivationSymmetricInferableQuantizer(8, [8.0], False))]
+        elif pick == 2:
+            mods.append(mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(int(rng.integers(2, 9)), [-2.5], [3.1])))
+        elif pick == 3:
+            mods.append(mq.PytorchFLNActivationQuantizationHolder(Q.ActivationPOTInferableQuantizer(8, [4.0], True),
+                                                                  quantization_bypass=bool(rng.integers(0, 2))))
+        elif pick == 4:
+            mods.append(mq.PytorchPreservingActivationQuantizationHolder(
+                Q.ActivationLutPOTInferableQuantizer(4, lut16, [4.0], True), quantization_bypass=bool(rng.integers(0, 2))))
+        elif pick == 5:
+            mods.append(nn.ReLU())
     model = nn.Sequential(*mods).to(device).eval()
     shape = (int(rng.integers(1, 4)), feat, 7, 7) if conv_part else (int(rng.integers(1, 5)), feat)
     return model, shape
@@ -559,4 +580,28 @@ def test_fuzz_accelerated_and_auto_captured_random_models_against_the_per_layer_
                 for key in w_ref:
                     assert bits_equal(w[key], w_ref[key]), (case, key, "after update")
         assert cap.__dict__["_mctq_auto_capture"]._graphs or mq.accelerated(cap)._plan is None, case
+        with torch.no_grad():
+            # a second input signature (its own graph at its second occurrence), then back to the first
+            x2 = torch.randn(shape[0] + 1, *shape[1:], device="cuda")
+            want2 = model(x2)
+            for m in (fast, cap):
+                for _ in range(3):
+                    assert torch.allclose(m(x2), want2, rtol=1e-4, atol=1e-4), (case, "second shape")
+                assert torch.allclose(m(x), want, rtol=1e-4, atol=1e-4), (case, "first shape again")
+            # 16-bit weights (affine quantizers only: LUT quantizers answer in float32 whatever the weight's type)
+            wrappers = [m for m in model.modules() if isinstance(m, mq.PytorchQuantizationWrapper)]
+            if not any(hasattr(q, "_lut_values_np") for w in wrappers for q in w.weights_quantizers.values()) and \
+                    not any(hasattr(getattr(m, "activation_holder_quantizer", None), "_lut_values_np") for m in model.modules()):
+                dt = torch.bfloat16 if case % 2 else torch.float16
+                model.to(dt); fast.to(dt); cap.to(dt)
+                xh = x.to(dt)
+                wanth = model(xh)
+                w_ref = _quantized_weights_any(model)
+                for m in (fast, cap):
+                    for _ in range(3):
+                        got = m(xh)
+                    assert got.dtype == dt and torch.allclose(got.float(), wanth.float(), rtol=2e-2, atol=2e-2), (case, str(dt))
+                    w = _quantized_weights_any(m)
+                    for key in w_ref:
+                        assert torch.equal(w[key], w_ref[key]), (case, key, str(dt))
         # (models with graphs are dropped here while later cases capture: what no_gc_while_capturing is for)
