@@ -208,3 +208,41 @@ def test_capture_forward_replays_the_model_and_follows_weight_updates(lib):
         cap.release()
         with torch.no_grad():
             assert torch.equal(model(x), ref(x))
+
+
+def test_captures_survive_an_aggressive_garbage_collector(lib):
+    """Captured objects form reference cycles with their models; if the cyclic collector frees an older hipGraph WHILE a
+    newer capture is recording, the runtime call in its destructor aborts the process (seen in the accelerate fuzz,
+    profiles/r04/fuzz_soak.log).  With the collector set to run at every allocation, build / use / drop captured forwards,
+    auto-captured models and graph-mode streams in a loop: pytorch/graphs.py: no_gc_while_capturing keeps this alive."""
+    import gc
+    import mct_quantizers_amd as mq
+    Q = mq.pytorch_quantizers
+
+    def model():
+        lin = torch.nn.Linear(32, 16).cuda()
+        thr = [float(v) for v in lin.weight.detach().abs().amax(dim=1)]
+        return torch.nn.Sequential(
+            mq.PytorchQuantizationWrapper(lin, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)}),
+            mq.PytorchActivationQuantizationHolder(Q.ActivationUniformInferableQuantizer(8, [-2.5], [3.1]))).eval()
+
+    x = torch.randn(4, 32, device="cuda")
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        for i in range(12):
+            m = mq.accelerate(model(), capture=True)                         # model <-> AutoCapture cycle, graphs inside
+            with torch.no_grad():
+                want = m(x)
+                for _ in range(3):
+                    assert torch.equal(m(x), want)
+            assert m.__dict__["_mctq_auto_capture"]._graphs
+            cf = mq.capture_forward(model(), x)                              # CapturedForward
+            assert cf(x).shape == (4, 16)
+            lutq = Q.ActivationLutPOTInferableQuantizer(3, [-128.0, -64.0, -20.0, -5.0, 0.0, 5.0, 20.0, 64.0], [4.0], True)
+            st = mq.capture_stream(lutq, x, depth=3, mode="graph")           # CapturedStream, hipGraph mode
+            st.run()
+            del m, cf, st                                                    # dropped WITHOUT release(): garbage with graphs
+    finally:
+        gc.set_threshold(*old)
+        gc.collect()
