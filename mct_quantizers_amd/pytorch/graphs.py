@@ -30,8 +30,9 @@ def no_gc_while_capturing():
     """Stream capture forbids most runtime calls, and the cyclic garbage collector may run at any allocation: if it then
     frees an object whose destructor makes such a call -- an older hipGraph with its memory pool, dropped together with a
     model it formed a reference cycle with -- the process aborts (seen in a fuzz that builds and drops captured models:
-    "Fatal Python error: Aborted ... Garbage-collecting" inside ``torch.cuda.graph``).  ``torch.cuda.graph`` collects BEFORE it
-    begins; this keeps the collector off until the capture has ended."""
+    "Fatal Python error: Aborted ... Garbage-collecting" inside ``torch.cuda.graph``).  ``torch.cuda.graph`` no longer
+    collects before it begins (``torch.compiler.config.force_cudagraph_gc`` is off by default since torch 2.x), so dead
+    cycles can still be around; this keeps the collector off until the capture has ended -- they are freed right after."""
     was = gc.isenabled()
     gc.disable()
     try:
