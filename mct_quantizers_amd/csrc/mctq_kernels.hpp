@@ -958,7 +958,8 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const TI* __restrict__ x
 // 4096 x 4096 bfloat16 launch 11.84 -> 12.6 us; compiling the all-steps-present path separately from the guarded one (what
 // one_tile does, and what helps this kernel when it is FORCED onto config 2: 23.5 -> 22.8 us, still behind rows_kernel's
 // 22.3) cost it 11.84 -> 12.8-13.0 us; eight steps per block on config 2 / 5 (one round of blocks) 22.2 / 94 us against
-// rows_kernel's 22.3 / 83.  The form below is the one the dispatcher's window was measured with.
+// rows_kernel's 22.3 / 83; all loads -> all results -> all stores 13.1.  The form below is the one the dispatcher's window was
+// measured with (its compiled schedule starts staggered: three loads, the fourth when the first has returned).
 // ------------------------------------------------------------------------------------------
 template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void rowsteps_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,
