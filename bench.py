@@ -43,6 +43,13 @@ needs no collective); ``value`` is the sum over ranks divided by the slowest ran
 dim 0 + ONE all-gather (RCCL) is measured outside the timed region and reported as ``sharded_cfg5`` plus the top-level
 ``sharded_cfg5_*`` fields (``--gather`` forces it at N = 1 under torchrun).
 
+Self-verifying at every N: each rank compares the SHA-256 of the output of its last timed step with the REFERENCE's digest
+(``ranks_parity_ok``), and of its config-5 shard with the reference's digest of that row block
+(``sharded_cfg5.ranks_shard_digest_ok``); one mismatch -> ``parity_error`` and exit status 3.  Rank 0 runs the
+``cpu_baseline`` leg at every N.  With N > 1 the job exits non-zero instead of printing a line when RCCL cannot form the
+group (status 6) or the sharded config-5 leg fails (status 7) -- unless ``--allow-gloo`` is given (rehearsals on fewer GPUs
+than ranks: gloo control plane, gather staged through the host; the line says so).
+
 ``--device cpu`` is a dry run of the entry path (launcher, process group over gloo, barriers, max-over-ranks, JSON)
 on the config-1 plumbing workload for the CPU test-suite; its line says so and is not a measurement.
 
@@ -112,6 +119,10 @@ def parse():
                          "pytorch_load_quantized_model (per-layer vs auto-batched vs captured; bench_e2e.py)")
     ap.add_argument("--e2e-lut", action="store_true", help="--e2e with 16-entry LUT weights quantizers")
     ap.add_argument("--e2e-side", type=int, default=224, help="--e2e: image side")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="N > 1 only: accept a gloo control plane when RCCL cannot form the group (rehearsal of the entry path "
+                         "on a box with fewer GPUs than ranks); without it such a run exits with status 6, and a run whose "
+                         "sharded config-5 leg did not execute with status 7")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: dry run of the entry path over gloo (tests); not a measurement")
     args = ap.parse_args()
@@ -215,12 +226,14 @@ def main():
     dist, control_plane = None, None
     if world > 1 or (args.gather and "RANK" in os.environ):
         dist, control_plane = bench_dist.init_process_group(
-            "gloo" if dry else "nccl", device, force_gloo=bool(os.environ.get("MCTQ_BENCH_FORCE_GLOO")))
+            "gloo" if dry else "nccl", device, force_gloo=bool(os.environ.get("MCTQ_BENCH_FORCE_GLOO")),
+            allow_gloo=args.allow_gloo)
     ranks_seen = dist.get_world_size() if dist is not None else 1
-    if ranks_seen != args.gpus and control_plane == "nccl":
-        # a scaling line must not claim GPUs the process group did not see (one rank per GPU over RCCL)
-        print(f"[bench] --gpus {args.gpus} but the RCCL process group has {ranks_seen} ranks", file=sys.stderr, flush=True)
-        dist.destroy_process_group()
+    if ranks_seen != args.gpus:
+        # a scaling line must not claim GPUs the process group did not see (one rank per GPU), whatever the control plane
+        print(f"[bench] --gpus {args.gpus} but the process group has {ranks_seen} ranks", file=sys.stderr, flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
         sys.exit(5)
 
     import mct_quantizers_amd as mq
@@ -528,6 +541,24 @@ def main():
     else:
         y_last = ys[last_slot]
 
+    # ---- every rank: its own last timed output against the REFERENCE's digest of this configuration ------------
+    # (tests/golden/full_sha.json: SHA-256 of the reference's float32 output on the same portable input).  The verdict
+    # of every rank travels to rank 0 (ranks_parity_ok); one False fails the job.  None = no digest for this workload
+    # (16-bit storage, model workloads).
+    own_parity = None
+    want_sha = None if (model_mode or args.dtype != "f32") else bench_dist.golden_output_digest(args.config, wl.shape, args.batch)
+    if want_sha is not None:
+        if isinstance(y_last, (list, tuple)):
+            own_parity = all(bench_dist.sha256_of(y) == want_sha for y in y_last[:2]) and \
+                all(bool(torch.equal(y, y_last[0])) for y in y_last[2:])
+        else:
+            own_parity = bench_dist.sha256_of(y_last) == want_sha
+    result["ranks_parity_ok"] = bench_dist.gather_flags(dist, own_parity, control_plane, device)
+    result["ranks_parity_is"] = ("per rank: SHA-256 of the output of its LAST timed step == the reference's digest "
+                                 "(tests/golden/full_sha.json); null = no digest recorded for this workload / storage type")
+    if any(v is False for v in result["ranks_parity_ok"]):
+        result["parity_error"] = f"ranks_parity_ok = {result['ranks_parity_ok']}: a rank's output differs from the reference's digest"
+
     # Extra (outside the judged region): the same K independent steps issued round-robin on two HIP streams,
     # which overlaps one kernel's tail with the next one's ramp.  Whole-job rate only; per-kernel durations
     # overlap, so this is not a roofline figure.
@@ -627,19 +658,27 @@ def main():
             result["batched_16x4096"] = {"error": repr(e)[:300]}
 
     # ---- N > 1 (or --gather under torchrun): config 5 sharded by dim 0 + ONE all-gather -----------------
-    if dist is not None and (control_plane == "nccl" or dry) and (args.gather or world > 1):
-        with bench_dist.Watchdog(120.0, rank, lambda: json.dumps(result)):
+    sharded_failed = None
+    if dist is not None and (args.gather or world > 1):
+        with bench_dist.Watchdog(300.0 if control_plane == "gloo" and not dry else 120.0, rank, lambda: json.dumps(result)):
             try:
                 kw = dict(rows=64, cols=128, reps=3, gather_reps=2) if dry else {}
-                leg = bench_dist.sharded_cfg5_leg(dist, rank, world, device, **kw)
+                leg = bench_dist.sharded_cfg5_leg(dist, rank, world, device, control=control_plane, **kw)
                 result["sharded_cfg5"] = leg
                 result["sharded_cfg5_compute_elems_per_s"] = leg["compute_elems_per_s"]
                 result["sharded_cfg5_compute_plus_allgather_elems_per_s"] = leg["compute_plus_allgather_elems_per_s"]
                 result["sharded_cfg5_allgather_gbs_per_link"] = leg["allgather_gbs_per_link"]
-            except Exception as e:  # noqa: BLE001  (extras only)
+                bad = [k for k in ("gathered_rows_match_local",) if leg.get(k) is not True]
+                if any(v is False for v in leg["ranks_shard_digest_ok"]) or leg.get("gathered_equals_reference_digest") is False:
+                    bad.append("digest")
+                if bad:
+                    result["parity_error"] = f"sharded config 5: {bad} -- ranks_shard_digest_ok = {leg['ranks_shard_digest_ok']}"
+            except Exception as e:  # noqa: BLE001
                 result["sharded_cfg5"] = {"error": repr(e)[:300]}
+                sharded_failed = repr(e)[:300]
 
-    if rank == 0 and world == 1 and not args.no_cpu and not dry and model_mode:
+    # CPU baseline: on rank 0, at every N (the other ranks are done; they leave through destroy_process_group below)
+    if rank == 0 and not args.no_cpu and not dry and model_mode:
         # CPU baseline of the model workloads: ATen's CPU operator on every weight in turn, oracle-derived parameters
         from oracle import torch_cpu
         fs = [torch_cpu.prepare("WeightsSymmetricInferableQuantizer", kw) for _, kw in weights]
@@ -662,7 +701,7 @@ def main():
                                   "gpu_output_checked": f"all {len(weights)} outputs of the last timed step"}
         if not same:
             result["parity_error"] = "GPU output differs from the CPU oracle"
-    elif rank == 0 and world == 1 and not args.no_cpu and not dry:
+    elif rank == 0 and not args.no_cpu and not dry:
         from oracle import torch_cpu
         f = torch_cpu.prepare(wl.quantizer, wl.kwargs)
         x_cpu = torch.from_numpy(x_np).to(tdtype)          # the same rounding to the storage type as on the device
@@ -710,7 +749,13 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and result.get("parity_error"):
+        print(f"[bench] {result['parity_error']}", file=sys.stderr, flush=True)
         sys.exit(3)
+    if world > 1 and not dry and sharded_failed is not None and not args.allow_gloo:
+        # a scaling line whose config-5 + all-gather leg did not execute must not look like success
+        print(f"[bench] the sharded config-5 leg failed ({sharded_failed}) and --allow-gloo was not given: exiting with status "
+              f"{bench_dist.EXIT_NO_SHARDED_LEG}", file=sys.stderr, flush=True)
+        sys.exit(bench_dist.EXIT_NO_SHARDED_LEG)
 
 
 if __name__ == "__main__":

@@ -37,22 +37,38 @@ def self_launch(script: str, n: int, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def init_process_group(backend: str, device: torch.device, force_gloo: bool = False):
+EXIT_NO_RCCL = 6          # --gpus N > 1 without a working RCCL group and without --allow-gloo
+EXIT_NO_SHARDED_LEG = 7   # --gpus N > 1 whose sharded config-5 + all-gather leg did not run (or failed) without --allow-gloo
+
+
+def init_process_group(backend: str, device: torch.device, force_gloo: bool = False, allow_gloo: bool = False):
     """Returns (dist module, control_plane).  ``backend`` "nccl" is probed with one all-reduce (RCCL creates its
-    communicators lazily: fail here, not mid-run) and replaced by gloo for the CONTROL plane (barrier,
-    max-over-ranks) if that probe fails -- the hot path itself has no collective."""
+    communicators lazily: fail here, not mid-run).  If the probe fails the process EXITS with status EXIT_NO_RCCL: a
+    multi-GPU line must not be printed by a job that has no RCCL group (a SCALE run could otherwise come
+    back rc 0 with no collective in it).  ``allow_gloo`` (bench.py --allow-gloo: rehearsals of the N > 1 entry path on a
+    box with fewer GPUs than ranks) replaces RCCL by gloo for the CONTROL plane instead (barrier, max-over-ranks; the
+    sharded leg's gather is then staged through the host) and the line says so.  ``force_gloo`` makes the probe fail
+    (tests)."""
     import torch.distributed as dist
     control = backend
     if backend == "nccl":
         try:
             if force_gloo:
-                raise RuntimeError("forced")
+                raise RuntimeError("RCCL probe failure forced by MCTQ_BENCH_FORCE_GLOO")
             dist.init_process_group("nccl", device_id=device)
             probe = torch.zeros(1, device=device)
             dist.all_reduce(probe)
             torch.cuda.synchronize(device)
         except Exception as e:  # noqa: BLE001
-            print(f"[bench] RCCL unavailable ({e!r:.200}); barrier / max-over-ranks go over gloo", file=sys.stderr, flush=True)
+            if not allow_gloo:
+                print(f"[bench] RCCL unavailable ({e!r:.300}) and --allow-gloo not given: no multi-GPU line without an RCCL "
+                      f"group; exiting with status {EXIT_NO_RCCL}", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                sys.exit(EXIT_NO_RCCL)
+            print(f"[bench] RCCL unavailable ({e!r:.200}); --allow-gloo: barrier / max-over-ranks go over gloo", file=sys.stderr, flush=True)
             try:
                 dist.destroy_process_group()
             except Exception:  # noqa: BLE001
@@ -133,7 +149,7 @@ def max_over_ranks(values, dist, control: str, device: torch.device):
 
 
 def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: int = 8192, cols: int = 8192,
-                     reps: int = 60, gather_reps: int = 20) -> Dict:
+                     reps: int = 60, gather_reps: int = 20, control: Optional[str] = None) -> Dict:
     """BASELINE config 5: WeightsPOT 4-bit per-channel on rows x cols, sharded by dim 0 across the ranks
     (strong scaling: rank r quantizes rows [rows r / N, rows (r+1) / N)), then ONE all-gather (RCCL over xGMI on
     GPUs).  Returns compute-only and compute + all-gather rates; every rank derives the same thresholds from the
@@ -152,6 +168,13 @@ def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: in
         y = sq(xs[i % 3])
     t_comp = timed_region(lambda i: sq(xs[i % 3]), reps, device, dist) / reps
     y = sq(xs[0])
+    # this rank's shard against the REFERENCE's digest of the same row block (tests/golden/shard_sha.json)
+    shard_ok = shard_digest_check(y, rows, cols, world, rank)
+    staged = device.type == "cuda" and (control or dist.get_backend()) == "gloo"
+    if staged:
+        # rehearsal on fewer GPUs than ranks (--allow-gloo): gloo has no all-gather of device tensors, so the collective
+        # moves host copies of the shards; what is rehearsed is the entry path, the row blocks and the digests, not xGMI
+        y = y.cpu()
     # the 256 MiB result lives outside the timed gather.  The collective is issued at world size 1 too (a group of one rank:
     # RCCL copies y into the result), so that all_gather_into_tensor has run on HIP tensors before any multi-GPU run
     buffers = sq.gather_buffers(y)
@@ -169,6 +192,7 @@ def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: in
           and bool(torch.equal(full[start:stop], y)))
     recv_gbs = recv / t_gather / 1e9 if t_gather > 0 else None
     digest = full_digest_check(full, rows, cols) if rank == 0 else None
+    shards_ok = gather_flags(dist, shard_ok, control or dist.get_backend(), device)
     return {
         "workload": f"cfg5 WeightsPOT per-channel(axis0) 4b {rows}x{cols}, dim-0 shards",
         "scaling": "strong", "rows_per_rank": stop - start, "ranks": world,
@@ -177,6 +201,7 @@ def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: in
         "allgather_recv_gbs_per_rank": recv_gbs,
         "allgather_backend": dist.get_backend() if dist is not None else None,
         "allgather_device": str(full.device) if full is not None else None,
+        "allgather_staged_through_host": staged,
         # a group of one rank moves nothing between GPUs: the figure is RCCL's local copy of the 256 MiB result
         "allgather_local_copy_gbs": (stop - start) * cols * 4 / t_gather / 1e9 if world == 1 and t_gather > 0 else None,
         # xGMI is point to point: a rank receives from its world - 1 peers over world - 1 links at once
@@ -185,26 +210,76 @@ def sharded_cfg5_leg(dist, rank: int, world: int, device: torch.device, rows: in
         "compute_plus_allgather_elems_per_s": rows * cols / (t_comp + t_gather),
         "gathered_rows_match_local": ok,
         "gathered_equals_reference_digest": digest,
+        # every rank's own shard == the reference's output rows of that block (None: no digest recorded for this shape)
+        "ranks_shard_digest_ok": shards_ok,
     }
+
+
+def sha256_of(t: torch.Tensor) -> str:
+    """SHA-256 of a tensor's bytes in its dense order (16-bit types as their bit patterns)."""
+    import hashlib
+    t = t.detach().cpu().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        t = t.view(torch.int16)
+    return hashlib.sha256(t.numpy().tobytes()).hexdigest()
+
+
+def _golden(name: str) -> dict:
+    import json
+    # MCTQ_BENCH_GOLDEN_DIR: another directory of digests (tests doctor one to see a mismatch fail the job)
+    root = os.environ.get("MCTQ_BENCH_GOLDEN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    path = os.path.join(root, name)
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
+
+def golden_output_digest(config: str, shape, batch: int = 8) -> Optional[str]:
+    """The reference's SHA-256 of the float32 output of a BASELINE configuration on workloads.py's input
+    (tests/golden/full_sha.json, written by tools/gen_golden.py from the imported reference); None if not recorded."""
+    configs = _golden("full_sha.json").get("configs", {})
+    for key in ((f"cfg3_n{batch}", "cfg3") if config == "cfg3" else (config,)):
+        entry = configs.get(key)
+        if entry and list(entry.get("shape", [])) == list(shape):
+            return entry.get("y_sha256")
+    return None
+
+
+def shard_digest(rows: int, cols: int, world: int, rank: int) -> Optional[str]:
+    """The reference's SHA-256 of rank ``rank``'s row block of config 5 at world size ``world``
+    (tests/golden/shard_sha.json: the reference's FULL output cut into sharded.row_block's blocks)."""
+    rec = _golden("shard_sha.json").get("cfg5", {}).get(f"{rows}x{cols}", {}).get("shards", {}).get(str(world))
+    return rec[rank] if rec and rank < len(rec) else None
+
+
+def shard_digest_check(y_local: torch.Tensor, rows: int, cols: int, world: int, rank: int) -> Optional[bool]:
+    want = shard_digest(rows, cols, world, rank)
+    return None if want is None else sha256_of(y_local) == want
+
+
+def gather_flags(dist, flag: Optional[bool], control: Optional[str], device: torch.device):
+    """[flag of rank 0, flag of rank 1, ...] on every rank; a flag is True / False / None (nothing to compare with)."""
+    code = {True: 1, False: 0, None: -1}[flag]
+    if dist is None:
+        return [flag]
+    t = torch.tensor([code], dtype=torch.int32, device=device if control == "nccl" else "cpu")
+    got = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    return [{1: True, 0: False, -1: None}[int(v[0])] for v in got]
 
 
 def full_digest_check(full: torch.Tensor, rows: int, cols: int) -> Optional[bool]:
     """SHA-256 of the re-assembled tensor against the REFERENCE's digest of BASELINE config 5 (tests/golden/full_sha.json,
     written by tools/gen_golden.py from the reference's output on the same portable input); None when the size has no
     recorded digest (the dry run's small shape)."""
-    import hashlib
-    import json
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "full_sha.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
-    entry = rec.get("configs", {}).get("cfg5", {})
-    want = entry.get("y_sha256") if list(entry.get("shape", [])) == [rows, cols] else None
+    want = golden_output_digest("cfg5", [rows, cols])
+    if want is None:
+        want = _golden("shard_sha.json").get("cfg5", {}).get(f"{rows}x{cols}", {}).get("y_sha256")
     if want is None:
         return None
-    return hashlib.sha256(full.detach().cpu().contiguous().numpy().tobytes()).hexdigest() == want
+    return sha256_of(full) == want
 
 
 class Watchdog:

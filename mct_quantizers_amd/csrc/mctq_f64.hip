@@ -304,6 +304,7 @@ static int launch_lut64_steps(const Lut64Steps& op, const void* xv, float* y, in
   else { if (vec) MCTQ_L64S(uint64_t, true); else MCTQ_L64S(uint64_t, false); }
 #undef MCTQ_L64S
   g_note.shape = "lut64_steps_kernel"; g_note.op = "LutSteps64"; g_note.unroll = 4; g_note.nt = 1; g_note.in_bytes = 8; g_note.out_bytes = 4; ++g_note.count;
+  if (g_launch_log) log_launch();
   return check_launch("float64 LUT threshold-list launch");
 }
 

@@ -1250,11 +1250,17 @@ extern int g_unroll;
 // what the calling thread launched last (mctq_last_launch(): lets a benchmark tie its counters to a kernel variant)
 struct LaunchNote { const char* shape; const char* op; int unroll, nt, in_bytes, out_bytes; int64_t count; };
 extern thread_local LaunchNote g_note;
+// MCTQ_LAUNCH_LOG=<file> in the environment when the library is loaded: every launch VARIANT (the text of
+// mctq_last_launch()) is appended to that file the first time the process takes it -- the evidence the set of
+// instantiated kernels is pruned against (tools/launch_log_summary.py).  Off: one predictable branch per launch.
+extern int g_launch_log;
+void log_launch();
 template <class Op, class TI, class TO>
 inline void note(const char* shape, int unroll, int nt) {
   g_note.shape = shape; g_note.op = Op::kName; g_note.unroll = unroll; g_note.nt = nt;
   g_note.in_bytes = (int)sizeof(TI); g_note.out_bytes = (int)sizeof(TO);
   ++g_note.count;
+  if (g_launch_log) log_launch();
 }
 extern int g_rowsteps;       // short whole-step rows: 0 rows_kernel, 1 rowsteps_kernel, 2 (default) rowsteps_kernel when its grid is one round
 extern int g_heavy_unroll;   // 0 = automatic

@@ -1,6 +1,12 @@
 // mctq_misc.hip -- part of libmctq_hip.so: shared state, tuning hook, diagnostics.
 #include "mctq_kernels.hpp"
 
+#include <stdlib.h>
+
+#include <mutex>
+#include <set>
+#include <string>
+
 namespace mctq {
 
 thread_local char g_err[256] = "";
@@ -16,6 +22,12 @@ int g_ql_band = 0;
 int g_ql_stagger = 0;         // tiled consumer kernel: half of the waves copy after multiplying (experiment: no gain)
 int g_ql_rot = 0;            // tiled consumer kernel: blocks that share a weight tile start at different K offsets (experiment: no gain)
 int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)
+
+static const char* launch_log_path() {
+  const char* p = getenv("MCTQ_LAUNCH_LOG");
+  return (p && p[0]) ? p : nullptr;
+}
+int g_launch_log = launch_log_path() != nullptr;
 
 int fail_arg(const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -83,6 +95,27 @@ const char* mctq_last_launch(void) {
 }
 
 int64_t mctq_launch_count(void) { return g_note.count; }
+
+}  // extern "C"
+
+namespace mctq {
+// first use of a launch variant by this process -> one line in $MCTQ_LAUNCH_LOG (O_APPEND: several processes may share it)
+void log_launch() {
+  static std::mutex mu;
+  static std::set<std::string> seen;
+  const char* path = launch_log_path();
+  if (!path) return;
+  const std::string text = mctq_last_launch();
+  std::lock_guard<std::mutex> lock(mu);
+  if (!seen.insert(text).second) return;
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s\n", text.c_str());
+    fclose(f);
+  }
+}
+}  // namespace mctq
+
+extern "C" {
 
 #ifndef MCTQ_BUILD_ID
 #define MCTQ_BUILD_ID "unstamped"

@@ -24,6 +24,7 @@ template <bool A_U8>
 static void note_ql(const char* shape, int u = 0) {
   g_note.shape = shape; g_note.op = A_U8 ? "u8 x i8" : "i8 x i8"; g_note.unroll = u; g_note.nt = 0;
   g_note.in_bytes = 1; g_note.out_bytes = 4; ++g_note.count;
+  if (g_launch_log) log_launch();
 }
 extern int g_ql_stagger;                // tuning hook "ql_stagger": half of the tiled kernel's waves copy after multiplying (default off)
 extern int g_ql_rot;                    // tuning hook "ql_rot": K rotation between the blocks that share a weight tile (default off)

@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 KEYS = {"workload", "scaling", "rows_per_rank", "compute_ms", "compute_elems_per_s", "allgather_ms",
         "allgather_recv_bytes_per_rank", "allgather_recv_gbs_per_rank", "compute_plus_allgather_elems_per_s",
         "gathered_rows_match_local", "ranks", "allgather_gbs_per_link", "allgather_output", "allgather_backend",
-        "allgather_device", "allgather_local_copy_gbs", "gathered_equals_reference_digest"}
+        "allgather_device", "allgather_local_copy_gbs", "gathered_equals_reference_digest", "allgather_staged_through_host",
+        "ranks_shard_digest_ok"}
 
 
 def _free_port():
@@ -40,6 +41,10 @@ def _worker(rank, world, port, rows, q):
         leg = bench_dist.sharded_cfg5_leg(dist, rank, world, device, rows=rows, cols=128, reps=3, gather_reps=2)
         assert set(leg) == KEYS, set(leg) ^ KEYS
         assert leg["gathered_rows_match_local"] is True and leg["scaling"] == "strong"
+        # every rank's shard against the REFERENCE's digest of that row block (tests/golden/shard_sha.json), gathered
+        assert leg["ranks_shard_digest_ok"] == [True] * world and leg["allgather_staged_through_host"] is False
+        if rank == 0:
+            assert leg["gathered_equals_reference_digest"] is True
         per = -(-rows // world)
         assert leg["rows_per_rank"] == min(rows, (rank + 1) * per) - min(rows, rank * per)
         assert leg["allgather_recv_bytes_per_rank"] == (rows - leg["rows_per_rank"]) * 128 * 4
@@ -97,6 +102,9 @@ def test_plain_python_bench_gpus_2_launches_itself_and_emits_the_multi_rank_line
     assert len(out["per_rank_kernel_us"]) == 2
     leg = out["sharded_cfg5"]
     assert leg["gathered_rows_match_local"] is True and leg["ranks"] == 2
+    # self-verifying: per-rank digest of the last timed output (config 1 here) and of every rank's config-5 shard
+    assert out["ranks_parity_ok"] == [True, True] and "parity_error" not in out
+    assert leg["ranks_shard_digest_ok"] == [True, True] and leg["gathered_equals_reference_digest"] is True
     for key in ("sharded_cfg5_compute_elems_per_s", "sharded_cfg5_compute_plus_allgather_elems_per_s",
                 "sharded_cfg5_allgather_gbs_per_link"):
         assert out[key] and out[key] > 0
@@ -104,3 +112,65 @@ def test_plain_python_bench_gpus_2_launches_itself_and_emits_the_multi_rank_line
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--device", "cpu", "--config", "nope"],
                        cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_no_multi_gpu_line_without_rccl_unless_allowed():
+    """when the RCCL probe fails the rank EXITS with status 6 instead of continuing over gloo; only
+    --allow-gloo (allow_gloo=True) turns the failure into a gloo control plane.  The probe failure is forced the way the
+    GPU test forces it (MCTQ_BENCH_FORCE_GLOO -> force_gloo=True), so no GPU is needed to see both outcomes."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, bench_dist\n"
+            "d, c = bench_dist.init_process_group('nccl', torch.device('cpu'), force_gloo=True, allow_gloo=%s)\n"
+            "print('CONTROL', c, d.get_world_size()); d.destroy_process_group()\n")
+    env = _clean_env(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, "-c", code % "False"], cwd=repo, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 6 and "CONTROL" not in r.stdout and "--allow-gloo not given" in r.stderr, (r.returncode, r.stderr[-500:])
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, "-c", code % "True"], cwd=repo, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "CONTROL gloo 1" in r.stdout, (r.returncode, r.stderr[-500:])
+
+
+def test_a_rank_whose_output_differs_from_the_reference_digest_fails_the_job(tmp_path):
+    """the N > 1 line is self-verifying.  With a doctored digest for rank 1's config-5 shard the line
+    says ranks_shard_digest_ok == [True, False] and the job exits 3; with a doctored digest of the timed workload every
+    rank reports False (ranks_parity_ok) and the job exits 3 as well
+    (the launcher relays that as a non-zero status of its own)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(repo, "tests", "golden")
+    for which in ("shard", "full"):
+        d = tmp_path / which
+        d.mkdir()
+        for name in ("full_sha.json", "shard_sha.json"):
+            shutil.copy(os.path.join(gold, name), d / name)
+        if which == "shard":
+            doc = json.loads((d / "shard_sha.json").read_text())
+            doc["cfg5"]["64x128"]["shards"]["2"][1] = "0" * 64
+            (d / "shard_sha.json").write_text(json.dumps(doc))
+        else:
+            doc = json.loads((d / "full_sha.json").read_text())
+            doc["configs"]["cfg1"]["y_sha256"] = "f" * 64
+            (d / "full_sha.json").write_text(json.dumps(doc))
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--device", "cpu"],
+                           cwd=repo, env=_clean_env(MCTQ_BENCH_GOLDEN_DIR=str(d)), capture_output=True, text=True, timeout=600)
+        # rank 0 leaves with status 3; torch.distributed.run reports a failed child as its own status 1 and names the
+        # child's status in its error table
+        import re
+        assert r.returncode != 0 and re.search(r"exitcode\s*:\s*3\b", r.stderr), (which, r.returncode, r.stderr[-1500:])
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert "parity_error" in out
+        if which == "shard":
+            assert out["sharded_cfg5"]["ranks_shard_digest_ok"] == [True, False] and out["ranks_parity_ok"] == [True, True]
+        else:
+            assert out["ranks_parity_ok"] == [False, False] and out["sharded_cfg5"]["ranks_shard_digest_ok"] == [True, True]

@@ -73,8 +73,10 @@ def test_bench_multi_process_leg_runs_over_rccl_on_one_gpu(lib):
     # different buffer) and the re-assembled tensor is the reference's config-5 output
     assert leg["allgather_backend"] == "nccl" and leg["allgather_device"].startswith("cuda"), leg
     assert leg["allgather_ms"] > 0 and leg["allgather_local_copy_gbs"] > 100, leg
-    assert leg["gathered_equals_reference_digest"] is True
+    assert leg["gathered_equals_reference_digest"] is True and leg["allgather_staged_through_host"] is False
     assert d["ranks_seen"] == 1
+    # self-verifying line: the rank's last timed output and its (whole-tensor) shard against the reference's digests
+    assert d["ranks_parity_ok"] == [True] and leg["ranks_shard_digest_ok"] == [True] and "parity_error" not in d
 
 
 @pytest.mark.parametrize("world", [2, 8, 3])
@@ -99,27 +101,59 @@ def test_dim0_shards_reassemble_to_the_reference_digest_of_config_5(lib, world):
     assert covered == rows and h.hexdigest() == rec["y_sha256"]
 
 
-@pytest.mark.gpu
-def test_plain_python_bench_gpus_2_on_the_gpu_box():
-    """`python bench.py --gpus 2` as the driver launched BENCH in round 2 (no launcher, no RANK): the script starts
-    torch.distributed.run on itself and rank 0 prints ONE line.  The box has one GPU, so both ranks share it
-    (MCTQ_BENCH_WRAP_DEVICES) and the control plane is gloo (two RCCL ranks cannot share a device): everything of the
-    N > 1 path except the RCCL collectives themselves runs on real kernels."""
-    import json
-    import os
+def _bench_wrapped(n, *flags, env_extra=None, timeout=1500):
+    """`python bench.py --gpus n` with no launcher and no RANK, all ranks sharing the box's one GPU."""
     import subprocess
     import sys
     from conftest import REPO
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MCTQ_BENCH_WRAP_DEVICES="1", MCTQ_BENCH_FORCE_GLOO="1")
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-seconds", "0.1",
-                        "--evidence-launches", "0"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    env.update(MCTQ_BENCH_WRAP_DEVICES="1", **(env_extra or {}))
+    return subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "20", "--warmup", "5", "--prewarm-seconds", "0.1",
+                           "--evidence-launches", "0", *flags], cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _check_self_verifying_line(d, n):
+    assert d["n_gpus"] == n and d["ranks_seen"] == n and d["config"]["ranks_seen"] == n and d["config"]["control_plane"] == "gloo"
+    assert len(d["per_rank_kernel_us"]) == n and all(v > 5 for v in d["per_rank_kernel_us"])
+    # (n processes time-slicing ONE GPU: the rate is not a measurement, only sanity)
+    assert d["value"] > 1e9 and d["scaling"] == "weak" and "rows_kernel" in d["roofline"]["kernel"]
+    # every rank compared its own last timed output with the reference's config-2 digest ...
+    assert d["ranks_parity_ok"] == [True] * n and "parity_error" not in d
+    # ... and its own config-5 shard with the reference's digest of that row block; rank 0 the re-assembled tensor
+    leg = d["sharded_cfg5"]
+    assert "error" not in leg, leg
+    assert leg["ranks"] == n and leg["ranks_shard_digest_ok"] == [True] * n and leg["rows_per_rank"] == 8192 // n
+    assert leg["gathered_rows_match_local"] is True and leg["gathered_equals_reference_digest"] is True
+    assert leg["allgather_staged_through_host"] is True and leg["allgather_backend"] == "gloo"
+    # rank 0 ran the CPU leg after the timed region at N > 1 too
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 1e7 and cb["gpu_output_bit_equal"] is True
+
+
+def test_plain_python_bench_gpus_2_on_the_gpu_box():
+    """`python bench.py --gpus 2` as the driver launched BENCH in round 2 (no launcher, no RANK): the script starts
+    torch.distributed.run on itself and rank 0 prints ONE line.  The box has one GPU, so both ranks share it
+    (MCTQ_BENCH_WRAP_DEVICES); two RCCL ranks cannot share a device, so WITHOUT --allow-gloo the job must refuse to print a
+    line (status 6 in the rank, non-zero from the launcher), and WITH it everything of the N > 1 path except the RCCL
+    collectives themselves runs on real kernels: gloo control plane, per-rank digests, host-staged gather, CPU leg."""
+    import re
+    r = _bench_wrapped(2, "--cpu-seconds", "2", env_extra={"MCTQ_BENCH_FORCE_GLOO": "1"})
+    assert r.returncode != 0 and re.search(r"exitcode\s*:\s*6\b", r.stderr), (r.returncode, r.stderr[-2000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-500:]
+    r = _bench_wrapped(2, "--cpu-seconds", "2", "--allow-gloo", env_extra={"MCTQ_BENCH_FORCE_GLOO": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["control_plane"] == "gloo"
-    assert len(d["per_rank_kernel_us"]) == 2 and all(v > 5 for v in d["per_rank_kernel_us"])
-    # (two processes time-slicing ONE GPU: the rate is not a measurement, only sanity)
-    assert d["value"] > 1e9 and d["scaling"] == "weak" and "rows_kernel" in d["roofline"]["kernel"]
-    assert d["ranks_seen"] == 2
+    _check_self_verifying_line(json.loads(lines[0]), 2)
+
+
+def test_eight_ranks_rehearsed_on_the_one_gpu():
+    """the command the driver's SCALE run issues, `python bench.py --gpus 8`, with the eight ranks
+    wrapped onto the one GPU of the box (RCCL's own probe fails here -- eight ranks, one device -- so --allow-gloo): the
+    line carries ranks_parity_ok / ranks_shard_digest_ok for all eight ranks, 1024-row shards re-assembling to the
+    reference's digest, and rank 0's cpu_baseline."""
+    r = _bench_wrapped(8, "--cpu-seconds", "2", "--allow-gloo")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_self_verifying_line(json.loads(lines[0]), 8)

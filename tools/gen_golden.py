@@ -685,6 +685,31 @@ def gen_extra_sha():
         json.dump(doc, f, indent=1)
 
 
+def gen_shard_sha():
+    """Per-rank digests of BASELINE config 5 sharded by dim 0: the REFERENCE quantizes the whole tensor,
+    its output is cut into the contiguous row blocks of every world size 1..8 (block = ceil(rows / world), the rule of
+    mct_quantizers_amd/sharded.py:row_block, restated here so that the package under test is not imported) and each
+    block is hashed.  bench.py's N > 1 line checks every rank's shard against these (bench_dist.shard_digest).  Also the
+    small shapes of the CPU dry run / gloo tests."""
+    out = {}
+    torch.set_num_threads(os.cpu_count() or 1)
+    for rows, cols in ((8192, 8192), (64, 128), (32, 128), (13, 128)):
+        x = workloads.make_input("cfg5", shape=(rows, cols))
+        wl = workloads.make_workload("cfg5", x)
+        y = np.ascontiguousarray(getattr(refq, wl.quantizer)(**wl.kwargs)(torch.from_numpy(x)).numpy())
+        rec = dict(quantizer=wl.quantizer, y_sha256=hashlib.sha256(y.tobytes()).hexdigest(), shards={})
+        for world in range(1, 9):
+            per = -(-rows // world)
+            rec["shards"][str(world)] = [
+                hashlib.sha256(y[min(rows, r * per):min(rows, (r + 1) * per)].tobytes()).hexdigest() for r in range(world)]
+        out[f"{rows}x{cols}"] = rec
+        print(f"cfg5 {rows}x{cols}", rec["y_sha256"], flush=True)
+    meta = dict(reference="sony/mct_quantizers v%s" % ref.__version__, torch=torch.__version__, numpy=np.__version__,
+                generator="tools/gen_golden.py --shard-sha-only", rule="rank r owns rows [min(R, r*ceil(R/N)), min(R, (r+1)*ceil(R/N)))")
+    with open(os.path.join(OUT, "shard_sha.json"), "w") as f:
+        json.dump(dict(meta=meta, cfg5=out), f, indent=1)
+
+
 def gen_traced_wrapper_pickle():
     """An fx-traced REFERENCE wrapper whose weights quantizer is per-tensor: its graph holds
     torch.fake_quantize_per_tensor_affine with TENSOR scale / zero point (graph values), the saved-model form of
@@ -948,6 +973,8 @@ if __name__ == "__main__":
         gen_extra_sha()
     elif "--traced-wrapper-only" in sys.argv:
         gen_traced_wrapper_pickle()
+    elif "--shard-sha-only" in sys.argv:
+        gen_shard_sha()
     else:
         main()
         gen_half_cases()
@@ -956,3 +983,4 @@ if __name__ == "__main__":
         gen_f64_cases()
         gen_extra_sha()
         gen_traced_wrapper_pickle()
+        gen_shard_sha()

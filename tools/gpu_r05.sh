@@ -1,0 +1,67 @@
+#!/bin/bash
+# How round 5's logs under profiles/r05/ were produced on the MI355X box: `gpurun -- 'bash tools/gpu_r05.sh <section> ...'`.
+# Everything is written under gpurun_out/r05/ and copied to profiles/r05/ by hand.  rocprofv3 --pmc passes never share a
+# run with other trace domains; the profiled program follows `--` directly (python3 <script>).
+mkdir -p gpurun_out/r05; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05
+cd $R
+line() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1', '| us', round(r['kernel_us'],2), 'frac', round(r['frac'],3), 'wall', round(r['frac_wall'],3), r['kernel'])"; }
+
+hist() {          # per-dispatch durations of the judged launch vs ring slot / output address / gap / time
+  for v in "cfg2 f32 1.0" "cfg2 bf16 0.5" "cfg4 bf16 2.0"; do
+    set -- $v; name=$1_$2
+    rm -rf /tmp/tr_$name
+    timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$name -- python3 $R/tools/dispatch_hist.py run --config $1 --dtype $2 --launches 3000 --log /tmp/tr_$name.json > $O/dispatch_${name}_run.log 2>&1
+    timeout 300 python tools/dispatch_hist.py analyze --log /tmp/tr_$name.json --trace /tmp/tr_$name --out $O/${name}_dispatch --scale $3 > $O/dispatch_${name}_phases.log 2>&1
+  done
+}
+
+launchlog() {     # every launch variant the GPU suite, the bench configurations and the shape sweeps select
+  export MCTQ_LAUNCH_LOG=$O/launch_variants_raw.log; : > $MCTQ_LAUNCH_LOG
+  timeout 1800 python -m pytest tests -m gpu -q -x > $O/pytest_gpu_launchlog.log 2>&1; echo "rc=$?" >> $O/pytest_gpu_launchlog.log
+  cp $MCTQ_LAUNCH_LOG $O/launch_variants_suite.log
+  for c in cfg2 cfg4 cfg5 resnet50 linear16; do for dt in f32 bf16 f16; do
+    timeout 300 python bench.py --config $c --dtype $dt --steps 50 --warmup 5 --prewarm-seconds 0.2 --no-cpu --evidence-launches 0 > /dev/null 2>&1
+  done; done
+  for n in 1 8 64 256; do timeout 300 python bench.py --config cfg3 --batch $n --steps 50 --warmup 5 --prewarm-seconds 0.2 --no-cpu --evidence-launches 0 > /dev/null 2>&1; done
+  timeout 300 python bench.py --config resnet50 --e2e --steps 20 > /dev/null 2>&1
+  timeout 300 python bench.py --config resnet50 --e2e --e2e-lut --steps 20 > /dev/null 2>&1
+  timeout 600 python tools/sweep_shapes.py > $O/sweep_shapes.log 2>&1
+  timeout 600 python tools/short_rows_probe.py > /dev/null 2>&1
+  timeout 600 python tools/bench_consumer.py launchlog > /dev/null 2>&1
+  python __graft_entry__.py smoke > /dev/null 2>&1
+  sort -u $MCTQ_LAUNCH_LOG > $O/launch_variants_all.log
+  unset MCTQ_LAUNCH_LOG
+  wc -l $O/launch_variants_suite.log $O/launch_variants_all.log
+}
+
+suite() {         # the GPU suite + the judged lines at the current head
+  timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
+  tail -3 $O/pytest_gpu.log
+}
+
+bench() {         # judged line + side lines
+  python __graft_entry__.py smoke > $O/smoke.log 2>&1
+  timeout 300 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
+  timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_20.json
+  : > $O/bench_other_configs.jsonl; : > $O/bench_dtype.jsonl; : > $O/bench_cfg3.jsonl
+  for c in cfg4 cfg5 resnet50; do timeout 300 python bench.py --config $c --steps 300 2>/dev/null | tail -1 >> $O/bench_other_configs.jsonl; done
+  for dt in bf16 f16; do timeout 300 python bench.py --dtype $dt 2>/dev/null | tail -1 >> $O/bench_dtype.jsonl; done
+  timeout 300 python bench.py --dtype bf16 --config cfg5 --steps 300 2>/dev/null | tail -1 >> $O/bench_dtype.jsonl
+  timeout 300 python bench.py --dtype bf16 --config cfg4 --steps 300 2>/dev/null | tail -1 >> $O/bench_dtype.jsonl
+  for n in 1 8 64; do timeout 300 python bench.py --config cfg3 --batch $n --steps 1000 --warmup 100 2>/dev/null | tail -1 >> $O/bench_cfg3.jsonl; done
+  for f in bench_default.json bench_20.json; do line $f < $O/$f; done
+  while read -r l; do echo "$l" | line other; done < $O/bench_other_configs.jsonl
+  while read -r l; do echo "$l" | line dtype; done < $O/bench_dtype.jsonl
+}
+
+rehearse8() {     # the N = 8 entry path on the one GPU (8 ranks share it), RCCL refused -> needs --allow-gloo
+  ( time MCTQ_BENCH_WRAP_DEVICES=1 timeout 1200 python bench.py --gpus 8 --steps 20 --warmup 5 --allow-gloo ) > $O/bench_gpus8_wrapped.log 2>&1
+  echo "rc=$?" >> $O/bench_gpus8_wrapped.log
+  ( time MCTQ_BENCH_WRAP_DEVICES=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 ) > $O/bench_gpus2_wrapped_no_allow.log 2>&1
+  echo "rc=$? (expected non-zero: two ranks on one GPU cannot form an RCCL group, and --allow-gloo was not given)" >> $O/bench_gpus2_wrapped_no_allow.log
+  tail -5 $O/bench_gpus8_wrapped.log | cut -c1-600
+}
+
+for s in "$@"; do echo "=== $s"; $s; done
