@@ -31,7 +31,8 @@ Protocol
   * per-launch evidence (after the timed region, outside it): >= 50 launches with an event between every two;
     median / mean / p10 / p90 of the per-launch periods are reported under ``roofline.per_launch``.
   * ``roofline.traffic`` is emitted only when profiles/pmc_traffic.json holds counters taken on the SAME kernel
-    variant this run launched (``mctq_last_launch()``); otherwise null with the reason.
+    variant (``mctq_last_launch()``) of the SAME library build (``mctq_build_id()``) this run launched; otherwise null
+    with the reason (``traffic_build_id_mismatch``).
   * the parity check compares the output of the LAST timed step with the CPU oracle.
   * at N = 1 the default run appends ``batched_16x4096``: the same tensor 16 times in one batched launch, measured
     after the judged region with the same event protocol (``--no-batched-extra`` skips it).
@@ -348,6 +349,7 @@ def main():
         step(i)
     dev_sync()
     kernel_variant = "aten cpu operator (dry run)" if dry else native.last_launch()
+    build_id = None if dry else native.load().mctq_build_id().decode()
     sync_method = bench_dist.calibrate_sync(step, device) if graph_ok_for_calibration(args) else "torch.cuda.synchronize()"
 
     graph = None
@@ -432,6 +434,7 @@ def main():
                               if stream_on else "eager (one holder / quantizer call per batch)"),
                    "steps_per_launch": per_launch, "streams": args.streams,
                    "binding": "none (dry run)" if dry else ("compiled" if native.fast() is not None else "ctypes"),
+                   "library_build_id": build_id,
                    "prewarm_s": round(prewarm_s, 3), "prewarm_steps": n_pre,
                    "parallelism": f"replicated x{world} (weak, no collective)",
                    "control_plane": control_plane, "ranks_seen": ranks_seen,
@@ -507,28 +510,15 @@ def main():
 
     # ---- measured HBM traffic per launch (rocprofv3 PMC passes committed under profiles/) ----------------
     if not dry:
-        try:
-            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-                key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
-                if args.batched and not model_mode:
-                    key = f"{key}_batched{tensors}"
-                if stream_on:
-                    key = f"{key}_stream{per_launch}"
-                if args.dtype != "f32":
-                    key = f"{key}_{args.dtype}"
-                rec = json.load(f).get(key)
-            result["roofline"]["traffic_key"] = key
-            if rec is None:
-                result["roofline"]["traffic_source"] = f"no PMC record {key!r} in profiles/pmc_traffic.json"
-            elif rec.get("variant") != kernel_variant:
-                result["roofline"]["traffic_source"] = (f"stale: profiles/pmc_traffic.json was taken on {rec.get('variant')!r}, "
-                                                        f"this run launched {kernel_variant!r}")
-            else:
-                result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = (f"profiles/pmc_traffic.json: {rec['variant']} at git {rec.get('git_head', '?')} "
-                                                        f"(FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
-        except OSError:
-            result["roofline"]["traffic_source"] = "profiles/pmc_traffic.json missing"
+        key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
+        if args.batched and not model_mode:
+            key = f"{key}_batched{tensors}"
+        if stream_on:
+            key = f"{key}_stream{per_launch}"
+        if args.dtype != "f32":
+            key = f"{key}_{args.dtype}"
+        result["roofline"].update(bench_dist.traffic_fields(os.path.join(REPO, "profiles", "pmc_traffic.json"), key,
+                                                            kernel_variant, build_id))
 
     # ---- the last timed step's output, kept for the parity check before anything overwrites the ring ----------
     last_slot = (n_launch - 1) % ring

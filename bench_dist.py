@@ -282,6 +282,39 @@ def full_digest_check(full: torch.Tensor, rows: int, cols: int) -> Optional[bool
     return sha256_of(full) == want
 
 
+def traffic_fields(pmc_path: str, key: str, kernel_variant: str, build_id: Optional[str]) -> Dict:
+    """The ``roofline.traffic*`` fields of a bench line: measured HBM bytes per launch from the committed PMC passes
+    (profiles/pmc_traffic.json, tools/gpu_pmc_traffic.sh + tools/pmc_summarize.py).  The number is emitted only when the
+    record was taken on the SAME kernel variant (``mctq_last_launch()``) of the SAME library build (``mctq_build_id()``:
+    the content hash of every kernel source, header and compiler flag) as the run that prints the line; otherwise
+    ``traffic`` stays null and the line says why (``traffic_build_id_mismatch``: counters of another build are not this
+    build's traffic)."""
+    import json
+    out: Dict = {"traffic": None, "traffic_key": key}
+    try:
+        with open(pmc_path) as f:
+            rec = json.load(f).get(key)
+    except OSError:
+        out["traffic_source"] = "profiles/pmc_traffic.json missing"
+        return out
+    if rec is None:
+        out["traffic_source"] = f"no PMC record {key!r} in profiles/pmc_traffic.json"
+    elif rec.get("variant") != kernel_variant:
+        out["traffic_source"] = (f"stale: profiles/pmc_traffic.json was taken on {rec.get('variant')!r}, "
+                                 f"this run launched {kernel_variant!r}")
+    elif not build_id or rec.get("build_id") != build_id:
+        out["traffic_build_id_mismatch"] = True
+        out["traffic_recorded_for_another_build"] = rec.get("hbm_bytes_per_launch")
+        out["traffic_source"] = (f"profiles/pmc_traffic.json holds counters of library build {rec.get('build_id', 'unrecorded')!r} "
+                                 f"(git {rec.get('git_head', '?')}), this run loaded build {build_id!r}: not emitted")
+    else:
+        out["traffic"] = rec["hbm_bytes_per_launch"]
+        out["traffic_build_id_mismatch"] = False
+        out["traffic_source"] = (f"profiles/pmc_traffic.json: {rec['variant']} of library build {build_id} at git "
+                                 f"{rec.get('git_head', '?')} (FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
+    return out
+
+
 class Watchdog:
     """A stuck collective must not cost the main result -- but it must not look like success either: prints the
     line it was given and exits with status 4."""

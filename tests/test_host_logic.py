@@ -516,3 +516,27 @@ def test_dotted_module_paths_of_the_reference_resolve():
     assert m.common.get_quantizers.get_inferable_quantizer_class is m.get_inferable_quantizer_class
     with pytest.raises(AttributeError):
         m.pytorch.no_such_module
+
+
+def test_bench_emits_measured_traffic_only_for_the_build_the_counters_were_taken_on(tmp_path):
+    """VERDICT r04 #7: roofline.traffic is tied to the library's build id, not to the kernel variant's name alone."""
+    import json
+    import bench_dist
+    rec = {"cfg2": {"variant": "rows_kernel<AffineOp,in4B,out4B,U=4,NT=1>", "build_id": "0123456789abcdef", "git_head": "abc",
+                    "hbm_bytes_per_launch": 134539156.0}}
+    path = tmp_path / "pmc_traffic.json"
+    path.write_text(json.dumps(rec))
+    v = rec["cfg2"]["variant"]
+    ok = bench_dist.traffic_fields(str(path), "cfg2", v, "0123456789abcdef")
+    assert ok["traffic"] == 134539156.0 and ok["traffic_build_id_mismatch"] is False
+    other = bench_dist.traffic_fields(str(path), "cfg2", v, "fedcba9876543210")            # same variant, another build
+    assert other["traffic"] is None and other["traffic_build_id_mismatch"] is True
+    assert other["traffic_recorded_for_another_build"] == 134539156.0 and "0123456789abcdef" in other["traffic_source"]
+    rec["cfg2"].pop("build_id")                                                             # a record from before build ids
+    path.write_text(json.dumps(rec))
+    old = bench_dist.traffic_fields(str(path), "cfg2", v, "0123456789abcdef")
+    assert old["traffic"] is None and old["traffic_build_id_mismatch"] is True
+    stale = bench_dist.traffic_fields(str(path), "cfg2", "rows_kernel<AffineOp,in4B,out4B,U=8,NT=1>", "0123456789abcdef")
+    assert stale["traffic"] is None and "stale" in stale["traffic_source"] and "traffic_build_id_mismatch" not in stale
+    assert bench_dist.traffic_fields(str(path), "cfg9", v, "x")["traffic"] is None
+    assert bench_dist.traffic_fields(str(tmp_path / "none.json"), "cfg2", v, "x")["traffic_source"].endswith("missing")

@@ -3,11 +3,12 @@
 profiles/pmc_traffic.json and profiles/r03/: per config the kernel VARIANT (mctq_last_launch, taken from the JSON line
 of the same profiled bench run), rocprof's kernel symbol, the average FETCH_SIZE / WRITE_SIZE per dispatch, the gfx950
 correction (FETCH_SIZE x 2 for wide coalesced reads, guide MI355X_MICROARCH.md "HBM"), and the git head they were
-taken at.  bench.py emits roofline.traffic only when its own variant string equals the recorded one."""
+taken at and the library build (mctq_build_id) they were taken on.  bench.py emits roofline.traffic only when its own variant
+string AND its library's build id equal the recorded ones."""
 import csv, json, os, shutil, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "pmc")
-DST = os.path.join(REPO, "profiles", os.environ.get("MCTQ_ROUND", "r04"))
+DST = os.path.join(REPO, "profiles", os.environ.get("MCTQ_ROUND", "r05"))
 os.makedirs(DST, exist_ok=True)
 head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
 
@@ -46,7 +47,9 @@ for cfg in sorted(os.listdir(SRC)):
     rows = list(csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))))
     stats = next((r for r in rows if r["Name"] == kern), rows[0])      # the judged kernel's row of the stats pass
     key = line.get("roofline", {}).get("traffic_key", cfg)       # the key bench.py will look its own run up under
-    out[key] = {"variant": variant, "kernel": kern, "git_head": head, "profiled_as": cfg,
+    bid = line.get("config", {}).get("library_build_id")
+    assert bid and bid == line_w.get("config", {}).get("library_build_id"), (cfg, bid)
+    out[key] = {"variant": variant, "kernel": kern, "git_head": head, "build_id": bid, "profiled_as": cfg,
                 "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
                 "correction": "gfx950: FETCH_SIZE reports 1/2 of wide (16 B/lane) streaming reads -> doubled (guide MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg,
