@@ -574,6 +574,15 @@ PyTypeObject LutPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 //      watch = (dict, ((name, object, version), ...)): dict[name] must still BE `object` and, for version >= 0, that
 //      tensor's in-place version counter must still equal `version` -- how the plan notices that a quantizer's public
 //      parameters were replaced or edited in place since it was built.
+//      Every launch bumps the version counter of every output tensor (the kernel rewrites it in place behind autograd's
+//      back otherwise: a quantized weight saved for a backward and overwritten by a later forward must raise "modified by
+//      an inplace operation", as any in-place op would).
+//      BatchPlan(items, True) = VERSIONED REUSE ("quantize once, not per forward"; the reference's
+//      enable_reuse_quantizer idea, base_pytorch_inferable_quantizer.py:34-49, made safe): a call whose inputs are what
+//      the last launch read -- same device pointer, same in-place version counter, same dtype / sizes of every x, outputs
+//      not written by anybody else since, parameters unchanged (watch) -- issues NO launch and returns None; any change
+//      relaunches the whole plan.  (A write through `x.data` does not move x's version counter: plan.invalidate() forces
+//      the next call to launch.)  Never skipped while the stream is being captured.
 struct BatchWatch { PyObject* dict; PyObject* name; PyObject* obj; int64_t version; };
 
 struct BatchPlan {
@@ -596,7 +605,20 @@ struct BatchPlan {
   at::Tensor* lut_dev_table;
   bool uploaded;
   c10::DeviceIndex device;
+  bool versioned;                          // skip the launch when nothing changed since the last one
+  bool fresh;                              // the outputs hold the quantization of the inputs as recorded below
+  std::vector<uint32_t>* seen;             // per item (affine items first, then LUT items): x version, y version after the launch
+  int64_t launches, skips;
 };
+
+// in-place version counter of a tensor; inference tensors have none (they are never skipped over: see `trackable`)
+inline uint32_t version_of(const at::Tensor& t) { return t.is_inference() ? 0u : (uint32_t)t._version(); }
+
+inline bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &status) != hipSuccess) { (void)hipGetLastError(); return true; }    // unknown: do not skip
+  return status != hipStreamCaptureStatusNone;
+}
 
 bool batchplan_upload_lut(BatchPlan* p) {
   const int64_t need = mctq_lutt_batch_pack(p->lut_items->data(), (int32_t)p->lut_items->size(), nullptr, 0);
@@ -641,11 +663,14 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
   }
   const size_t n = p->items->size();
   bool dirty = !p->uploaded;
+  bool changed = !p->versioned || !p->fresh;        // versioned reuse: did anything the last launch read or wrote move on?
+  uint32_t* seen = p->seen->data();
   for (size_t i = 0; i < n; ++i) {
     const at::Tensor& x = THPVariable_Unpack((*p->refs)[4 * i]);
     const at::Tensor& y = THPVariable_Unpack((*p->refs)[4 * i + 1]);
     const at::Tensor& sc = THPVariable_Unpack((*p->refs)[4 * i + 2]);
     mctq_fq_item& d = (*p->items)[i];
+    if (!changed && (x.is_inference() || version_of(x) != seen[2 * i] || version_of(y) != seen[2 * i + 1])) changed = true;
     const std::vector<int64_t>& sz = (*p->sizes)[i];
     if (x.sizes() != c10::IntArrayRef(sz) || y.sizes() != x.sizes() || !x.is_cuda() || !y.is_cuda() ||
         x.device().index() != p->device || y.device().index() != p->device ||
@@ -682,6 +707,7 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
     const at::Tensor& y = THPVariable_Unpack((*p->lut_refs)[4 * i + 1]);
     const at::Tensor& tb = THPVariable_Unpack((*p->lut_refs)[4 * i + 3]);
     mctq_lut_item& d = (*p->lut_items)[i];
+    if (!changed && (x.is_inference() || version_of(x) != seen[2 * (n + i)] || version_of(y) != seen[2 * (n + i) + 1])) changed = true;
     if (x.sizes() != c10::IntArrayRef((*p->lut_sizes)[i]) || y.sizes() != x.sizes() || !x.is_cuda() || !y.is_cuda() ||
         x.device().index() != p->device || y.device().index() != p->device || !x.is_contiguous() || !y.is_contiguous() ||
         dtype_code(x.scalar_type()) != d.dtype || y.scalar_type() != c10::ScalarType::Float ||
@@ -705,7 +731,13 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
   }
   if (n > 0 || nl > 0) {
     DeviceScope scope(p->device);
-    void* stream = (void*)c10::hip::getCurrentHIPStream(p->device).stream();
+    hipStream_t st = c10::hip::getCurrentHIPStream(p->device).stream();
+    if (p->versioned && !changed && !dirty && !lut_dirty && !stream_is_capturing(st)) {
+      ++p->skips;                                    // the outputs ARE the quantization of these inputs: nothing to launch
+      Py_RETURN_NONE;
+    }
+    void* stream = (void*)st;
+    p->fresh = false;
     if (n > 0) {
       if (dirty && !batchplan_upload(p)) return nullptr;
       const int rc = mctq_fq_batch_run(p->host_table->data(), p->dev_table->const_data_ptr(), stream);
@@ -717,6 +749,16 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
       if (rc) return raise_rc(rc, "mctq_lutt_batch_run");
     }
     p->uploaded = true;
+    ++p->launches;
+    // the kernels rewrote every output in place: say so to autograd, and remember what this launch read and wrote
+    for (size_t i = 0; i < n + nl; ++i) {
+      PyObject* const* r = i < n ? &(*p->refs)[4 * i] : &(*p->lut_refs)[4 * (i - n)];
+      const at::Tensor& y = THPVariable_Unpack(r[1]);
+      if (!y.is_inference()) y.unsafeGetTensorImpl()->bump_version();
+      seen[2 * i] = version_of(THPVariable_Unpack(r[0]));
+      seen[2 * i + 1] = version_of(y);
+    }
+    p->fresh = true;
   }
   Py_RETURN_NONE;
   END_HANDLE_TH_ERRORS
@@ -729,8 +771,24 @@ void batchplan_dealloc(PyObject* self) {
   if (p->lut_refs) for (PyObject* o : *p->lut_refs) Py_XDECREF(o);
   delete p->items; delete p->refs; delete p->sizes; delete p->axes; delete p->watch; delete p->host_table; delete p->dev_table;
   delete p->lut_items; delete p->lut_refs; delete p->lut_sizes; delete p->lut_axes; delete p->lut_host_table; delete p->lut_dev_table;
+  delete p->seen;
   Py_TYPE(self)->tp_free(self);
 }
+
+// plan.invalidate(): the next call launches whatever the version counters say (after a write the counters cannot see)
+PyObject* batchplan_invalidate(PyObject* self, PyObject*) {
+  ((BatchPlan*)self)->fresh = false;
+  Py_RETURN_NONE;
+}
+// plan.stats() -> (launches, skipped calls)
+PyObject* batchplan_stats(PyObject* self, PyObject*) {
+  BatchPlan* p = (BatchPlan*)self;
+  return Py_BuildValue("(LL)", (long long)p->launches, (long long)p->skips);
+}
+PyMethodDef batchplan_methods[] = {
+    {"invalidate", batchplan_invalidate, METH_NOARGS, nullptr},
+    {"stats", batchplan_stats, METH_NOARGS, nullptr},
+    {nullptr, nullptr, 0, nullptr}};
 
 // watch = (dict, ((name, object, version), ...)); returns an error text or nullptr
 const char* batchplan_add_watch(BatchPlan* p, PyObject* w) {
@@ -754,7 +812,9 @@ const char* batchplan_add_watch(BatchPlan* p, PyObject* w) {
 
 PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   HANDLE_TH_ERRORS
-  if (PyTuple_GET_SIZE(args) != 1) { PyErr_SetString(PyExc_TypeError, "BatchPlan(items)"); return nullptr; }
+  if (PyTuple_GET_SIZE(args) != 1 && PyTuple_GET_SIZE(args) != 2) { PyErr_SetString(PyExc_TypeError, "BatchPlan(items[, versioned])"); return nullptr; }
+  int versioned = 0;
+  if (PyTuple_GET_SIZE(args) == 2 && (versioned = PyObject_IsTrue(PyTuple_GET_ITEM(args, 1))) < 0) return nullptr;
   PyObject* seq = PySequence_Fast(PyTuple_GET_ITEM(args, 0), "BatchPlan expects a sequence of tuples");
   if (!seq) return nullptr;
   BatchPlan* p = (BatchPlan*)type->tp_alloc(type, 0);
@@ -768,6 +828,8 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   p->lut_host_table = new std::vector<uint8_t>(); p->lut_dev_table = new at::Tensor();
   p->uploaded = false;
   p->device = -1;
+  p->versioned = versioned != 0; p->fresh = false; p->launches = 0; p->skips = 0;
+  p->seen = new std::vector<uint32_t>();
   const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
   const char* err = nullptr;
   for (Py_ssize_t i = 0; i < n && !err; ++i) {
@@ -861,6 +923,7 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   }
   Py_DECREF(seq);
   if (err) { Py_DECREF(p); PyErr_Format(PyExc_TypeError, "BatchPlan: %s", err); return nullptr; }
+  p->seen->assign(2 * (p->items->size() + p->lut_items->size()), 0u);
   return (PyObject*)p;
   END_HANDLE_TH_ERRORS
 }
@@ -930,6 +993,7 @@ PyMODINIT_FUNC PyInit__mctq_torch(void) {
   BatchPlanType.tp_basicsize = sizeof(BatchPlan);
   BatchPlanType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL;
   BatchPlanType.tp_new = batchplan_new;
+  BatchPlanType.tp_methods = batchplan_methods;
   BatchPlanType.tp_dealloc = batchplan_dealloc;
   BatchPlanType.tp_call = PyVectorcall_Call;
   BatchPlanType.tp_vectorcall_offset = offsetof(BatchPlan, vectorcall);

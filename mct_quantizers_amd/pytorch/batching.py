@@ -17,7 +17,13 @@ previous forward's quantized weights across forwards in that mode.  The plan is 
 wrappers and quantizer parameters found then; in-place updates of the WEIGHTS are followed (that is the point), and so
 are replaced or edited quantizer parameters, ``model.half()`` / ``.to(device)`` and re-pointed storages: the plan
 re-checks its tensors and the quantizers' public attributes on every call and is rebuilt when something changed.
-Only adding / removing wrappers needs ``handle.refresh()``.  The launch is ONE grid per storage type whatever the
+Only adding / removing wrappers needs ``handle.refresh()``.  Every launch bumps the in-place version counter of the
+persistent outputs it rewrites, so autograd notices a quantized weight saved for a backward and overwritten by a later
+forward exactly as it notices any other in-place write.
+``versioned=True`` (``accelerate(model, reuse="versioned")``) adds plan-level versioned reuse: a forward whose weights are
+what the last launch read issues NO launch at all (the reference's ``enable_reuse_quantizer`` idea,
+base_pytorch_inferable_quantizer.py:34-49, without its staleness: an optimizer step, ``load_state_dict``, a ``.data``
+swap or an edited quantizer parameter relaunches the whole plan).  The launch is ONE grid per storage type whatever the
 number of weights (mctq_fq_batch_pack / mctq_fq_batch_run: the descriptors live in a small device table).
 A wrapper uses the tensor prepared for it only inside the model forward whose pre-hook has just filled it (generation
 counter, closed again by a forward hook): calling a sub-module directly, past the hook, falls back to that wrapper's
@@ -43,9 +49,14 @@ from mct_quantizers_amd.pytorch.containers import PytorchQuantizationWrapper
 class BatchedWeightQuantization:
     """Handle returned by ``batch_weight_quantization``; ``remove()`` restores per-layer quantization."""
 
-    def __init__(self, model: nn.Module, reuse_buffers: bool = False, auto: bool = False):
+    def __init__(self, model: nn.Module, reuse_buffers: bool = False, auto: bool = False, versioned: bool = False):
         self.model = model
-        self.reuse_buffers = reuse_buffers
+        self.reuse_buffers = reuse_buffers or versioned
+        # versioned reuse (SURVEY 8(f2), "quantize once, not per forward"): the pre-packed plan skips its launch while every
+        # planned weight is what the last launch read (device pointer, in-place version counter, dtype, sizes), its outputs
+        # were not written by anybody else and the quantizers' parameters are unchanged; any change relaunches the whole
+        # plan.  Writes through ``weight.data`` do not move a version counter: ``invalidate()`` after those.
+        self.versioned = versioned
         # auto: installed by ``accelerate`` / ``pytorch_load_quantized_model`` on a model nobody asked to batch -- it must
         # never change what a forward does except for the number of launches: weights that are not on a GPU, an
         # active trace or compile, or anything the pre-packed launch cannot take leave the per-layer calls in charge
@@ -158,7 +169,7 @@ class BatchedWeightQuantization:
             items.append((x, y, scales, zps, axis, qmin, qmax, self._watch(quantizer)))
             per_wrapper.setdefault(wrapper, {})[name] = y
         try:
-            plan = fast.BatchPlan(items)
+            plan = fast.BatchPlan(items, bool(self.__dict__.get("versioned")))
         except TypeError:
             return None                   # something the pre-packed launch cannot take: per-forward batching instead
         for wrapper, outs in per_wrapper.items():
@@ -170,6 +181,18 @@ class BatchedWeightQuantization:
         """Rebuild the pre-packed plan at the next forward.  Not needed after changing quantizer parameters or moving /
         casting the model (the plan notices and is rebuilt); needed after adding or removing wrappers."""
         self._drop_plan()
+
+    def invalidate(self):
+        """Versioned reuse: the next forward launches whatever the version counters say (call after writing weights
+        through ``.data`` or raw pointers, which no counter sees)."""
+        plan = self._plan
+        if plan is not None:
+            plan[0].invalidate()
+
+    def stats(self):
+        """(launches, skipped calls) of the current pre-packed plan; (0, 0) without one."""
+        plan = self._plan
+        return tuple(plan[0].stats()) if plan is not None else (0, 0)
 
     def _drop_plan(self):
         self._plan = None
@@ -258,9 +281,12 @@ class BatchedWeightQuantization:
         self._drop_plan()
 
 
-def batch_weight_quantization(model: nn.Module, reuse_buffers: bool = False, auto: bool = False) -> BatchedWeightQuantization:
+def batch_weight_quantization(model: nn.Module, reuse_buffers: bool = False, auto: bool = False,
+                              versioned: bool = False) -> BatchedWeightQuantization:
     """Install the batched weight re-quantization on ``model`` (a forward pre-hook on the given module).
     ``reuse_buffers``: see the module docstring (persistent output tensors + pre-packed launch).
+    ``versioned`` (implies ``reuse_buffers``): skip the launch of a forward whose weights are what the last launch read
+    (``BatchedWeightQuantization.versioned``).
     ``auto``: stand aside (per-layer calls, as without the hook) whenever the weights are not on a GPU or a trace /
     compile is running -- the mode ``accelerate`` and ``pytorch_load_quantized_model`` install."""
-    return BatchedWeightQuantization(model, reuse_buffers, auto)
+    return BatchedWeightQuantization(model, reuse_buffers, auto, versioned)

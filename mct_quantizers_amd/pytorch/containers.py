@@ -151,7 +151,7 @@ class PytorchQuantizationWrapper(nn.Module):
 
     def __getstate__(self):
         # tensors a batched launch prepared for one forward (pytorch/batching.py) are not part of the module's state
-        state = self.__dict__.copy()
+        state = super().__getstate__()            # nn.Module's own: leaves out what a .compile()d module cannot pickle
         state.pop("_prequantized_plan", None)
         state.pop("_prequantized_seen", None)
         return state
@@ -194,6 +194,20 @@ class PytorchQuantizationWrapper(nn.Module):
 
     def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
         return {name: quantizer(w) for name, w, quantizer in self.get_weights_vars()}
+
+
+def _is_own_call(qtype) -> bool:
+    """Is ``qtype.__call__`` the ``__call__`` one of this package's own per-tensor activation quantizers defines?"""
+    own = _OWN_CALLS.get("v")
+    if own is None:
+        from mct_quantizers_amd.pytorch.quantizers import affine
+        own = _OWN_CALLS["v"] = {c.__dict__["__call__"] for c in vars(affine).values()
+                                 if isinstance(c, type) and c.__module__ == affine.__name__ and "__call__" in c.__dict__}
+    call = getattr(qtype, "__call__", None)
+    return call in own
+
+
+_OWN_CALLS = {}
 
 
 class PytorchActivationQuantizationHolder(torch.nn.Module):
@@ -245,7 +259,10 @@ class PytorchActivationQuantizationHolder(torch.nn.Module):
         self.__dict__["_fast_key"] = (q, plan)    # what the C call was (or was not) built for: re-made when it changes
         ok = (type(self).forward in (PytorchActivationQuantizationHolder.forward, _BypassableHolder.forward)
               and type(self).__call__ is PytorchActivationQuantizationHolder.__call__
-              and hasattr(q, "_plan_attrs") and plan is not None and plan is not False)
+              and hasattr(q, "_plan_attrs") and plan is not None and plan is not False
+              # the C call goes to the plan directly: only when the quantizer's __call__ is one of this package's own (a
+              # user subclass that overrides __call__ must be called)
+              and _is_own_call(type(q)))
         if ok:
             from mct_quantizers_amd.hip import ops
             fast = ops._fast_mod()
@@ -257,7 +274,7 @@ class PytorchActivationQuantizationHolder(torch.nn.Module):
                                                               isinstance(self, _BypassableHolder))
 
     def __getstate__(self):
-        state = self.__dict__.copy()
+        state = super().__getstate__()            # nn.Module's own (drops _compiled_call_impl: a .compile()d holder pickles)
         state.pop("_fast_call", None)             # C object over this module's own dictionaries: rebuilt on first use
         state.pop("_fast_key", None)
         return state

@@ -167,6 +167,64 @@ def test_jit_trace_of_an_accelerated_model_records_the_reference_nodes():
 # GPU: launches counted
 # ---------------------------------------------------------------------------------------------------------------------
 
+def test_the_switch_set_to_zero_takes_the_hook_off_a_model_that_was_saved_with_it(tmp_path, monkeypatch):
+    """a model re-saved with the hook kept batching under MCTQ_AUTO_BATCH=0; the switch means the reference's
+    per-layer calls, so the loader removes the hook then."""
+    monkeypatch.setenv("TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD", "1")
+    net = mq.accelerate(_small_model())
+    assert mq.accelerated(net) is not None
+    path = tmp_path / "with_hook.pth"
+    torch.save(net, path)
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "1")
+    on = mq.pytorch_load_quantized_model(path)
+    assert mq.accelerated(on) is not None and len(on._forward_pre_hooks) == 1
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "0")
+    off = mq.pytorch_load_quantized_model(path)
+    assert mq.accelerated(off) is None and len(off._forward_pre_hooks) == 0 and len(off._forward_hooks) == 0
+    x = torch.randn(2, 3, 10, 10)
+    with torch.no_grad():
+        assert torch.equal(off(x), on(x))
+
+
+def test_accelerate_reuse_argument():
+    net = _small_model()
+    with pytest.raises(ValueError):
+        mq.accelerate(net, reuse="always")
+    mq.accelerate(net)
+    assert mq.accelerated(net).versioned is False
+    mq.accelerate(net, reuse="versioned")                    # re-installed in the versioned form
+    h = mq.accelerated(net)
+    assert h.versioned and h.reuse_buffers and h.auto and len(net._forward_pre_hooks) == 1
+    assert h.stats() == (0, 0)                               # no plan on the CPU: per-layer calls, as without the hook
+    x = torch.randn(2, 3, 10, 10)
+    with torch.no_grad():
+        assert torch.equal(net(x), _small_model()(x))
+    h.invalidate()                                           # harmless without a plan
+    mq.decelerate(net)
+
+
+def test_holder_pickles_after_compile_and_a_foreign_call_is_never_bypassed():
+    """the holder's __getstate__ goes through nn.Module's (a .compile()d holder pickles); the one-C-call
+    path is built only for quantizers whose __call__ is this package's own."""
+    import pickle
+    from mct_quantizers_amd.pytorch import containers
+    q = Q.ActivationUniformInferableQuantizer(8, [-1.0], [3.0])
+    h = mq.PytorchActivationQuantizationHolder(q)
+    h.compile()
+    h2 = pickle.loads(pickle.dumps(h))
+    x = torch.linspace(-2, 4, 50)
+    assert torch.equal(h2(x), q(x))
+    assert containers._is_own_call(type(q)) and containers._is_own_call(Q.ActivationPOTInferableQuantizer)
+
+    class Mine(Q.ActivationUniformInferableQuantizer):
+        def __call__(self, inputs):
+            return super().__call__(inputs) + 1.0
+    assert not containers._is_own_call(Mine)
+    hm = mq.PytorchActivationQuantizationHolder(Mine(8, [-1.0], [3.0]))
+    hm._make_fast_call()
+    assert hm.__dict__.get("_fast_call") is None and torch.equal(hm(x), q(x) + 1.0)
+
+
 @pytest.fixture
 def compiled_binding():
     """The launch counts below are those of the pre-packed plan, which lives in the compiled binding; with
@@ -182,6 +240,12 @@ def _logits_close(a, b):
     (profiles/r04/conv_determinism_probe.log) -- a last-bit difference flips a quantization step in a later holder now and
     then, a few logits move by a few tenths."""
     return float((a.float() - b.float()).norm() / b.float().norm()) < 0.05
+
+
+def _sig(*xs):
+    """AutoCapture's signature of positional CUDA arguments outside autocast (device index, autocast state, per argument
+    sizes / strides / dtype)."""
+    return (xs[0].device.index, None) + tuple((tuple(x.shape), tuple(x.stride()), x.dtype) for x in xs)
 
 
 def _forward_launches(model, x):
@@ -417,10 +481,10 @@ def test_auto_capture_replays_the_forward_and_follows_weights_shapes_and_modes(c
     extra = torch.nn.Parameter(torch.zeros(1, device="cuda"))
     model.register_parameter("extra", extra); cap.__dict__.pop("_params", None)
     model(x9); model(x9)
-    assert (((3, 3, 9, 9), torch.float32, 0),) not in cap._graphs           # no replay: it would build no autograd graph
+    assert _sig(x9) not in cap._graphs                       # no replay: it would build no autograd graph
     with torch.no_grad():
         model(x9); model(x9)
-    assert (((3, 3, 9, 9), torch.float32, 0),) in cap._graphs
+    assert _sig(x9) in cap._graphs
     del model._parameters["extra"]; cap.__dict__.pop("_params", None)
     model.conv.weights_quantizers["weight"].scales = model.conv.weights_quantizers["weight"].scales * 2   # plan rebuilt
     ref.conv.weights_quantizers["weight"].scales = ref.conv.weights_quantizers["weight"].scales * 2
@@ -605,3 +669,198 @@ def test_fuzz_accelerated_and_auto_captured_random_models_against_the_per_layer_
                     for key in w_ref:
                         assert torch.equal(w[key], w_ref[key]), (case, key, str(dt))
         # (models with graphs are dropped here while later cases capture: what no_gc_while_capturing is for)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# plan-level versioned reuse and the advisor's AutoCapture findings
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_versioned_reuse_skips_the_weight_launch_until_something_changes(compiled_binding):
+    """accelerate(model, reuse="versioned"): forward 2..N issue NO weight launch; an in-place update, a .data swap, an edited
+    quantizer parameter or a write to the quantized weight issue exactly one re-quantization of the whole plan; the
+    quantized weights are bit-equal to the per-layer path throughout.  (Launches counted: mctq_launch_count.)"""
+    model = mq.accelerate(_small_model("cuda").eval(), reuse="versioned")
+    ref = _small_model("cuda").eval()
+    h = mq.accelerated(model)
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+
+    def same_as_ref():
+        with torch.no_grad():
+            ref(x)
+        a, b = _quantized_weights(model), _quantized_weights(ref)
+        return all(bits_equal(a[k], b[k]) for k in b)
+
+    n1, _ = _forward_launches(model, x)
+    assert n1 == 3 and h.stats() == (1, 0) and same_as_ref()                # affine table + LUT table + the activation holder
+    for k in range(3):                                                          # nothing changed: only the holder launches
+        n, _ = _forward_launches(model, x)
+        assert n == 1 and h.stats() == (1, k + 1)
+    assert same_as_ref()
+    with torch.no_grad():
+        model.conv.weight.mul_(0.5); ref.conv.weight.mul_(0.5)                 # in-place update: version counter moved
+    n, _ = _forward_launches(model, x)
+    assert n == 3 and h.stats()[0] == 2 and same_as_ref()
+    assert _forward_launches(model, x)[0] == 1
+    new = (model.lin.weight.detach() * 1.5).clone()
+    model.lin.weight.data = new; ref.lin.weight.data = new.clone()             # .data swap: another device pointer
+    n, _ = _forward_launches(model, x)
+    assert n == 3 and h.stats()[0] == 3 and same_as_ref()
+    assert _forward_launches(model, x)[0] == 1
+    opt = torch.optim.SGD([model.conv.layer.bias], lr=0.1)                      # a tensor outside the plan: no relaunch
+    model.conv.layer.bias.grad = torch.ones_like(model.conv.layer.bias); opt.step()
+    assert _forward_launches(model, x)[0] == 1
+    model.lin.layer.weight.zero_()                                              # somebody wrote into a quantized weight
+    n, _ = _forward_launches(model, x)
+    assert n == 3 and same_as_ref()
+    # a quantizer parameter edited: the plan is rebuilt (one launch pair again) and follows
+    for m in (model, ref):
+        q = m.conv.weights_quantizers["weight"]
+        q.scales = q.scales * 2
+    n, _ = _forward_launches(model, x)
+    assert n == 3 and same_as_ref() and mq.accelerated(model).stats() == (1, 0)
+    assert _forward_launches(model, x)[0] == 1
+    # the documented blind spot: a write through .data moves no version counter -> invalidate()
+    with torch.no_grad():
+        model.conv.weight.data.mul_(2.0); ref.conv.weight.data.mul_(2.0)
+    assert _forward_launches(model, x)[0] == 1 and not same_as_ref()
+    mq.accelerated(model).invalidate()
+    assert _forward_launches(model, x)[0] == 3 and same_as_ref()
+    mq.decelerate(model)
+    assert _forward_launches(model, x)[0] == 4 and same_as_ref()              # per layer again: 3 weights + the holder
+
+
+@pytest.mark.gpu
+def test_versioned_reuse_on_the_wrapped_resnet50_and_the_cost_of_the_check(compiled_binding):
+    """54 weights: forward 2..N of an accelerated inference model issue 0 weight launches; the check is one C call."""
+    import time
+    model = workloads.wrapped_resnet50("cuda").eval()
+    mq.accelerate(model, reuse="versioned")
+    h = mq.accelerated(model)
+    x = torch.randn(1, 3, 64, 64, device="cuda")
+    from mct_quantizers_amd.hip import native
+    with torch.no_grad():
+        model(x)
+        n0 = native.launch_count()
+        y1 = model(x)
+        skipped = native.launch_count() - n0
+    per_layer = workloads.wrapped_resnet50("cuda").eval()
+    with torch.no_grad():
+        n0 = native.launch_count()
+        per_layer(x)
+        full = native.launch_count() - n0
+    assert full - skipped == 54 and h.stats()[0] == 1 and h.stats()[1] >= 1, (full, skipped, h.stats())
+    a, b = _quantized_weights_any(model), _quantized_weights_any(per_layer)
+    assert len(b) == 54 and all(torch.equal(a[k], b[k]) for k in b)
+    plan = h._plan[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        plan()
+    us = (time.perf_counter() - t0) / 2000 * 1e6
+    assert plan.stats()[0] == 1                                                 # all of them skipped
+    print(f"versioned check, 54 weights: {us:.2f} us per call")
+    assert us < 15.0                                                            # (measured: profiles/r05/versioned_reuse_cost.log)
+    with torch.no_grad():                                                       # an optimizer-style update of every weight
+        torch._foreach_mul_([p for p in model.parameters() if p.dim() > 1], 0.5)
+        torch._foreach_mul_([p for p in per_layer.parameters() if p.dim() > 1], 0.5)
+        n0 = native.launch_count()
+        model(x); per_layer(x)
+    a, b = _quantized_weights_any(model), _quantized_weights_any(per_layer)
+    assert h.stats()[0] == 2 and all(torch.equal(a[k], b[k]) for k in b)
+
+
+@pytest.mark.gpu
+def test_a_launch_bumps_the_version_of_the_persistent_outputs_so_autograd_sees_the_overwrite(compiled_binding):
+    """the batched launch rewrites the quantized weights in place.  A forward whose graph saved such a weight,
+    followed by a weight update and another forward, must fail its backward with autograd's in-place error (as any in-place
+    write would) instead of silently using the newer values."""
+    model = mq.accelerate(_small_model("cuda").eval())
+    x = torch.randn(2, 3, 10, 10, device="cuda", requires_grad=True)
+    w_q_version = None
+    out1 = model(x).sum()
+    w_q = model.conv.layer.weight
+    w_q_version = w_q._version
+    with torch.no_grad():
+        model.conv.weight.add_(0.25)
+    model(x)                                                                    # rewrites the same tensor in place
+    assert model.conv.layer.weight is w_q and w_q._version > w_q_version
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out1.backward()
+    x.grad = None
+    out2 = model(x).sum()                                                       # a forward followed by its own backward is fine
+    out2.backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.gpu
+def test_auto_capture_stays_eager_while_any_hook_is_registered_whenever_it_was(compiled_binding):
+    """ADVICE r04: a hook that was already on a sub-module at the first capture became the baseline and never fired again;
+    global module hooks were not looked at.  Now: any sub-module hook or global module hook -> eager, every call."""
+    model = mq.accelerate(_small_model("cuda").eval(), capture=True)
+    cap = model.__dict__["_mctq_auto_capture"]
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+    fired = []
+    hk = model.act.register_forward_hook(lambda m, i, o: fired.append(o.data_ptr()))      # BEFORE any capture
+    with torch.no_grad():
+        for _ in range(4):
+            model(x)
+    assert len(fired) == 4 and not cap._graphs                  # once per call: no warm-up / capture passes, no replay
+    hk.remove()
+    with torch.no_grad():
+        model(x); model(x); model(x)
+    assert len(cap._graphs) == 1 and len(fired) == 4
+    seen = []
+    gh = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: seen.append(1) if m is model.pool else None)
+    try:
+        with torch.no_grad():
+            model(x); model(x)
+        assert len(seen) == 2 and not cap._graphs               # dropped, eager while the global hook is there
+    finally:
+        gh.remove()
+    pre = model.conv.register_forward_pre_hook(lambda m, a: None)
+    with torch.no_grad():
+        model(x); model(x)
+    assert not cap._graphs
+    pre.remove()
+    bw = model.lin.register_full_backward_hook(lambda m, gi, go: None)
+    with torch.no_grad():
+        model(x); model(x); model(x)
+    assert not cap._graphs
+    bw.remove()
+    with torch.no_grad():
+        model(x); model(x)
+    assert len(cap._graphs) == 1
+    mq.decelerate(model)
+
+
+@pytest.mark.gpu
+def test_auto_capture_signature_carries_autocast_and_strides(compiled_binding):
+    """a graph captured outside torch.autocast must not be replayed inside it (and the reverse); a channels_last
+    input gets its own graph with channels_last static buffers instead of a contiguous copy."""
+    model = mq.accelerate(_small_model("cuda").eval(), capture=True)
+    cap = model.__dict__["_mctq_auto_capture"]
+    ref = _small_model("cuda").eval()
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+    with torch.no_grad():
+        model(x); y = model(x)
+        assert len(cap._graphs) == 1 and y.dtype == torch.float32
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            want = ref(x)
+            y_ac1 = model(x)                                    # first occurrence of the autocast signature: eager
+            y_ac2 = model(x)                                    # captured under autocast
+            y_ac3 = model(x)
+        assert want.dtype == torch.bfloat16 and y_ac1.dtype == y_ac2.dtype == y_ac3.dtype == torch.bfloat16
+        assert len(cap._graphs) == 2 and torch.allclose(y_ac3.float(), want.float(), atol=0.1)
+        assert model(x).dtype == torch.float32                  # outside again: the float32 graph
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert model(x).dtype == torch.float16 and len(cap._graphs) == 2     # another autocast dtype: not the bf16 graph
+        xcl = x.to(memory_format=torch.channels_last)
+        assert _sig(xcl) != _sig(x)
+        want_cl = ref(xcl)
+        model(xcl)
+        ycl = model(xcl)
+        assert len(cap._graphs) == 3 and _sig(xcl) in cap._graphs
+        assert cap._graphs[_sig(xcl)][1][0].stride() == xcl.stride()           # static input keeps the layout
+        assert torch.allclose(ycl, want_cl, atol=1e-5) and ycl.stride() == want_cl.stride()
+    mq.decelerate(model)
