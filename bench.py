@@ -96,7 +96,6 @@ def parse():
     ap.add_argument("--unroll", type=int, default=None)
     ap.add_argument("--heavy-unroll", type=int, default=None)
     ap.add_argument("--rowsteps", type=int, default=None, help="tuning key rowsteps (include/mctq_hip.h): 1 = rowsteps_kernel for short whole-step rows")
-    ap.add_argument("--heavy-persistent", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batched-extra", action="store_true", help="skip the batched_16x4096 object of the default run")
@@ -242,8 +241,7 @@ def main():
     from mct_quantizers_amd.hip import native
     if not dry:
         native.load()
-        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll), ("rowsteps", args.rowsteps),
-                         ("heavy_persistent", args.heavy_persistent)):
+        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll), ("rowsteps", args.rowsteps)):
             if val is not None:
                 native.set_tuning(key, val)
 

@@ -46,7 +46,10 @@
 extern "C" {
 #endif
 
-#define MCTQ_ABI_VERSION 7
+/* v8 (round 5): the compact-decision-table entry points (mctq_lut_compact_words, mctq_lut_build_compact, mctq_lutc_*) and the
+ * tuning keys "heavy_persistent", "nt" = 0, "unroll" / "heavy_unroll" = 8 and the experiment codes of "ql_variant" left the
+ * library with the kernels behind them (measured, not adopted: tools/experiments/); nothing else changed. */
+#define MCTQ_ABI_VERSION 8
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
@@ -344,38 +347,6 @@ int mctq_lutt_per_channel(const void* x, float* y,
                           void* stream);
 
 /*
- * Compact form of the decision table (same codebooks, same cells, same exact thresholds, same results): one byte per
- * half-unit cell -- the index of the first of the codebook's steps at or above the cell -- plus the list of steps
- * {threshold (float32), half2(centre below, centre above)}.  648 bytes instead of 4 KB for 16 centres on an 8-bit clip
- * range, two dependent LDS reads per element instead of one.  An experiment on what the per-block staging of the table
- * costs (profiles/r04/cfg4_lut_experiments.md): equal to the decision-table kernels under the cold benchmark protocol, so
- * the package's quantizers use it only with MCTQ_COMPACT_LUT=1.  Codebooks with at most 256 distinct centres.
- *   mctq_lut_compact_words  upper bound of the blob size in 32-bit words for a clip range and a codebook of n_lut entries
- *   mctq_lut_build_compact  host code: fills blob_host and *n_words (the actual size); MCTQ_E_ARG when the codebook has no
- *                           decision table or more than 255 steps (use mctq_lut_build_table / the literal kernels then)
- *   mctq_lutc_per_tensor / _per_channel   as mctq_lutt_*, with `blob` (DEVICE copy, 4-byte aligned) and n_words in place
- *                           of table and entries.  Replaces lut_quantizer (pytorch/quantizer_utils.py:95-139) at the same
- *                           call sites as mctq_lut_per_tensor / mctq_lut_per_channel.
- */
-int32_t mctq_lut_compact_words(float clip_min, float clip_max, int32_t n_lut);
-
-int mctq_lut_build_compact(const float* lut_host, int32_t n_lut, float mult, float clip_min, float clip_max,
-                           void* blob_host, int32_t* n_words);
-
-int mctq_lutc_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32_t step_round,
-                         float thr_div, float thr_mul,
-                         const void* blob, int32_t n_words,
-                         float mult, float clip_min, float clip_max,
-                         void* stream);
-
-int mctq_lutc_per_channel(const void* x, float* y,
-                          int64_t outer, int64_t channels, int64_t inner, int32_t dtype,
-                          const float* thresholds, float eps,
-                          const void* blob, int32_t n_words,
-                          float mult, float clip_min, float clip_max,
-                          void* stream);
-
-/*
  * Threshold-list ("steps") form of the LUT quantizer: INTEGER codebooks whose clip range is too large for the decision
  * table (lut_values_bitwidth > 10; clip bounds and centres within +-2^20).  For such codebooks the literal scan's
  * result is a non-decreasing staircase of the scaled value with one hand-over per pair of adjacent sorted centres;
@@ -487,20 +458,21 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
 
 /*
  * Tuning hook (benchmarks only): selects the launch variant used by later calls on any thread.
- *   key "nt"     : 0 = cached loads/stores, 1 = non-temporal loads and stores (default), 2 = non-temporal
- *                  loads with cached stores
+ *   key "nt"     : 1 = non-temporal loads and stores (default), 2 = non-temporal loads with cached stores
  *   key "cached_store_max_mb" : with nt = 1, outputs of at most this many MiB are stored through the caches
  *                  (mode 2) so that a consumer launched right after finds them in L2 / the Infinity Cache; default 32, 0 = never
- *   key "unroll" : float4 accesses in flight per lane (1, 2, 4 or 8)
- *   key "ql_variant" : mctq_qlinear_i8 launch shape: 0 = automatic (cost model, csrc/mctq_qlinear.hip: qlinear_dispatch), or one
- *                  of the codes listed in csrc/mctq_misc.hip -- streaming kernels <1?><waves><16-row tiles per pass> (41 ... 184),
- *                  tiles <BM/..><BN/..>[K step][LDS buffers] (66 ... 12124), 8- / 16-wave tiles (8xxxx / 16xxxxx), wide tiles (25xx ... 4442)
- *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
- *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
+ *   key "unroll" : upper bound of the 16-byte accesses in flight per lane the affine kernels choose from (1, 2 or 4; default 4)
+ *   key "heavy_unroll" : the decision-table LUT kernels' lane-vectors per tile (0 = automatic, 1, 2 or 4)
  *   key "rowsteps" : per-channel rows of two or three whole 256-lane-vector steps: 0 = one- / two-step tiles inside a row
  *                  (rows_kernel), 1 = four steps per block across row boundaries (rowsteps_kernel), 2 (default) = rowsteps_kernel
  *                  when its grid is one round of resident blocks, where it measured 5-10 % faster (64 MiB launches)
- *   key "heavy_unroll" : same for the LUT kernels' per-iteration tile (0 = automatic, 1, 2 or 4)
+ *   key "ql_variant" : mctq_qlinear_i8 launch shape: 0 = automatic (cost model, csrc/mctq_qlinear.hip: qlinear_dispatch), or ONE of
+ *                  the kernels that choice can select: 181 / 182 / 184 (weight streaming, 16 / 32 / 64 rows per pass), 83233, 86433,
+ *                  86633, 812613 (8-wave ring tiles 32x32 ... 128x64), 166623, 1612623 (16-wave), 612, 1212, 662 (two-buffer tiles),
+ *                  2544, 2548 (wave-wide tiles), 2560 (256 x 256 ping-pong)
+ *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
+ *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
+ * Only variants a default dispatcher can select are instantiated; every value of every key is exercised by the GPU tests.
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */
 int mctq_set_tuning(const char* key, int32_t value);

@@ -228,18 +228,13 @@ PyObject* py_lutt_per_tensor(PyObject*, PyObject* const* args, Py_ssize_t nargs)
   if (!xp || dt == MCTQ_DT_F64) return not_implemented();
   const at::Tensor& x = *xp;
   const at::Tensor* tp = param_tensor(args[1], x, c10::ScalarType::Float, -1);
-  const bool compact = tp && tp->dim() == 1;           // 1-D: the compact table's words (mctq_lut_build_compact)
-  if (!tp || (!compact && (tp->dim() != 2 || tp->size(1) != 2))) return not_implemented();
+  if (!tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();
   at::Tensor y = like(x, c10::ScalarType::Float);
   const c10::DeviceIndex idx = x.device().index();
   DeviceScope scope(idx);
-  const int rc = compact
-      ? mctq_lutc_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, (int32_t)step_round,
-                             (float)thr_div, (float)thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->numel(),
-                             (float)mult, (float)cmin, (float)cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream())
-      : mctq_lutt_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, (int32_t)step_round,
-                             (float)thr_div, (float)thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->size(0) - 1,
-                             (float)mult, (float)cmin, (float)cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  const int rc = mctq_lutt_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, (int32_t)step_round,
+      (float)thr_div, (float)thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->size(0) - 1,
+      (float)mult, (float)cmin, (float)cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_lutt_per_tensor");
   return THPVariable_Wrap(std::move(y));
   END_HANDLE_TH_ERRORS
@@ -259,22 +254,16 @@ PyObject* py_lutt_per_channel(PyObject*, PyObject* const* args, Py_ssize_t nargs
   if (axis < 0 || axis >= x.dim()) return not_implemented();
   const at::Tensor* thr = param_tensor(args[1], x, c10::ScalarType::Float, x.size(axis));
   const at::Tensor* tp = param_tensor(args[3], x, c10::ScalarType::Float, -1);
-  const bool compact = tp && tp->dim() == 1;           // 1-D: the compact table's words (mctq_lut_build_compact)
-  if (!thr || !tp || (!compact && (tp->dim() != 2 || tp->size(1) != 2))) return not_implemented();
+  if (!thr || !tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();
   at::Tensor y = like(x, c10::ScalarType::Float);
   int64_t outer, c, inner;
   channel_view(x, axis, &outer, &c, &inner);
   const c10::DeviceIndex idx = x.device().index();
   DeviceScope scope(idx);
-  const int rc = compact
-      ? mctq_lutc_per_channel(x.const_data_ptr(), y.mutable_data_ptr<float>(), outer, c, inner, dt,
-                              thr->const_data_ptr<float>(), (float)eps, tp->const_data_ptr<float>(),
-                              (int32_t)tp->numel(), (float)mult, (float)cmin, (float)cmax,
-                              (void*)c10::hip::getCurrentHIPStream(idx).stream())
-      : mctq_lutt_per_channel(x.const_data_ptr(), y.mutable_data_ptr<float>(), outer, c, inner, dt,
-                              thr->const_data_ptr<float>(), (float)eps, tp->const_data_ptr<float>(),
-                              (int32_t)tp->size(0) - 1, (float)mult, (float)cmin, (float)cmax,
-                              (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  const int rc = mctq_lutt_per_channel(x.const_data_ptr(), y.mutable_data_ptr<float>(), outer, c, inner, dt,
+      thr->const_data_ptr<float>(), (float)eps, tp->const_data_ptr<float>(),
+      (int32_t)tp->size(0) - 1, (float)mult, (float)cmin, (float)cmax,
+      (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_lutt_per_channel");
   return THPVariable_Wrap(std::move(y));
   END_HANDLE_TH_ERRORS
@@ -511,19 +500,14 @@ PyObject* lutplan_vectorcall(PyObject* self, PyObject* const* args, size_t nargs
   if (p->half_steps == 2 && dt != MCTQ_DT_F32) return not_implemented();   // clip bounds not exact in a half type: general route
   const at::Tensor& x = *xp;
   const at::Tensor* tp = param_tensor(p->table, x, c10::ScalarType::Float, -1);
-  const bool compact = tp && tp->dim() == 1;           // 1-D: the compact table's words (mctq_lut_build_compact)
-  if (!tp || (!compact && (tp->dim() != 2 || tp->size(1) != 2))) return not_implemented();
+  if (!tp || tp->dim() != 2 || tp->size(1) != 2) return not_implemented();
   at::Tensor y = like(x, c10::ScalarType::Float);
   const c10::DeviceIndex idx = x.device().index();
   DeviceScope scope(idx);
   const int step = (p->half_steps && dt != MCTQ_DT_F32) ? dt : 0;
-  const int rc = compact
-      ? mctq_lutc_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, step, p->thr_div[dt],
-                             p->thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->numel(), p->mult, p->cmin,
-                             p->cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream())
-      : mctq_lutt_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, step, p->thr_div[dt],
-                             p->thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->size(0) - 1, p->mult, p->cmin,
-                             p->cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
+  const int rc = mctq_lutt_per_tensor(x.const_data_ptr(), y.mutable_data_ptr<float>(), x.numel(), dt, step, p->thr_div[dt],
+      p->thr_mul, tp->const_data_ptr<float>(), (int32_t)tp->size(0) - 1, p->mult, p->cmin,
+      p->cmax, (void*)c10::hip::getCurrentHIPStream(idx).stream());
   if (rc) return raise_rc(rc, "mctq_lutt_per_tensor");
   return THPVariable_Wrap(std::move(y));
   END_HANDLE_TH_ERRORS

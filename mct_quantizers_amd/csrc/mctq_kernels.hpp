@@ -23,13 +23,15 @@
 //                 block = one contiguous tile; the parameters of the rows that tile touches are
 //                 staged in LDS once per block and looked up per element without any per-element
 //                 division.
-//   flat_loop /   optional variants for the LUT ops (tuning key heavy_persistent): persistent blocks
-//   rows_persist  stride over tiles with two tiles of prefetch; measured 2-5 % slower than one tile
-//                 per block, which is the default for every op.
 // The LUT ops stage their codebook table in LDS after the block's data loads are in flight.
 //
-// MCTQ_ABLATE_* / MCTQ_AFFINE_HEAVY are timing-experiment switches (tools/build_variant.py); they are
-// never defined in the shipped build.
+// What is instantiated is what the dispatchers below can select (evidence: the launch-variant log of the
+// whole GPU suite + every bench configuration + the shape sweeps, profiles/r05/launch_variants_all.log):
+//   tuned ops (AffineOp, LutTableOp): lane-vectors per lane U in {1, 2, 4} (16-bit affine: {2, 4}) x cache policy
+//     NT in {1, 2}; window tiles of 4 lane-vectors, or 1 when the parameter window of a 4-wide tile would not fit LDS;
+//   every other op (integer codes, export grid, literal scan, threshold lists): ONE variant per launch shape.
+// Experiments that were measured and not adopted (persistent blocks, the compact decision table, staging ablations) live
+// under tools/experiments/, outside the library.
 //
 // Storage types: float32, float16, bfloat16 in; the affine ops write the input type (as ATen
 // does), the LUT ops always write float32 (the reference's op chain promotes).  All arithmetic is
@@ -82,13 +84,12 @@ struct IO {
   typedef typename VecT<TI, N>::type VI;
   typedef typename VecT<TO, N>::type VO;
 
-  // NT: 0 = cached loads and stores, 1 = non-temporal loads and stores (streaming: the default),
-  //     2 = non-temporal loads, cached stores (the output is consumed right away and fits the Infinity Cache)
+  // NT: 1 = non-temporal loads and stores (streaming: the default),
+  //     2 = non-temporal loads, cached stores (the output is consumed right away and fits the aggregate L2)
   template <int NT>
   __device__ __forceinline__ static VI load(const TI* p) {
     const VI* q = reinterpret_cast<const VI*>(p);
-    if (NT != 0) return __builtin_nontemporal_load(q);
-    return *q;
+    return __builtin_nontemporal_load(q);
   }
   template <int NT>
   __device__ __forceinline__ static void store(TO* p, VO v) {
@@ -103,7 +104,10 @@ struct IO {
   __device__ __forceinline__ static VO pack(const float* f) {
     VO o;
 #pragma unroll
-    for (int i = 0; i < N; ++i) o[i] = (TO)f[i];               // round-to-nearest-even narrowing
+    for (int i = 0; i < N; ++i) {
+      if constexpr (sizeof(TO) == 1) o[i] = (TO)(int32_t)f[i];  // integer codes in [-128, 255]: the low byte (int8 and uint8 alike)
+      else o[i] = (TO)f[i];                                     // round-to-nearest-even narrowing
+    }
     return o;
   }
 };
@@ -125,12 +129,8 @@ struct AffineOp {
   struct Param { float s, inv, zf; };
   typedef NoBook Book;
   static constexpr int kWords = 3;
-#ifdef MCTQ_AFFINE_HEAVY
-  static constexpr bool kHeavy = true;        // timing experiment: affine through the persistent path
-#else
   static constexpr bool kHeavy = false;       // a few VALU ops per element: pure streaming
-#endif
-  static constexpr int kFixedU = 0;            // 0: every launch variant is built; else only <kFixedU lane-vectors, non-temporal>
+  static constexpr int kFixedU = 0;           // 0: the tuned set of launch variants (U x cache policy); else ONE variant
 
   __host__ __device__ __forceinline__ static Param make(float s, int32_t zp) {
     Param p;
@@ -186,6 +186,7 @@ struct AffineOp {
 // quantizers for consumers that dequantize themselves (1 B written per element instead of 4).
 struct AffineCodesOp : AffineOp {
   static constexpr const char* kName = "AffineCodesOp";
+  static constexpr int kFixedU = 4;            // an extension without a reference counterpart: one variant per launch shape
   template <bool FAST = true>
   __device__ __forceinline__ float apply(float x, const Param& p, const Book&) const {
     const float q = __builtin_rintf(x * p.inv) + p.zf;
@@ -209,7 +210,7 @@ struct GridOp {
   typedef NoBook Book;
   static constexpr int kWords = 3;
   static constexpr bool kHeavy = false;
-  static constexpr int kFixedU = 0;            // 0: every launch variant is built; else only <kFixedU lane-vectors, non-temporal>
+  static constexpr int kFixedU = 4;            // runs once per export: one variant per launch shape
 
   __host__ __device__ __forceinline__ static Param make(float lo, float hi, float d) {
     Param p; p.lo = lo; p.hi = hi; p.d = d; return p;
@@ -261,7 +262,7 @@ struct LutCommon {
   struct Param { float d, t, r, ds; };
   static constexpr int kWords = 4;
   static constexpr bool kHeavy = true;         // launched through the heavy-op dispatch
-  static constexpr int kFixedU = 0;            // overridden by the literal-scan and the steps op (one variant each)
+  static constexpr int kFixedU = 0;            // LutTableOp: the tuned set; the literal-scan and the list ops override it (one variant each)
 
   __host__ __device__ __forceinline__ static Param make(float d, float t, float mult) {
     Param p; p.d = d; p.t = t;
@@ -302,9 +303,6 @@ struct LutCommon {
   // Verified exhaustively against '/' on the GPU (tests/test_gpu_parity.py::test_fast_division_is_exact).
   __device__ __forceinline__ static float divide_fast(float x, float ds, float r) {
     const float q0 = x * r;
-#ifdef MCTQ_ABLATE_DIV
-    return q0;
-#endif
     const float e0 = __builtin_fmaf(-q0, ds, x);
     const float q1 = __builtin_fmaf(e0, r, q0);
     const float e1 = __builtin_fmaf(-q1, ds, x);
@@ -441,13 +439,6 @@ struct LutTableOp : LutCommon {
   __device__ __forceinline__ Prefetch prefetch() const {
     const f32x2* src = reinterpret_cast<const f32x2*>(table);
     Prefetch p;
-#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE != 3   // timing experiments (results wrong): 1 = no table traffic, no LDS
-    return p;                                                 // writes, no barrier; 2 = the barrier only; 3 = loads + LDS writes,
-#endif                                                        // no barrier; 4 = a quarter of the table (1 KB), barrier kept
-#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 4
-    if ((int)threadIdx.x * 4 <= entries) p.r[0] = src[threadIdx.x];
-    return p;
-#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = (int)threadIdx.x + i * kThreads;
@@ -457,22 +448,11 @@ struct LutTableOp : LutCommon {
   }
   __device__ __forceinline__ Book commit(const Prefetch& p, float* lds) const {
     f32x2* dst = reinterpret_cast<f32x2*>(lds);
-#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 4
-    if ((int)threadIdx.x * 4 <= entries) dst[threadIdx.x] = p.r[0];
-    { __syncthreads(); Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
-#elif defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 1
-    { Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
-#elif defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 2
-    { __syncthreads(); Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
-#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = (int)threadIdx.x + i * kThreads;
       if (j <= entries) dst[j] = p.r[i];
     }
-#if defined(MCTQ_ABLATE_STAGE) && MCTQ_ABLATE_STAGE == 3
-    { Book b; b.tab = dst; b.nan_q = 0.0f; return b; }
-#endif
     __syncthreads();
     Book b; b.tab = dst; b.nan_q = dst[entries].x;
     return b;
@@ -517,105 +497,7 @@ struct LutTableOp : LutCommon {
 #pragma unroll
     for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], k[i]);
 #pragma unroll
-#ifdef MCTQ_ABLATE_LDS
-    for (int i = 0; i < NE; ++i) { e[i].x = (float)k[i]; e[i].y = __uint_as_float(0x3c003800u); }
-#else
     for (int i = 0; i < NE; ++i) e[i] = b.tab[k[i]];
-#endif
-#pragma unroll
-    for (int i = 0; i < NE; ++i) out[i] = decide<FAST>(in[i], v[i], e[i], p, b);
-  }
-};
-
-// Compact decision table (mctq_table_builder.h: build_compact): the same cells k and the same exact thresholds as
-// LutTableOp, stored as one BYTE per cell (index j of the first step at or above the cell) plus the list of the codebook's
-// steps {T_j, half2(q below, q above)} -- 648 bytes instead of 4 KB for 16 centres on an 8-bit clip range; two dependent
-// LDS reads per element instead of one.  Built to test whether the 4 KB staged by every block is what keeps the table
-// kernel behind the affine one on config 4.  Measured (profiles/r04/cfg4_lut_experiments.md): under bench.py's cold,
-// sustained protocol the two forms are equal at U = 4 (58.6-59.2 vs 58.9 us) and one-step tiles, which the small table makes
-// affordable and which win 3 us in short half-warm runs, LOSE 3 us there -- so the decision table stays the default and this
-// op is selected by MCTQ_COMPACT_LUT=1 only.
-struct LutCompactBook { const uint8_t* cell; const f32x2* step; float nan_q; };
-
-struct LutCompactOp : LutCommon {
-  static constexpr const char* kName = "LutCompactOp";
-  const uint32_t* __restrict__ blob;   // device, n_words words
-  int entries;                         // K cells
-  int n_words;
-  float koff;                          // 0.5 - 2*clip_min
-  float kmax;                          // entries - 1
-
-  typedef LutCompactBook Book;
-  __device__ __forceinline__ uint32_t book_words() const { return ((uint32_t)n_words + 3u) & ~3u; }
-  __device__ __forceinline__ Book book_at(float* lds) const {
-    const uint32_t cw = ((uint32_t)entries + 3u) >> 2;
-    Book b;
-    b.cell = reinterpret_cast<const uint8_t*>(lds);
-    b.step = reinterpret_cast<const f32x2*>(lds + cw);
-    b.nan_q = lds[n_words - 2];
-    return b;
-  }
-  __device__ __forceinline__ Book setup(float* lds) const {
-    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-    for (int j = threadIdx.x; j < n_words; j += kThreads) dst[j] = blob[j];
-    __syncthreads();
-    return book_at(lds);
-  }
-  // requested BEFORE the tile's data loads, written to LDS after them (in-order return of vector loads: LutTableOp::prefetch)
-  struct Prefetch { uint32_t r[5]; };                // n_words <= 512 + 512 + 2 over 256 threads
-  __device__ __forceinline__ Prefetch prefetch() const {
-    Prefetch p;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int j = (int)threadIdx.x + i * kThreads;
-      if (j < n_words) p.r[i] = blob[j];
-    }
-    return p;
-  }
-  __device__ __forceinline__ Book commit(const Prefetch& p, float* lds) const {
-    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int j = (int)threadIdx.x + i * kThreads;
-      if (j < n_words) dst[j] = p.r[i];
-    }
-    __syncthreads();
-    return book_at(lds);
-  }
-
-  template <bool FAST>
-  __device__ __forceinline__ void locate(float x, const Param& p, float& v, int& k) const {   // as LutTableOp::locate
-    v = scaled<FAST>(x, p);
-    k = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(v, 2.0f, koff), 0.0f, kmax);
-  }
-  template <bool FAST>
-  __device__ __forceinline__ float decide(float x, float v, f32x2 e, const Param& p, const Book& b) const {
-    const uint32_t pair = __float_as_uint(e.y);
-    const uint32_t h = (v >= e.x) ? (pair >> 16) : pair;
-    float q = __half2float(__ushort_as_half((unsigned short)h));
-    const bool nan = (FAST && step_round == 0) ? (x != x) : (v != v);    // see LutTableOp::decide
-    q = nan ? b.nan_q : q;
-    return q * p.t;
-  }
-  template <bool FAST = false>
-  __device__ __forceinline__ float apply(float x, const Param& p, const Book& b) const {
-    float v; int k;
-    locate<FAST>(x, p, v, k);
-    return decide<FAST>(x, v, b.step[b.cell[k]], p, b);
-  }
-  // a whole tile level by level: the NE reads of a level are issued back to back
-  template <bool FAST, int NE>
-  __device__ __forceinline__ void tile(const float* in, float* out, const Param& p, const Book& b) const {
-    float v[NE];
-    int k[NE];
-    uint32_t j[NE];
-    f32x2 e[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) locate<FAST>(in[i], p, v[i], k[i]);
-#pragma unroll
-    for (int i = 0; i < NE; ++i) j[i] = b.cell[k[i]];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) e[i] = b.step[j[i]];
 #pragma unroll
     for (int i = 0; i < NE; ++i) out[i] = decide<FAST>(in[i], v[i], e[i], p, b);
   }
@@ -755,6 +637,13 @@ struct LutCellsOp : LutCommon {
     for (int i = 0; i < NE; ++i) out[i] = ((t[i] != t[i]) ? b.nan_q : q[i]) * p.t;
   }
 };
+
+// one element to its storage type (the scalar tails and the unaligned paths)
+template <class TO>
+__device__ __forceinline__ TO narrow_to(float v) {
+  if constexpr (sizeof(TO) == 1) return (TO)(int32_t)v;
+  else return (TO)v;
+}
 
 template <class Op, class = void>
 struct HasTile : std::false_type {};
@@ -905,7 +794,7 @@ __global__ __launch_bounds__(kThreads) void flat_kernel(const TI* __restrict__ x
     __syncthreads();                                         // everyone is done with the block's table
     const typename Op::Book book = op.setup(smem);           // all threads: setup may synchronise
     const int64_t i = nv * io::N + threadIdx.x;
-    if (i < n) ys[i] = (TO)op.template apply<false>((float)xs[i], p, book);
+    if (i < n) ys[i] = narrow_to<TO>(op.template apply<false>((float)xs[i], p, book));
   }
 }
 
@@ -917,7 +806,7 @@ __global__ __launch_bounds__(kThreads) void flat_scalar_kernel(Op op, typename O
   const typename Op::Book book = op.setup(smem);
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
-    y[i] = (TO)op.template apply<false>((float)x[i], p, book);
+    y[i] = narrow_to<TO>(op.template apply<false>((float)x[i], p, book));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -995,85 +884,6 @@ __global__ __launch_bounds__(kThreads) void rowsteps_kernel(const TI* __restrict
       run_vectors<true, Op, TI, TO, 1>(op, one, res, p[u], book);
       io::template store<NT>(ys + (first + u * kThreads) * io::N, res[0]);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Heavy ops: persistent blocks.  The work is cut into tiles of 256*U lane-vectors (tiles never
-// cross a row); block b takes tiles b, b+grid, b+2*grid, ... so every CU finishes at the same time
-// (a one-block-per-row grid leaves the last round of blocks mostly empty), prefetches the next
-// tile's loads before it computes the current one, and pays the table / codebook staging once.
-// Full tiles run straight-line code so the LDS table reads of a tile are issued back to back.
-// ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void rows_persist_kernel(Op op, const TI* __restrict__ xs, TO* __restrict__ ys,
-                                                                uint32_t tiles_per_row, uint32_t total_tiles,
-                                                                uint32_t innerv, uint32_t channels) {
-  typedef IO<TI, TO> io;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr uint32_t TILE = kThreads * U;
-  const uint32_t G = gridDim.x;
-  uint32_t item = blockIdx.x;                                // grid <= total_tiles
-  // two tiles of loads in flight per lane: vA = the tile after the current one, vB = the one after that
-  typename io::VI vA[U], vB[U];
-  auto issue = [&](typename io::VI (&v)[U], uint32_t it) {
-    const uint32_t row = it / tiles_per_row, tile = it - row * tiles_per_row;
-    const int64_t rbase = (int64_t)row * innerv;
-    load_tile<TI, TO, U, NT>(v, xs, rbase + tile * TILE + threadIdx.x, rbase + innerv, (tile + 1) * TILE <= innerv);
-  };
-  issue(vA, item);
-  if (item + G < total_tiles) issue(vB, item + G);
-  const typename Op::Book book = op.setup(smem);
-  // The parameters of a tile are fetched one iteration ahead (scalar loads + one IEEE reciprocal), so
-  // their latency sits under the previous tile's compute instead of in front of the next loads.
-  auto params_of = [&](uint32_t it) {
-    const uint32_t row = it / tiles_per_row;
-    return op.fetch(row >= channels ? row % channels : row);
-  };
-  typename Op::Param p_next = params_of(item);
-  for (; item < total_tiles; item += G) {
-    const uint32_t row = item / tiles_per_row;
-    const uint32_t tile = item - row * tiles_per_row;
-    const typename Op::Param p = p_next;
-    const bool fast = __builtin_amdgcn_readfirstlane((int)Op::can_fast(p)) != 0;
-    typename io::VI w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { w[u] = vA[u]; vA[u] = vB[u]; }
-    if (item + 2 * G < total_tiles) issue(vB, item + 2 * G);
-    if (item + G < total_tiles) p_next = params_of(item + G);
-    const int64_t rbase = (int64_t)row * innerv;
-    const int64_t first = rbase + tile * TILE + threadIdx.x;
-    const bool full = (tile + 1) * TILE <= innerv;
-    if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, w, ys, first, rbase + innerv, full);
-    else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, w, ys, first, rbase + innerv, full);
-  }
-}
-
-template <class Op, class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void flat_loop_kernel(Op op, typename Op::Param p, const TI* __restrict__ xs,
-                                                             TO* __restrict__ ys, int64_t n) {
-  typedef IO<TI, TO> io;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int64_t TILE = (int64_t)kThreads * U;
-  const int64_t nv = n / io::N;
-  const int64_t tiles = (nv + TILE - 1) / TILE;
-  typename io::VI v[U];
-  load_tile<TI, TO, U, NT>(v, xs, (int64_t)blockIdx.x * TILE + threadIdx.x, nv, ((int64_t)blockIdx.x + 1) * TILE <= nv);
-  const typename Op::Book book = op.setup(smem);
-  const bool fast = Op::can_fast(p);                        // kernel argument: uniform
-  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    typename io::VI w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = v[u];
-    const int64_t tn = t + gridDim.x;
-    if (tn < tiles) load_tile<TI, TO, U, NT>(v, xs, tn * TILE + threadIdx.x, nv, (tn + 1) * TILE <= nv);
-    const bool full = (t + 1) * TILE <= nv;
-    if (fast) finish_tile<true, Op, TI, TO, U, NT>(op, p, book, w, ys, t * TILE + threadIdx.x, nv, full);
-    else finish_tile<false, Op, TI, TO, U, NT>(op, p, book, w, ys, t * TILE + threadIdx.x, nv, full);
-  }
-  if (blockIdx.x == 0) {
-    const int64_t i = nv * io::N + threadIdx.x;
-    if (i < n) ys[i] = (TO)op.template apply<false>((float)xs[i], p, book);
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1224,7 +1034,7 @@ __global__ __launch_bounds__(kThreads) void window_kernel(const TI* __restrict__
       io::template store<NT>(ys + e0 + off, io::pack(out));
     } else {
       for (uint32_t j = 0; j < V && off + j < count; ++j) {
-        ys[e0 + off + j] = (TO)op.template apply<false>((float)xs[e0 + off + j], Op::get(tab, li, stride), book);
+        ys[e0 + off + j] = narrow_to<TO>(op.template apply<false>((float)xs[e0 + off + j], Op::get(tab, li, stride), book));
         if (++lrem == inner) {
           lrem = 0;
           ++li;
@@ -1240,7 +1050,7 @@ __global__ __launch_bounds__(kThreads) void window_kernel(const TI* __restrict__
 // ------------------------------------------------------------------------------------------
 // shared state and helpers, defined in mctq_misc.hip
 extern thread_local char g_err[256];
-extern int g_nt;             // 0 cached, 1 non-temporal (+7% on the cold 4096x4096 stream), 2 nt loads + cached stores
+extern int g_nt;             // 1 non-temporal loads and stores (+7% on the cold 4096x4096 stream), 2 nt loads + cached stores
 extern int64_t g_cached_store_max_bytes;   // with g_nt == 1: outputs up to this size use mode 2 (0 = never)
 inline int nt_mode(int64_t out_bytes) {
   if (g_nt != 1) return g_nt;
@@ -1264,7 +1074,6 @@ inline void note(const char* shape, int unroll, int nt) {
 }
 extern int g_rowsteps;       // short whole-step rows: 0 rows_kernel, 1 rowsteps_kernel, 2 (default) rowsteps_kernel when its grid is one round
 extern int g_heavy_unroll;   // 0 = automatic
-extern int g_heavy_persistent;
 int fail_arg(const char* msg);
 int check_launch(const char* what);
 int cu_count();
@@ -1298,30 +1107,35 @@ inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st,
   hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
 }
 
-// Launch-variant dispatch.  NT_ is the runtime cache-policy mode (0, 1, 2: see IO::load/store).  Unroll
-// variants and mode 0 are instantiated for float32 -> float32 only (that is where tuning is done); the
-// other storage types use U = 4.  Fallback ops are built in one variant.
-#define MCTQ_WITH_MODE(MODE_, ALLOW0_, ...)                                                 \
+// Launch-variant dispatch.  NT_ is the runtime cache-policy mode (1: non-temporal loads and stores, 2: non-temporal
+// loads + cached stores; see IO::load/store).  An op with kFixedU != 0 is built in ONE variant (U = kFixedU, NT = 1).
+#define MCTQ_WITH_MODE(MODE_, ...)                                                          \
   do {                                                                                      \
-    const int mode__ = (MODE_);                                                             \
-    if (mode__ == 2) { constexpr int NT = 2; __VA_ARGS__; }                                 \
-    else if ((ALLOW0_) && mode__ == 0) { constexpr int NT = (ALLOW0_) ? 0 : 1; __VA_ARGS__; } \
+    if ((MODE_) == 2) { constexpr int NT = 2; __VA_ARGS__; }                                \
     else { constexpr int NT = 1; __VA_ARGS__; }                                             \
+  } while (0)
+
+// single-variant ops: NT = 1 whatever the mode
+#define MCTQ_WITH_OP_MODE(MODE_, ...)                                                       \
+  do {                                                                                      \
+    if constexpr (Op::kFixedU != 0) { constexpr int NT = 1; __VA_ARGS__; }                  \
+    else MCTQ_WITH_MODE(MODE_, __VA_ARGS__);                                                \
   } while (0)
 
 #define MCTQ_DISPATCH_U_NT(U_, NT_, ...)                                                    \
   do {                                                                                      \
-    if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {      \
+    if constexpr (Op::kFixedU != 0) {                                                       \
+      constexpr int U = Op::kFixedU; constexpr int NT = 1; __VA_ARGS__;                     \
+    } else if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) { \
       switch (U_) {                                                                         \
-        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
-        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
-        case 8: { constexpr int U = 8; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
-        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;    \
+        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;           \
+        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;           \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;          \
       }                                                                                     \
     } else {                                                                                \
       switch (U_) {       /* 16-bit storage: 8 elements per lane-vector, so rows are half as many vectors */ \
-        case 1: case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break; \
-        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;   \
+        case 1: case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;   \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;          \
       }                                                                                     \
     }                                                                                       \
   } while (0)
@@ -1330,33 +1144,14 @@ inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st,
   do {                                                                                      \
     if constexpr (Op::kFixedU != 0) {                                                       \
       constexpr int U = Op::kFixedU; constexpr int NT = 1; __VA_ARGS__;                     \
-    } else if constexpr (std::is_same<TI, float>::value) {                                  \
-      switch (U_) {                                                                         \
-        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
-        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;     \
-        case 8: { constexpr int U = 8; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;    \
-        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, true, __VA_ARGS__); } break;    \
-      }                                                                                     \
     } else {                                                                                \
       switch (U_) {                                                                         \
-        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;    \
-        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;    \
-        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, false, __VA_ARGS__); } break;   \
+        case 1: { constexpr int U = 1; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;           \
+        case 2: { constexpr int U = 2; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;           \
+        default: { constexpr int U = 4; MCTQ_WITH_MODE(NT_, __VA_ARGS__); } break;          \
       }                                                                                     \
     }                                                                                       \
   } while (0)
-
-template <class Op, class TI, class TO, int U, int NT>
-static int persist_blocks_per_cu(size_t book_bytes) {
-  static int per_cu = 0;
-  if (per_cu == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rows_persist_kernel<Op, TI, TO, U, NT>, kThreads,
-                                                     book_bytes) != hipSuccess || nb < 1) nb = 4;
-    per_cu = nb > 8 ? 8 : nb;
-  }
-  return per_cu;
-}
 
 template <class TI, class TO, class Op>
 static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv, void* yv, int64_t n,
@@ -1375,27 +1170,15 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
   }
   const int64_t nv = n / io::N;
   if constexpr (Op::kHeavy) {
-    if (Op::kFixedU != 0 || !g_heavy_persistent) {
-      MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, nt_mode(n * (int64_t)sizeof(TO)), {
-        int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
-        if (blocks == 0) blocks = 1;
-        if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
-        hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                           x, y, n, op, p);
-        note<Op, TI, TO>("flat_kernel", U, NT);
-      });
-      return check_launch("flat launch");
-    }
-    if constexpr (Op::kFixedU == 0) MCTQ_DISPATCH_HEAVY(2, nt_mode(n * (int64_t)sizeof(TO)), {
+    MCTQ_DISPATCH_HEAVY(g_heavy_unroll ? g_heavy_unroll : 4, nt_mode(n * (int64_t)sizeof(TO)), {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
-      const int64_t cap = (int64_t)cu_count() * 16;
-      if (blocks > cap) blocks = cap;
       if (blocks == 0) blocks = 1;
-      hipLaunchKernelGGL((flat_loop_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                         op, p, x, y, n);
-      note<Op, TI, TO>("flat_loop_kernel", U, NT);
+      if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
+      hipLaunchKernelGGL((flat_kernel<Op, TI, TO, U, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
+                         x, y, n, op, p);
+      note<Op, TI, TO>("flat_kernel", U, NT);
     });
-    return check_launch("flat loop launch");
+    return check_launch("flat launch");
   } else {
     // small tensors: fewer lane-vectors per lane so that the grid still covers the chip (>= 2 blocks per CU)
     int u_sel = g_unroll;
@@ -1440,23 +1223,13 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       const int64_t per = (int64_t)kThreads * u_sel;
       const int64_t tiles = (innerv + per - 1) / per;
       const int64_t total = rows * tiles;
-      if ((Op::kFixedU != 0 || !g_heavy_persistent) && total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
+      if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
         MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
           hipLaunchKernelGGL((rows_kernel<Op, TI, TO, U, NT>), dim3((unsigned)total), dim3(kThreads), book_bytes,
                              st, x, y, (uint32_t)tiles, (uint32_t)innerv, (uint32_t)channels, op);
           note<Op, TI, TO>("rows_kernel", U, NT);
         });
         return check_launch("rows launch");
-      }
-      if constexpr (Op::kFixedU == 0) if (total <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
-        MCTQ_DISPATCH_HEAVY(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
-          int64_t grid = (int64_t)cu_count() * persist_blocks_per_cu<Op, TI, TO, U, NT>(book_bytes);
-          if (grid > total) grid = total;
-          hipLaunchKernelGGL((rows_persist_kernel<Op, TI, TO, U, NT>), dim3((unsigned)grid), dim3(kThreads), book_bytes,
-                             st, op, x, y, (uint32_t)tiles, (uint32_t)total, (uint32_t)innerv, (uint32_t)channels);
-          note<Op, TI, TO>("rows_persist_kernel", U, NT);
-        });
-        return check_launch("rows persistent launch");
       }
     } else {
       // Largest U <= tuned unroll that wastes the fewest lanes in the last tile of a row.
@@ -1479,7 +1252,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         const bool one_round = rs_blocks <= round && rs_blocks * 4 >= round * 3;
         if ((g_rowsteps == 1 || (g_rowsteps == 2 && one_round)) && best_u < 4 && g_unroll >= 4 && innerv % kThreads == 0 &&
             total_steps <= 0xffffffffLL) {
-          MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), false, {
+          MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
             constexpr int U = 4;
             hipLaunchKernelGGL((rowsteps_kernel<Op, TI, TO, U, NT>), dim3((unsigned)((total_steps + U - 1) / U)), dim3(kThreads),
                                0, st, x, y, (uint32_t)(innerv / kThreads), (uint32_t)total_steps, (uint32_t)channels, op);
@@ -1489,6 +1262,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
         }
       }
       if (!(std::is_same<TI, float>::value && std::is_same<TO, float>::value) && best_u < 2) best_u = 2;   // built: U = 2, 4
+      if (Op::kFixedU != 0) best_u = Op::kFixedU;          // single-variant ops
       const int64_t per = (int64_t)kThreads * best_u;
       const int64_t tiles = (innerv + per - 1) / per;
       if (rows * tiles <= 0x7fffffffLL && innerv <= 0x7fffffffLL) {
@@ -1516,7 +1290,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
     const int64_t bps = (k * vc + kThreads - 1) / kThreads;
     const int64_t blocks = bps * ((outer + LU * k - 1) / (LU * k));
     if (blocks <= 0x7fffffffLL && k * vc <= 0x7fffffffLL) {
-      MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
+      MCTQ_WITH_OP_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
         hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
                            x, y, (uint64_t)outer, (uint32_t)vc, (uint32_t)k, (uint32_t)bps, op);
         note<Op, TI, TO>("lastaxis_kernel", LU, NT);
@@ -1528,50 +1302,54 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   // window shape.
   if (inner > 0x7fffffffLL || channels > 0x7fffffffLL) return fail_arg("inner/channels exceed 2^31-1");
   const uint32_t V = vec_ok ? io::N : 1;
-  // lane-vectors per lane: 4, or fewer when the parameter window of a 4-wide tile would not fit LDS
-  // (tiny inner with many channels)
+  // lane-vectors per lane: 4, or ONE when the parameter window of a 4-wide tile would not fit LDS (tiny inner with many
+  // channels and a large codebook).  Unaligned tensors (one element per lane access) always fit with 4.
   int wu = 4;
   uint32_t tile = 0, stride = 0;
   size_t lds = 0;
-  for (;; wu >>= 1) {
+  for (;; wu = 1) {
     tile = kThreads * wu * V;
     const uint64_t max_rows = (uint64_t)(tile - 1 + (inner - 1)) / (uint64_t)inner + 1;   // rows a tile can touch
     const uint64_t entries = (uint64_t)channels <= max_rows ? (uint64_t)channels : max_rows;
     stride = (uint32_t)entries | 1u;       // odd: keeps the parameter planes on different LDS banks
     lds = book_bytes + (size_t)stride * Op::kWords * sizeof(float);
-    if (lds <= 64 * 1024 || wu == 1) break;
+    if (lds <= 64 * 1024 || wu == 1 || !vec_ok) break;
   }
   if (lds > 64 * 1024) return fail_arg("parameter window exceeds 64 KiB of LDS");
   const int64_t blocks = (n + tile - 1) / tile;
   if (blocks > 0x7fffffffLL) return fail_arg("tensor too large for one launch");
   const bool idx32 = n <= (int64_t)0xffffffffLL - (int64_t)tile;
-#define MCTQ_WINDOW(WU_, VEC_, IDX_)                                                                               \
-  hipLaunchKernelGGL((window_kernel<Op, TI, TO, WU_, VEC_, NT, IDX_>), dim3((unsigned)blocks), dim3(kThreads), lds, st, \
+#define MCTQ_WINDOW(WU_, VEC_, NT_, IDX_)                                                                           \
+  hipLaunchKernelGGL((window_kernel<Op, TI, TO, WU_, VEC_, NT_, IDX_>), dim3((unsigned)blocks), dim3(kThreads), lds, st, \
                      x, y, (IDX_)n, (uint32_t)inner, (uint32_t)channels, stride, op)
-#define MCTQ_WINDOW_WU(VEC_, IDX_)                                    \
-  do {                                                                \
-    if (wu == 4) MCTQ_WINDOW(4, VEC_, IDX_);                          \
-    else if (wu == 2) MCTQ_WINDOW(2, VEC_, IDX_);                     \
-    else MCTQ_WINDOW(1, VEC_, IDX_);                                  \
-  } while (0)
-  MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)) == 0 ? 1 : nt_mode(n * (int64_t)sizeof(TO)), false, {
-    if (!idx32) {                                      // > 4 Gi elements: only the common shape is built
+  if (!idx32) {
+    // > 4 Gi elements in short rows: the common shape of the affine quantizers only (aligned, 4 lane-vectors, streaming)
+    if constexpr (std::is_same<Op, AffineOp>::value) {
       if (!vec_ok || wu != 4) return fail_arg("tensors above 2^32 elements need vector alignment and a small window");
-      MCTQ_WINDOW(4, true, uint64_t);
-    } else if (vec_ok) {
-      MCTQ_WINDOW_WU(true, uint32_t);
+      MCTQ_WINDOW(4, true, 1, uint64_t);
+      note<Op, TI, TO>("window_kernel<vector,u64>", 4, 1);
+      return check_launch("window launch");
     } else {
-      MCTQ_WINDOW_WU(false, uint32_t);
+      return fail_arg("per-channel rows shorter than 256 lane-vectors above 2^32 elements: affine quantizers only");
     }
-    note<Op, TI, TO>(vec_ok ? "window_kernel<vector>" : "window_kernel<scalar>", wu, NT);
+  }
+  if (!vec_ok) {                                       // one element per lane access: the slow path, one variant
+    MCTQ_WINDOW(4, false, 1, uint32_t);
+    note<Op, TI, TO>("window_kernel<scalar>", 4, 1);
+    return check_launch("window launch");
+  }
+  MCTQ_WITH_OP_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
+    if (wu == 4) MCTQ_WINDOW(4, true, NT, uint32_t);
+    else MCTQ_WINDOW(1, true, NT, uint32_t);
+    note<Op, TI, TO>("window_kernel<vector>", wu, NT);
   });
-#undef MCTQ_WINDOW_WU
 #undef MCTQ_WINDOW
   return check_launch("window launch");
 }
 
 // ---- LUT helpers (host) ---------------------------------------------------------------------------
-inline int lut_class(int n_lut) { return n_lut <= 4 ? 4 : n_lut <= 16 ? 16 : n_lut <= 64 ? 64 : 0; }
+// literal scan: codebooks of up to 16 entries live in scalar registers (v_readlane broadcast), longer ones in LDS
+inline int lut_class(int n_lut) { return n_lut <= 16 ? 16 : 0; }
 
 inline void fill_lut_common(LutCommon& op, const float* thr, float eps, float mult, float cmin, float cmax,
                             int step_round) {
@@ -1616,21 +1394,6 @@ inline int make_table_op(LutTableOp& op, const float* thr, float eps, const floa
   return 0;
 }
 inline size_t table_bytes(int32_t entries) { return (size_t)(((entries + 1) * 2 + 3) & ~3) * 4; }
-inline int make_compact_op(LutCompactOp& op, const float* thr, float eps, const void* blob, int32_t n_words, float mult,
-                           float cmin, float cmax, int step_round) {
-  if (!blob) return fail_arg("compact table is NULL");
-  if (int rc = check_pow2(mult)) return rc;
-  const int entries = table_entries(cmin, cmax);
-  if (entries < 0) return fail_arg("decision table unsupported for this clip range");
-  const int cw = (entries + 3) / 4;
-  if (n_words < cw + 4 || n_words > cw + 2 * 256 + 2 || ((n_words - cw) & 1)) return fail_arg("n_words does not match the clip range");
-  fill_lut_common(op, thr, eps, mult, cmin, cmax, step_round);
-  op.blob = static_cast<const uint32_t*>(blob); op.entries = entries; op.n_words = n_words;
-  op.koff = 0.5f - 2.0f * cmin; op.kmax = (float)(entries - 1);
-  return 0;
-}
-inline size_t compact_bytes(int32_t n_words) { return (size_t)((n_words + 3) & ~3) * 4; }
-
 // storage-type dispatch: f(TI{}, TO{})
 template <class F>
 static int with_affine_types(int dtype, F f) {
@@ -1641,25 +1404,16 @@ static int with_affine_types(int dtype, F f) {
     default: return fail_arg("unknown dtype");
   }
 }
+// int8 and uint8 codes are the same bytes (the low byte of the clamped integer): ONE 1-byte storage type
 template <class F>
 static int with_codes_types(int dtype, int code_dtype, F f) {
-  if (code_dtype == MCTQ_CODE_I8) {
-    switch (dtype) {
-      case MCTQ_DT_F32: return f(float(), int8_t());
-      case MCTQ_DT_F16: return f(_Float16(), int8_t());
-      case MCTQ_DT_BF16: return f(__bf16(), int8_t());
-      default: return fail_arg("unknown dtype");
-    }
+  if (code_dtype != MCTQ_CODE_I8 && code_dtype != MCTQ_CODE_U8) return fail_arg("unknown code dtype");
+  switch (dtype) {
+    case MCTQ_DT_F32: return f(float(), uint8_t());
+    case MCTQ_DT_F16: return f(_Float16(), uint8_t());
+    case MCTQ_DT_BF16: return f(__bf16(), uint8_t());
+    default: return fail_arg("unknown dtype");
   }
-  if (code_dtype == MCTQ_CODE_U8) {
-    switch (dtype) {
-      case MCTQ_DT_F32: return f(float(), uint8_t());
-      case MCTQ_DT_F16: return f(_Float16(), uint8_t());
-      case MCTQ_DT_BF16: return f(__bf16(), uint8_t());
-      default: return fail_arg("unknown dtype");
-    }
-  }
-  return fail_arg("unknown code dtype");
 }
 template <class F>
 static int with_lut_types(int dtype, F f) {

@@ -28,11 +28,7 @@ int mctq_lut_per_tensor(const void* x, float* y, int64_t n, int32_t dtype, int32
     typedef decltype(ti) TI;
     typedef decltype(to) TO;
     switch (lut_class(n_lut)) {
-      case 4: return launch_flat<TI, TO>(make_lut_op<4>(nullptr, 0.f, lut, n_lut, mult, clip_min, clip_max, step_round),
-                                         p, x, y, n, 0, st);
       case 16: return launch_flat<TI, TO>(make_lut_op<16>(nullptr, 0.f, lut, n_lut, mult, clip_min, clip_max, step_round),
-                                          p, x, y, n, 0, st);
-      case 64: return launch_flat<TI, TO>(make_lut_op<64>(nullptr, 0.f, lut, n_lut, mult, clip_min, clip_max, step_round),
                                           p, x, y, n, 0, st);
       default: return launch_flat<TI, TO>(make_lut_op<0>(nullptr, 0.f, lut, n_lut, mult, clip_min, clip_max, step_round),
                                           p, x, y, n, (size_t)((n_lut + 3) & ~3) * sizeof(float), st);
@@ -54,11 +50,7 @@ int mctq_lut_per_channel(const void* x, float* y, int64_t outer, int64_t channel
     typedef decltype(ti) TI;
     typedef decltype(to) TO;
     switch (lut_class(n_lut)) {
-      case 4: return launch_channels<TI, TO>(make_lut_op<4>(thresholds, eps, lut, n_lut, mult, clip_min, clip_max, 0),
-                                             x, y, outer, channels, inner, 0, st);
       case 16: return launch_channels<TI, TO>(make_lut_op<16>(thresholds, eps, lut, n_lut, mult, clip_min, clip_max, 0),
-                                              x, y, outer, channels, inner, 0, st);
-      case 64: return launch_channels<TI, TO>(make_lut_op<64>(thresholds, eps, lut, n_lut, mult, clip_min, clip_max, 0),
                                               x, y, outer, channels, inner, 0, st);
       default: return launch_channels<TI, TO>(make_lut_op<0>(thresholds, eps, lut, n_lut, mult, clip_min, clip_max, 0),
                                               x, y, outer, channels, inner, (size_t)((n_lut + 3) & ~3) * sizeof(float), st);

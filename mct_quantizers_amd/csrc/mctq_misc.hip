@@ -21,7 +21,6 @@ int g_ql_variant = 0;
 int g_ql_band = 0;
 int g_ql_stagger = 0;         // tiled consumer kernel: half of the waves copy after multiplying (experiment: no gain)
 int g_ql_rot = 0;            // tiled consumer kernel: blocks that share a weight tile start at different K offsets (experiment: no gain)
-int g_heavy_persistent = 0;   // one tile per block measured 5% faster than persistent blocks (profiles/r01)
 
 static const char* launch_log_path() {
   const char* p = getenv("MCTQ_LAUNCH_LOG");
@@ -129,7 +128,7 @@ const char* mctq_build_id(void) {
 int mctq_set_tuning(const char* key, int32_t value) {
   if (!key) return fail_arg("key is NULL");
   if (!strcmp(key, "nt")) {
-    if (value != 0 && value != 1 && value != 2) return fail_arg("nt must be 0, 1 or 2");
+    if (value != 1 && value != 2) return fail_arg("nt must be 1 or 2");
     g_nt = value;
     return 0;
   }
@@ -139,13 +138,13 @@ int mctq_set_tuning(const char* key, int32_t value) {
     return 0;
   }
   if (!strcmp(key, "unroll")) {
-    if (value != 1 && value != 2 && value != 4 && value != 8) return fail_arg("unroll must be 1, 2, 4 or 8");
+    if (value != 1 && value != 2 && value != 4) return fail_arg("unroll must be 1, 2 or 4");
     g_unroll = value;
     return 0;
   }
   if (!strcmp(key, "heavy_unroll")) {
-    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-      return fail_arg("heavy_unroll must be 0, 1, 2, 4 or 8");
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail_arg("heavy_unroll must be 0, 1, 2 or 4");
     g_heavy_unroll = value;
     return 0;
   }
@@ -154,17 +153,12 @@ int mctq_set_tuning(const char* key, int32_t value) {
     g_rowsteps = value;
     return 0;
   }
-  if (!strcmp(key, "heavy_persistent")) {
-    if (value != 0 && value != 1) return fail_arg("heavy_persistent must be 0 or 1");
-    g_heavy_persistent = value;
-    return 0;
-  }
   if (!strcmp(key, "ql_variant")) {
-    static const int ok[] = {0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 141, 142, 144, 1212, 612, 66, 662, 12122, 2588, 2548, 2584, 2544, 2560, 3448, 3486, 3846, 4442,
-                             6623, 6624, 663, 664, 666, 6123, 6124, 12123, 12124, 12623, 12622, 12613, 12614, 3263, 3262, 6433, 3233, 86623, 86622, 86633, 86433, 83233, 812613, 812123, 812122, 1612122, 1612623, 1612622, 166623};   // <tile code><ring stages> of the tiled kernel
+    // 0 = automatic; otherwise one of the kernels the automatic choice can select (csrc/mctq_qlinear.hip: qlinear_dispatch)
+    static const int ok[] = {0, 181, 182, 184, 83233, 86433, 166623, 86633, 812613, 1612623, 612, 1212, 662, 2544, 2548, 2560};
     bool found = false;
     for (int v : ok) found = found || v == value;
-    if (!found) return fail_arg("ql_variant must be 0 (automatic) or one of the launch-variant codes listed in mctq_misc.hip (streaming 41 ... 184, tiles 66 ... 12124, 8- / 16-wave tiles 8xxxx / 16xxxxx, wide tiles 25xx ... 4442)");
+    if (!found) return fail_arg("ql_variant must be 0 (automatic) or one of 181 182 184 (streaming), 83233 86433 86633 812613 (8-wave ring tiles), 166623 1612623 (16-wave), 612 1212 662 (two-buffer tiles), 2544 2548 (wide), 2560 (ping-pong)");
     g_ql_variant = value;
     return 0;
   }

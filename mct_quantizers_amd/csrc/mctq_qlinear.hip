@@ -1045,111 +1045,42 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
   const bool u8 = a_code_dtype == MCTQ_CODE_U8;
   const int za = u8 ? a_zero_point - 128 : a_zero_point;
   const hipStream_t s = (hipStream_t)stream;
-#define MCTQ_QL(W_, MT_)                                                                                         \
-  (u8 ? launch_qlinear<W_, MT_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)    \
-      : launch_qlinear<W_, MT_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-  switch (g_ql_variant) {                           // experiments (mctq_set_tuning "ql_variant")
-    case 81: return MCTQ_QL(8, 1);
-    case 82: return MCTQ_QL(8, 2);
-    case 84: return MCTQ_QL(8, 4);
-    case 41: return MCTQ_QL(4, 1);
-    case 42: return MCTQ_QL(4, 2);
-    case 44: return MCTQ_QL(4, 4);
-    default: break;
-  }
 #define MCTQ_QLL(W_, MT_)                                                                                          \
   (u8 ? launch_qlinear_lds<W_, MT_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s) \
       : launch_qlinear_lds<W_, MT_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-  switch (g_ql_variant) {                           // LDS-staged activations: 1<waves><row tiles>
-    case 181: return MCTQ_QLL(8, 1);
-    case 182: return MCTQ_QLL(8, 2);
-    case 184: return MCTQ_QLL(8, 4);
-    case 141: return MCTQ_QLL(4, 1);
-    case 142: return MCTQ_QLL(4, 2);
-    case 144: return MCTQ_QLL(4, 4);
-    default: break;
-  }
 #define MCTQ_QG(BM_, BN_, BK_)                                                                                    \
   (u8 ? launch_glds<BM_, BN_, BK_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
 #define MCTQ_QW(TM_, TN_)                                                                                         \
   (u8 ? launch_wide<TM_, TN_, true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)      \
       : launch_wide<TM_, TN_, false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-#define MCTQ_QWS(TM_, TN_, S_)                                                                                    \
-  (u8 ? launch_wide<TM_, TN_, true, S_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
-      : launch_wide<TM_, TN_, false, S_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-#define MCTQ_QWO(TM_, TN_, S_, OCC_)                                                                                 \
-  (u8 ? launch_wide<TM_, TN_, true, S_, OCC_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
-      : launch_wide<TM_, TN_, false, S_, OCC_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-  if (g_ql_variant == 4442) return MCTQ_QWO(4, 4, 4, 2);     // 128 x 128 tiles, two blocks per CU
-  switch (g_ql_variant) {                            // deeper rings: 3<TM><TN><stages>
-    case 3448: return MCTQ_QWS(4, 4, 8);
-    case 3486: return MCTQ_QWS(4, 8, 6);
-    case 3846: return MCTQ_QWS(8, 4, 6);
-    default: break;
-  }
-  switch (g_ql_variant) {
-    case 2588: return MCTQ_QW(8, 8);
-    case 2548: return MCTQ_QW(4, 8);
-    case 2584: return MCTQ_QW(8, 4);
-    case 2544: return MCTQ_QW(4, 4);
-    case 2560: return u8 ? launch_pp<true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)
-                         : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
-    default: break;
-  }
-#define MCTQ_QGR(BM_, BN_, BK_, ST_)                                                                                   \
-  (u8 ? launch_glds<BM_, BN_, BK_, true, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
-      : launch_glds<BM_, BN_, BK_, false, ST_>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
 #define MCTQ_QG16(BM_, BN_, BK_, ST_)                                                                                      \
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_, 4>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_, 4>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-  switch (g_ql_variant) {                            // 16-wave blocks (four wave groups): 16<tile code><stages>
-    case 1612122: return MCTQ_QG16(128, 128, 256, 2);
-    case 1612623: return MCTQ_QG16(128, 64, 256, 3);
-    case 1612622: return MCTQ_QG16(128, 64, 256, 2);
-    case 166623: return MCTQ_QG16(64, 64, 256, 3);
-    default: break;
-  }
 #define MCTQ_QG8(BM_, BN_, BK_, ST_)                                                                                       \
   (u8 ? launch_glds<BM_, BN_, BK_, true, ST_, 2>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)  \
       : launch_glds<BM_, BN_, BK_, false, ST_, 2>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
-  switch (g_ql_variant) {                            // 8-wave blocks (two wave groups): 8<tile code><stages>
-    case 86623: return MCTQ_QG8(64, 64, 256, 3);
-    case 86622: return MCTQ_QG8(64, 64, 256, 2);
-    case 86633: return MCTQ_QG8(64, 64, 128, 3);
-    case 86433: return MCTQ_QG8(64, 32, 256, 3);
-    case 83233: return MCTQ_QG8(32, 32, 256, 3);
-    case 812613: return MCTQ_QG8(128, 64, 128, 3);
-    case 812123: return MCTQ_QG8(128, 128, 128, 3);
-    case 812122: return MCTQ_QG8(128, 128, 128, 2);
-    default: break;
-  }
-  switch (g_ql_variant) {                            // rings of the tiled kernel: <tile code><stages>
-    case 3263: return MCTQ_QGR(32, 64, 256, 3);
-    case 3262: return MCTQ_QGR(32, 64, 256, 2);
-    case 6433: return MCTQ_QGR(64, 32, 256, 3);
-    case 3233: return MCTQ_QGR(32, 32, 256, 3);
-    case 12623: return MCTQ_QGR(128, 64, 256, 3);
-    case 12622: return MCTQ_QGR(128, 64, 256, 2);
-    case 12613: return MCTQ_QGR(128, 64, 128, 3);
-    case 12614: return MCTQ_QGR(128, 64, 128, 4);
-    case 6623: return MCTQ_QGR(64, 64, 256, 3);
-    case 6624: return MCTQ_QGR(64, 64, 256, 4);
-    case 663: return MCTQ_QGR(64, 64, 128, 3);
-    case 664: return MCTQ_QGR(64, 64, 128, 4);
-    case 666: return MCTQ_QGR(64, 64, 128, 6);
-    case 6123: return MCTQ_QGR(64, 128, 128, 3);
-    case 6124: return MCTQ_QGR(64, 128, 128, 4);
-    case 12123: return MCTQ_QGR(128, 128, 128, 3);
-    case 12124: return MCTQ_QGR(128, 128, 128, 4);
-    default: break;
-  }
+#define MCTQ_QPP()                                                                                                    \
+  (u8 ? launch_pp<true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)                      \
+      : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s))
+  // tuning key "ql_variant": force ONE of the kernels the automatic choice below can select (tests run each of them over
+  // ragged shapes against the integer oracle); the experiment variants of round 3 are not built any more
   switch (g_ql_variant) {
+    case 181: return MCTQ_QLL(8, 1);                  // weight streaming, activation codes through per-wave LDS: 16 / 32 / 64 rows per pass
+    case 182: return MCTQ_QLL(8, 2);
+    case 184: return MCTQ_QLL(8, 4);
+    case 83233: return MCTQ_QG8(32, 32, 256, 3);      // 8-wave blocks (two wave groups), ring of three LDS buffers
+    case 86433: return MCTQ_QG8(64, 32, 256, 3);
+    case 86633: return MCTQ_QG8(64, 64, 128, 3);
+    case 812613: return MCTQ_QG8(128, 64, 128, 3);
+    case 166623: return MCTQ_QG16(64, 64, 256, 3);    // 16-wave blocks (four wave groups)
+    case 1612623: return MCTQ_QG16(128, 64, 256, 3);
+    case 612: return MCTQ_QG(64, 128, 128);           // 4-wave blocks, two LDS buffers
     case 1212: return MCTQ_QG(128, 128, 128);
-    case 612: return MCTQ_QG(64, 128, 128);
-    case 66: return MCTQ_QG(64, 64, 128);
     case 662: return MCTQ_QG(64, 64, 256);
-    case 12122: return MCTQ_QG(128, 128, 256);
+    case 2544: return MCTQ_QW(4, 4);                  // wave-wide 128 x 128 / 128 x 256 tiles
+    case 2548: return MCTQ_QW(4, 8);
+    case 2560: return MCTQ_QPP();                     // 256 x 256 ping-pong tiles
     default: break;
   }
   const int64_t cus = cu_count();
@@ -1165,9 +1096,7 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     const double old_rate = 1.5 * fill(blocks(128, 128), 2 * cus);
     const double pp_rate = M % 256 == 0 ? 2.25 * fill(blocks(256, 256), cus) : 0.0;
     const double w48_rate = 2.0 * fill(blocks(128, 256), cus);
-    if (pp_rate >= w48_rate && pp_rate > old_rate)
-      return u8 ? launch_pp<true>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s)
-                : launch_pp<false>(a_codes, w_codes, w_scales, w_rowsum, bias, y, M, N, K, za, a_scale, oq, s);
+    if (pp_rate >= w48_rate && pp_rate > old_rate) return MCTQ_QPP();
     if (w48_rate > old_rate) return MCTQ_QW(4, 8);
   }
   // Between the two regimes every kernel runs at the CU's intake of direct-to-LDS copies, an issue rate: about 36 KiB/us
@@ -1225,11 +1154,10 @@ static int qlinear_dispatch(const void* a_codes, int32_t a_code_dtype, int32_t a
     }
   }
 #undef MCTQ_QG
-#undef MCTQ_QGR
 #undef MCTQ_QG8
 #undef MCTQ_QG16
 #undef MCTQ_QW
-#undef MCTQ_QL
+#undef MCTQ_QPP
 #undef MCTQ_QLL
 }
 

@@ -19,10 +19,13 @@ import sys
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("mctq_misc.hip", "mctq_affine.hip", "mctq_codes.hip", "mctq_lut_scan.hip",
-                                             "mctq_lut_table.hip", "mctq_lut_compact.hip", "mctq_grid.hip", "mctq_qlinear.hip", "mctq_codes4.hip", "mctq_codes_nhwc.hip", "mctq_batched.hip", "mctq_f64.hip", "mctq_lut_steps.hip")]
+# slowest translation units first (they are started in this order; the build's critical path is mctq_batched_lut.hip, ~35 s)
+SOURCES = [os.path.join(CSRC, f) for f in ("mctq_batched_lut.hip", "mctq_lut_steps.hip", "mctq_lut_table.hip", "mctq_lut_scan.hip",
+                                             "mctq_qlinear.hip", "mctq_batched.hip", "mctq_affine.hip", "mctq_codes.hip",
+                                             "mctq_f64.hip", "mctq_grid.hip", "mctq_codes4.hip", "mctq_codes_nhwc.hip",
+                                             "mctq_misc.hip")]
 HEADERS = [os.path.join(REPO, "include", "mctq_hip.h"), os.path.join(CSRC, "mctq_kernels.hpp"),
-           os.path.join(CSRC, "mctq_table_builder.h")]
+           os.path.join(CSRC, "mctq_table_builder.h"), os.path.join(CSRC, "mctq_batched.hpp")]
 OUT = os.path.join(PKG, "lib", "libmctq_hip.so")
 BINDING_SRC = os.path.join(CSRC, "binding", "mctq_torch.cpp")
 BINDING_OUT = os.path.join(PKG, "lib", "_mctq_torch.so")
@@ -73,7 +76,7 @@ def _digest(paths, extra=()) -> str:
 
 def tree_build_id() -> str:
     """Hash of the kernel sources, the headers and the compiler flags as they are in the tree now."""
-    return _digest(SOURCES + HEADERS, FLAGS)
+    return _digest(sorted(SOURCES) + HEADERS, FLAGS)
 
 
 def embedded_id(path: str, marker: bytes = ID_MARKER):
@@ -134,8 +137,9 @@ def _build(verbose: bool, force: bool = False) -> str:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
         os.replace(obj + ".tmp", obj)
+    keep.add("mctq_torch.binding.o")                 # the binding's object (build_all compiles it beside these jobs)
     for name in os.listdir(objdir):                  # objects of earlier source versions
-        if name not in keep:
+        if name not in keep and not name.endswith(".tmp"):
             os.remove(os.path.join(objdir, name))
     tmp = OUT + ".tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
@@ -178,33 +182,81 @@ def build_binding(force: bool = False, verbose: bool = True) -> str:
         return _build_binding(verbose)
 
 
-def _build_binding(verbose: bool) -> str:
+def _binding_compile_cmd(obj: str):
+    """g++ -c of the binding (the slow part: torch's headers); needs no library, so it can run beside the hipcc jobs."""
     import sysconfig
     import torch
     tdir = os.path.dirname(torch.__file__)
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("g++ not found; cannot build the compiled binding")
+    flags = [f for f in _binding_flags() if f != "-shared"]
+    return [cxx, *flags, '-DMCTQ_BINDING_ID="%s"' % binding_build_id(),
+            "-I", os.path.join(REPO, "include"), "-I", os.path.join(tdir, "include"),
+            "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
+            "-I", sysconfig.get_paths()["include"], "-c", BINDING_SRC, "-o", obj]
+
+
+def _binding_link(obj: str, verbose: bool) -> str:
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    cxx = shutil.which("g++") or shutil.which("c++")
     tmp = BINDING_OUT + ".tmp"
-    bid = binding_build_id()
-    cmd = [cxx, *_binding_flags(), '-DMCTQ_BINDING_ID="%s"' % bid,
-           "-I", os.path.join(REPO, "include"), "-I", os.path.join(tdir, "include"),
-           "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
-           "-I", sysconfig.get_paths()["include"], BINDING_SRC, "-o", tmp,
-           "-L", os.path.join(tdir, "lib"), "-L", os.path.dirname(OUT),
+    cmd = [cxx, "-shared", "-fPIC", obj, "-o", tmp, "-L", os.path.join(tdir, "lib"), "-L", os.path.dirname(OUT),
            "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python", "-lmctq_hip",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tdir, "lib")]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    bid = binding_build_id()
     if embedded_id(tmp, BINDING_ID_MARKER) != bid:
         raise RuntimeError(f"{tmp} does not carry binding id {bid}")
     os.replace(tmp, BINDING_OUT)
     return BINDING_OUT
 
 
+def _build_binding(verbose: bool) -> str:
+    objdir = os.path.join(os.path.dirname(OUT), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, "mctq_torch.binding.o")
+    cmd = _binding_compile_cmd(obj)
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return _binding_link(obj, verbose)
+
+
+def build_all(force: bool = False, verbose: bool = True):
+    """Library + binding, the binding's compile step running beside the hipcc jobs (a clean build is then as long as the
+    slowest translation unit + two link steps: ~45 s on 8 cores).  Returns (library path, binding path, seconds)."""
+    import time
+    t0 = time.time()
+    with _build_lock():
+        lib_needed = force or needs_build()
+        bind_needed = force or binding_needs_build()
+        proc = obj = None
+        if bind_needed:
+            objdir = os.path.join(os.path.dirname(OUT), "obj")
+            os.makedirs(objdir, exist_ok=True)
+            obj = os.path.join(objdir, "mctq_torch.binding.o")
+            cmd = _binding_compile_cmd(obj)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            proc = subprocess.Popen(cmd)
+        try:
+            if lib_needed:
+                _build(verbose, force)
+        finally:
+            rc = proc.wait() if proc is not None else 0
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, "g++ (binding)")
+        if bind_needed:
+            _binding_link(obj, verbose)
+    return OUT, BINDING_OUT, time.time() - t0
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
-    build_binding(force="--force" in sys.argv)
-    print(BINDING_OUT)
+    lib, binding, seconds = build_all(force="--force" in sys.argv)
+    print(lib)
+    print(binding)
+    print(f"{seconds:.1f} s")

@@ -14,7 +14,7 @@ import ctypes
 import os
 import threading
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
 CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
 FQ_ITEM_PER_TENSOR = 1
@@ -100,15 +100,6 @@ SIGNATURES = {
                                             ctypes.c_float, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mctq_lutt_per_channel": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
-                                             ctypes.c_int32, _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32,
-                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
-    "mctq_lut_compact_words": (ctypes.c_int32, [ctypes.c_float, ctypes.c_float, ctypes.c_int32]),
-    "mctq_lut_build_compact": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
-                                              ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
-    "mctq_lutc_per_tensor": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
-                                            ctypes.c_float, ctypes.c_float, _c_f32p, ctypes.c_int32, ctypes.c_float,
-                                            ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
-    "mctq_lutc_per_channel": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int32, _c_f32p, ctypes.c_float, _c_f32p, ctypes.c_int32,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mctq_grid_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
@@ -353,24 +344,6 @@ def build_lut_table(lut_values, mult: float, clip_min: float, clip_max: float):
     if rc != 0:
         return None
     return table
-
-
-def build_lut_compact(lut_values, mult: float, clip_min: float, clip_max: float):
-    """Host-side compact decision table (numpy float32 [n_words] holding the blob's 32-bit words bit for bit: see
-    include/mctq_hip.h, mctq_lut_build_compact), or None when the codebook has no decision table / too many steps."""
-    import numpy as np
-    lib = load()
-    lut = np.ascontiguousarray(np.asarray(lut_values, dtype=np.float32).reshape(-1))
-    cap = lib.mctq_lut_compact_words(clip_min, clip_max, lut.size)
-    if cap < 0:
-        return None
-    blob = np.zeros(cap, dtype=np.uint32)
-    n_words = ctypes.c_int32(0)
-    rc = lib.mctq_lut_build_compact(lut.ctypes.data, lut.size, mult, clip_min, clip_max, blob.ctypes.data,
-                                    ctypes.addressof(n_words))
-    if rc != 0:
-        return None
-    return blob[:n_words.value].copy().view(np.float32)
 
 
 # ------------------------------------------------------------------------------------------

@@ -306,7 +306,7 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
     if dt != native.DT_F64 and table is not None and native.TRACE is False:
         f = _FAST if _FAST_READY else _fast_mod()
         if f is not None:
-            y = f.lutt_per_tensor(x, _compact_of(table, x), step_round, thr_div, thr_mul, mult, cmin, cmax)
+            y = f.lutt_per_tensor(x, table, step_round, thr_div, thr_mul, mult, cmin, cmax)
             if y is not NotImplemented:
                 return y if x.is_contiguous() else y.contiguous()      # see _lut_result
     lib = native.load()
@@ -329,10 +329,6 @@ def _hip_lut_per_tensor(x, lut, thr_div: float, thr_mul: float, mult: float, cmi
             else:
                 rc = _launch(lib.mctq_lut_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, 0, thr_div, thr_mul,
                              lut.data_ptr(), lut.numel(), mult, cmin, cmax, _stream(x))
-        elif table is not None and _compact_of(table, x) is not table:
-            blob = _compact_of(table, x)
-            rc = _launch(lib.mctq_lutc_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
-                         blob.data_ptr(), blob.numel(), mult, cmin, cmax, _stream(x))
         elif table is not None:
             table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_tensor, x.data_ptr(), y.data_ptr(), x.numel(), dt, step_round, thr_div, thr_mul,
@@ -361,7 +357,7 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
     if dt != native.DT_F64 and table is not None and native.TRACE is False:
         f = _FAST if _FAST_READY else _fast_mod()
         if f is not None:
-            y = f.lutt_per_channel(x, thresholds, eps, _compact_of(table, x), axis, mult, cmin, cmax)
+            y = f.lutt_per_channel(x, thresholds, eps, table, axis, mult, cmin, cmax)
             if y is not NotImplemented:
                 return y if x.is_contiguous() else y.contiguous()      # see _lut_result
     lib = native.load()
@@ -376,10 +372,6 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
         if s64 is not None:
             rc = _launch(lib.mctq_luts_per_channel_f64, x.data_ptr(), y.data_ptr(), outer, c, inner, thresholds.data_ptr(),
                          eps, s64[0].data_ptr(), s64[1], mult, cmin, cmax, _stream(x))
-        elif table is not None and dt != native.DT_F64 and _compact_of(table, x) is not table:
-            blob = _compact_of(table, x)
-            rc = _launch(lib.mctq_lutc_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
-                         eps, blob.data_ptr(), blob.numel(), mult, cmin, cmax, _stream(x))
         elif table is not None and dt != native.DT_F64:
             table = _param_on(x, table, "table", torch.float32)
             rc = _launch(lib.mctq_lutt_per_channel, x.data_ptr(), y.data_ptr(), outer, c, inner, dt, thresholds.data_ptr(),
@@ -552,24 +544,7 @@ def make_lut_table(lut_values, mult: float, cmin: float, cmax: float, device):
     table = native.build_lut_table(lut_values, mult, cmin, cmax)
     if table is None:
         return None
-    t = torch.from_numpy(table).to(device)
-    # (MCTQ_COMPACT_LUT=1) the same table in its compact form rides on the tensor object: single-tensor launches take it,
-    # the batched table launches keep the full form
-    compact = native.build_lut_compact(lut_values, mult, cmin, cmax) if USE_COMPACT_LUT else None
-    if compact is not None:
-        t._mctq_compact = torch.from_numpy(compact).to(device)
-    return t
-
-
-# 1: single-tensor LUT launches stage the compact form of the decision table (648 B instead of 4 KB per block).  Off by
-# default: measured equal to the full table under bench.py's cold protocol (profiles/r04/cfg4_lut_experiments.md)
-USE_COMPACT_LUT = os.environ.get("MCTQ_COMPACT_LUT", "0") not in ("", "0")
-
-
-def _compact_of(table, x):
-    """The compact blob riding on a decision-table tensor, when it lives on x's device."""
-    c = table.__dict__.get("_mctq_compact") if table is not None else None
-    return c if c is not None and c.device == x.device else table
+    return torch.from_numpy(table).to(device)
 
 
 def make_lut_steps(lut_values, mult: float, cmin: float, cmax: float, device):

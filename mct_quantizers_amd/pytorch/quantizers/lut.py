@@ -246,7 +246,7 @@ class ActivationLutPOTInferableQuantizer(BaseLUTSymmetricInferableQuantizer):
         exact = all(b == (cmin, cmax) for b in self._clip_by_dtype.values())
         if fast is not None:
             d = self._thr_div_by_dtype
-            plan = fast.LutPlan(getattr(self._lut_table_torch, "_mctq_compact", self._lut_table_torch), d[torch.float32], d[torch.float16], d[torch.bfloat16],
+            plan = fast.LutPlan(self._lut_table_torch, d[torch.float32], d[torch.float16], d[torch.bfloat16],
                                 self._thr_mul0, mult, cmin, cmax, 1 if exact else 2)
         self.__dict__["_plan"] = plan
         self.__dict__["_stale"] = False

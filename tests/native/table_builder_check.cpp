@@ -29,49 +29,6 @@ static int check(const std::vector<float>& lut, float mult, float cmin, float cm
   return bad != 0;
 }
 
-// compact table: cell byte -> step entry -> one comparison equals the literal scan (and therefore the full table) on a dense
-// sweep around every half-unit point, around every step's threshold and on a grid; `expect_fail`: codebooks with more than
-// 255 steps must be refused
-static int check_compact(const std::vector<float>& lut, float mult, float cmin, float cmax, bool expect_fail = false) {
-  const int K = mctq_tb::table_entries(cmin, cmax);
-  if (K < 0) return 1;
-  std::vector<uint32_t> blob(mctq_tb::compact_words_for(K, (int)lut.size()) + 8, 0xdeadbeefu);
-  int nw = 0;
-  const char* err = mctq_tb::build_compact(lut.data(), (int)lut.size(), mult, cmin, cmax, blob.data(), &nw);
-  if (expect_fail) { if (!err) printf("compact: accepted a codebook it must refuse\n"); return err ? 0 : 1; }
-  if (err) { printf("build_compact: %s\n", err); return 1; }
-  if (nw > mctq_tb::compact_words_for(K, (int)lut.size()) || blob[nw] != 0xdeadbeefu) { printf("compact: size\n"); return 1; }
-  const int CW = mctq_tb::compact_cell_words(K);
-  const uint8_t* cell = reinterpret_cast<const uint8_t*>(blob.data());
-  const uint32_t* step = blob.data() + CW;
-  float pf; memcpy(&pf, &blob[nw - 1], 4);
-  const int P = (int)pf;
-  if (nw != CW + 2 * (P + 1) + 2) { printf("compact: n_words\n"); return 1; }
-  auto model = [&](float t) {
-    const float kf = t * 2.0f + (0.5f - 2.0f * cmin);       // (the kernel's fma: exact here, |t| small)
-    int k = (int)(kf < 0.0f ? 0.0f : (kf > (float)(K - 1) ? (float)(K - 1) : kf));
-    const int j = cell[k];
-    float T; memcpy(&T, &step[2 * j], 4);
-    const uint32_t pair = step[2 * j + 1];
-    return mctq_tb::f16_to_f32((uint16_t)((t >= T) ? (pair >> 16) : (pair & 0xffffu)));
-  };
-  long bad = 0;
-  auto probe = [&](float t) { if (t >= cmin && t <= cmax && model(t) != mctq_tb::literal(t, lut.data(), (int)lut.size()) / mult) ++bad; };
-  for (int k = 0; k < K; ++k) {
-    const float Pk = cmin + 0.5f * (float)k;
-    for (int d = -60; d <= 60; ++d) probe(mctq_tb::ord2f(mctq_tb::f2ord(Pk) + (uint32_t)d));
-    for (int d = -3; d <= 3; ++d) probe(mctq_tb::ord2f(mctq_tb::f2ord(Pk + 0.25f) + (uint32_t)d));      // cell borders
-  }
-  for (int j = 0; j < P; ++j) {
-    float T; memcpy(&T, &step[2 * j], 4);
-    for (int d = -200; d <= 200; ++d) probe(mctq_tb::ord2f(mctq_tb::f2ord(T) + (uint32_t)d));
-  }
-  const double span = (double)cmax - (double)cmin;
-  for (int i = 0; i <= 400000; ++i) probe((float)((double)cmin + span * i / 400000.0));
-  if (bad) printf("compact: %ld mismatches\n", bad);
-  return bad != 0;
-}
-
 // threshold list: the binary search over T equals the literal scan around every threshold and on a coarse sweep
 static int check_steps(const std::vector<float>& lut, float mult, float cmin, float cmax) {
   std::vector<float> steps(mctq_tb::steps_words_for((int)lut.size()));
@@ -171,16 +128,6 @@ int main() {
   rc |= check(wide, 512, -512, 511);
   std::vector<float> all; for (int v = 127; v >= -128; --v) all.push_back((float)((v * 37) % 256 - 128 + ((v * 37) % 256 < 0 ? 256 : 0)));
   rc |= check(all, 128, -128, 127);
-  rc |= check_compact({-5, 5}, 128, -128, 127);
-  rc |= check_compact({3, 3, -8}, 128, -128, 127);
-  rc |= check_compact({7}, 128, -128, 127);
-  rc |= check_compact({22, -53, 62, 0, -66, -21, 44, -40}, 128, -128, 127);
-  rc |= check_compact({-128, -96, -64, -40, -24, -12, -5, 0, 5, 12, 24, 40, 64, 96, 120, 127}, 128, -128, 127);
-  rc |= check_compact({0, 13, 50, 90, 128, 200, 255, 256}, 256, 0, 255);
-  rc |= check_compact(wide, 512, -512, 511);
-  rc |= check_compact(all, 128, -128, 127);                                              // 256 centres = 255 steps: the limit
-  { std::vector<float> many; for (int v = -512; v < 512; v += 2) many.push_back((float)v);
-    rc |= check_compact(many, 512, -512, 511, true); }                                   // 511 steps: refused
   float bad_lut[2] = {0.5f, 1.0f}; float tmp[8];
   if (!mctq_tb::build(bad_lut, 2, 128, -128, 127, tmp)) { printf("non-integer codebook accepted\n"); rc = 1; }
   rc |= check_steps({-5, 5}, 2048, -2048, 2047);

@@ -775,18 +775,23 @@ def test_a_launch_bumps_the_version_of_the_persistent_outputs_so_autograd_sees_t
     """the batched launch rewrites the quantized weights in place.  A forward whose graph saved such a weight,
     followed by a weight update and another forward, must fail its backward with autograd's in-place error (as any in-place
     write would) instead of silently using the newer values."""
-    model = mq.accelerate(_small_model("cuda").eval())
+    torch.manual_seed(5)
+    conv = nn.Conv2d(3, 8, 3).cuda()
+    thr = [float(v) for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
+    model = nn.Sequential(mq.PytorchQuantizationWrapper(conv, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)}))
+    mq.accelerate(model.eval())                                                 # (no holder behind it: holders cut the graph)
+    wrapper = model[0]
     x = torch.randn(2, 3, 10, 10, device="cuda", requires_grad=True)
-    w_q_version = None
     out1 = model(x).sum()
-    w_q = model.conv.layer.weight
+    assert out1.grad_fn is not None
+    w_q = wrapper.layer.weight
     w_q_version = w_q._version
     with torch.no_grad():
-        model.conv.weight.add_(0.25)
+        wrapper.weight.add_(0.25)
     model(x)                                                                    # rewrites the same tensor in place
-    assert model.conv.layer.weight is w_q and w_q._version > w_q_version
+    assert wrapper.layer.weight is w_q and w_q._version > w_q_version
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
-        out1.backward()
+        out1.backward()                                                         # grad wrt x needs the weight out1 was computed with
     x.grad = None
     out2 = model(x).sum()                                                       # a forward followed by its own backward is fine
     out2.backward()

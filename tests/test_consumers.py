@@ -148,9 +148,9 @@ def _run_kernel(lib, native, a, u8, za, sa, w, ws, bias):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 41, 42, 44, 81, 82, 84, 181, 182, 184, 142, 144, 1212, 612, 66, 662, 12122,
-                                     6623, 6624, 663, 664, 666, 6123, 6124, 12123, 12124, 12623, 12622, 12613, 12614, 3263, 3262, 6433, 3233,
-                                     86623, 86622, 86633, 86433, 83233, 812613, 812123, 812122, 1612122, 1612623, 1612622, 166623])
+@pytest.mark.parametrize("variant", [0, 181, 182, 184, 83233, 86433, 86633, 812613, 166623, 1612623, 612, 1212, 662])      # every
+# kernel the automatic choice can select for ragged shapes (ABI v8: only those are built; the whole-tile kernels 2544 / 2548 /
+# 2560 have their own test below)
 def test_qlinear_kernel_is_bit_exact_against_the_integer_oracle(variant):
     from oracle import mctq_oracle as O
     from mct_quantizers_amd.hip import native
@@ -308,7 +308,7 @@ def test_chained_consumers_pass_codes_between_layers_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [2560, 2588, 2548, 2584, 0])
+@pytest.mark.parametrize("variant", [2560, 2548, 2544, 0])
 def test_dense_tile_kernels_are_bit_exact_and_requantize(variant):
     """Whole-tile shapes of the many-rows kernels (256 x 256 ping-pong, wave-wide 256 x 256 / 128 x 256 / 256 x 128):
     exact against the int64 oracle for int8 and uint8 activation codes (extreme codes at the longest K included), the

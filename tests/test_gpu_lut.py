@@ -1,7 +1,7 @@
 """GPU parity of the LUT quantizers beyond test_gpu_parity.py: the literal scan on half inputs, the sorted threshold list
 (wide codebooks) against the literal scan for ALL 2^32 inputs and against the oracle, the quantizer classes' choice of
 kernel, fuzz over shapes / axes / layouts / dtypes / codebook widths, the clip bounds of half-precision activations,
-attribute assignment, integer tensors.  (Compact table: test_gpu_lut_compact.py; float64 lists: test_lut_f64_steps.py.)"""
+attribute assignment, integer tensors.  (float64 lists: test_lut_f64_steps.py.)"""
 import hashlib
 import json
 import os
@@ -278,8 +278,7 @@ def test_fuzz_lut_quantizers_shapes_axes_layouts_dtypes_and_codebook_widths(lib)
             w = O.lut_quantize(x.numpy(), lut, thr_o, signed, B, 1e-8, per_channel=(kind == 0),
                                channel_axis=(axis if kind == 0 else None))
             assert bits_equal(got.cpu().numpy(), w), info
-    table = "LutCompactOp" if os.environ.get("MCTQ_COMPACT_LUT", "0") not in ("", "0") else "LutTableOp"    # soak runs with the compact form
-    assert {table, "LutStepsOp"} <= seen, seen
+    assert {"LutTableOp", "LutStepsOp"} <= seen, seen
 
 
 def test_half_activation_lut_clip_bounds_follow_the_tensor_type(lib):

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Timing-experiment builds of libmctq_hip.so: the listed translation units recompiled with extra -D switches
-(MCTQ_ABLATE_* in csrc/mctq_kernels.hpp: results are WRONG by construction), everything else linked from the regular
-build's objects.  Output: tools/ablate/libmctq_hip_<NAME>.so (git-ignored, travels to the GPU box); run with
+"""Experiment builds of libmctq_hip.so: the listed translation units recompiled with extra -D switches, and / or the
+experiment translation units under tools/experiments/ added, everything else linked from the regular build's objects.
+Output: tools/ablate/libmctq_hip_<NAME>.so (git-ignored, travels to the GPU box); run with
     MCTQ_HIP_LIB=tools/ablate/libmctq_hip_<NAME>.so MCTQ_BINDING=ctypes python tools/...
-Usage: python tools/build_variant.py NAME -DFLAG [-DFLAG ...] [--units a.hip,b.hip]"""
+Usage: python tools/build_variant.py NAME [-DFLAG ...] [--units=a.hip,b.hip]
+       python tools/build_variant.py lut_compact          (regular objects + tools/experiments/lut_compact/mctq_lut_compact.hip)"""
 import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -11,6 +12,10 @@ from mct_quantizers_amd.hip import build as B
 
 def main():
     name, defs, units = sys.argv[1], [a for a in sys.argv[2:] if a.startswith("-D")], ["mctq_lut_table.hip"]
+    extra = []
+    if name == "lut_compact":
+        units, xdir = [], os.path.join(REPO, "tools", "experiments", "lut_compact")
+        extra = [(os.path.join(xdir, "mctq_lut_compact.hip"), ["-I", xdir])]
     for a in sys.argv[2:]:
         if a.startswith("--units"):
             units = a.split("=", 1)[1].split(",")
@@ -31,6 +36,12 @@ def main():
         else:
             obj = os.path.join(objdir, f"{base}.{B._digest([src] + B.HEADERS, B.FLAGS + stamp)}.o")
             assert os.path.exists(obj), obj
+        objs.append(obj)
+    for src, inc in extra:
+        obj = os.path.join(out_dir, "obj_" + name, os.path.basename(src) + ".o")
+        cmd = ["hipcc", *B.FLAGS, *defs, "-I", os.path.join(REPO, "include"), "-I", B.CSRC, *inc, "-c", "-o", obj, src]
+        print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
         objs.append(obj)
     assert all(p.wait() == 0 for p in procs)
     out = os.path.join(out_dir, f"libmctq_hip_{name}.so")

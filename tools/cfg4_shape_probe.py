@@ -24,11 +24,10 @@ t0 = time.perf_counter()
 while time.perf_counter() - t0 < 1.0:          # clocks up before the first variant is timed
     for i in range(20): qlut(xs[i % ring])
     torch.cuda.synchronize()
-for pers in (0, 1):
-    for hu in (0, 1, 2, 4, 8):
-        native.set_tuning("heavy_persistent", pers); native.set_tuning("heavy_unroll", hu)
-        us = timeit(qlut); print(f"LUT table kernel heavy_persistent={pers} heavy_unroll={hu}: {us:7.2f} us {nbytes/us/1e3:6.0f} GB/s  {native.last_launch()}", flush=True)
-native.set_tuning("heavy_persistent", 0); native.set_tuning("heavy_unroll", 0)
+for hu in (0, 1, 2, 4):
+    native.set_tuning("heavy_unroll", hu)
+    us = timeit(qlut); print(f"LUT table kernel heavy_unroll={hu}: {us:7.2f} us {nbytes/us/1e3:6.0f} GB/s  {native.last_launch()}", flush=True)
+native.set_tuning("heavy_unroll", 0)
 thr = wl.kwargs["threshold"]
 qa = Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)
 for u in (1, 2, 4):

@@ -1,6 +1,8 @@
-// mctq_lut_compact.hip -- part of libmctq_hip.so (C ABI: include/mctq_hip.h); kernels: mctq_kernels.hpp (LutCompactOp)
-#include "mctq_kernels.hpp"
-#include "mctq_table_builder.h"
+// mctq_lut_compact.hip -- the compact decision table of round 4 as an EXPERIMENT translation unit (not part of the shipped
+// libmctq_hip.so since ABI v8): python tools/build_variant.py lut_compact links it with the regular objects into
+// tools/ablate/libmctq_hip_lut_compact.so, which exports the regular ABI plus the four entry points below.
+#include "lut_compact_op.hpp"
+#include "compact_table_builder.h"
 
 using namespace mctq;
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (kept as the provenance of profiles/r04/): sections that use --heavy-persistent, MCTQ_COMPACT_LUT, tools/ablate/ or
+# the ql_variant experiment codes need the round-4 library (ABI v7, commit f72a681); round 5's driver is tools/gpu_r05.sh.
 # How round 4's logs under profiles/r04/ were produced on the MI355X box: `gpurun -- 'bash tools/gpu_r04.sh <section> ...'`
 # (several sections per call are fine).  Everything is written under gpurun_out/r04/ and copied to profiles/r04/ by hand.
 # rocprofv3 --pmc passes never share a run with other trace domains (tools/gpu_pmc_traffic.sh, tools/gpu_r04_lut_pmc.sh).

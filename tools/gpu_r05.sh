@@ -64,4 +64,14 @@ rehearse8() {     # the N = 8 entry path on the one GPU (8 ra
   tail -5 $O/bench_gpus8_wrapped.log | cut -c1-600
 }
 
+placement() {     # VERDICT r04 #2, the one experiment: where input and output live vs the launch's duration
+  timeout 900 python tools/placement_probe.py 2>&1 | grep -v amdgpu.ids > $O/placement_probe.log
+  tail -50 $O/placement_probe.log
+}
+
+newtests() {      # the tests this round added, verbose (the versioned check prints its host cost)
+  timeout 1800 python -m pytest tests/test_accelerate.py tests/test_gpu_multigpu.py tests/test_holder_fast_call.py tests/test_gpu_batched.py tests/test_gpu_streams.py -m gpu -q -s -x 2>&1 | grep -v amdgpu.ids | tail -40 > $O/pytest_new_tests.log
+  tail -15 $O/pytest_new_tests.log
+}
+
 for s in "$@"; do echo "=== $s"; $s; done

@@ -156,3 +156,16 @@ print("  addresses x:", [hex(x.data_ptr()) for x in xs], "y:", [hex(y.data_ptr()
 report("separate allocations: x0 five times | 5 outputs", [(x_first.data_ptr(), y.data_ptr()) for y in ys])
 del spacer
 torch.cuda.empty_cache()
+
+# ---- 4. what is it about x0?  Inputs written by a host-to-device copy vs by a kernel (clone), allocated late vs first -------
+late_h2d = [torch.from_numpy(x_np).to(dev) for _ in range(5)]
+ys2 = [torch.empty_like(x_first) for _ in range(5)]
+report("5 inputs uploaded from the host NOW (late allocations)", [(x.data_ptr(), y.data_ptr()) for x, y in zip(late_h2d, ys2)])
+clones2 = [x_first.clone() for _ in range(5)]
+report("5 clones allocated after them, same outputs", [(x.data_ptr(), y.data_ptr()) for x, y in zip(clones2, ys2)])
+for x in clones2:
+    x.copy_(torch.from_numpy(x_np), non_blocking=False)             # the same buffers, now written by a host-to-device copy
+report("the same 5 clone buffers after a host-to-device copy into them", [(x.data_ptr(), y.data_ptr()) for x, y in zip(clones2, ys2)])
+for x in late_h2d:
+    x.copy_(x_first)                                                # the uploaded buffers, now written by a copy kernel
+report("the 5 uploaded buffers after a device copy kernel wrote them", [(x.data_ptr(), y.data_ptr()) for x, y in zip(late_h2d, ys2)])
