@@ -586,6 +586,51 @@ def test_lut_tuning_variants_do_not_change_results(lib):
         native.set_tuning("heavy_unroll", 0)
 
 
+def test_one_vector_window_tiles_where_the_parameter_window_of_four_would_not_fit_lds(lib):
+    """The dispatcher's last branch (csrc/mctq_kernels.hpp: launch_channels): per-channel along the fastest axis with so many
+    channels that the parameter window of a 4-lane-vector tile exceeds 64 KiB of LDS -> tiles of ONE lane-vector.  The
+    launch log of the whole suite never reached it before this test (profiles/r05/launch_variants_all.log)."""
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(77)
+    # (a) affine, bfloat16 storage: 8192-element tiles touch 8192 rows of one element, 8193 x 12 B > 64 KiB
+    rows, C = 700, 9001                                      # C % 8 != 0: not the lastaxis shape
+    scales = rng.uniform(0.01, 0.5, size=C).astype(np.float32)
+    zps = rng.integers(0, 16, size=C).astype(np.int32)
+    x32 = _tie_heavy(rng, (rows, C), scales.reshape(1, C), zps.reshape(1, C).astype(np.float32), 0, 15)
+    xb = _dev(x32).to(torch.bfloat16)
+    yb = torch.empty_like(xb)
+    s_d, z_d = _dev(scales), _dev(zps)
+    rc = lib.mctq_fq_per_channel(xb.data_ptr(), yb.data_ptr(), rows, C, 1, native.DT_BF16, s_d.data_ptr(), z_d.data_ptr(), 0, 15,
+                                 _stream())
+    assert rc == 0, lib.mctq_last_error()
+    assert native.last_launch() == "window_kernel<vector><AffineOp,in2B,out2B,U=1,NT=2>", native.last_launch()
+    xw = xb.float().cpu().numpy()
+    want = torch.from_numpy(O.fake_quant_affine(xw, scales, zps, 0, 15, axis=1)).to(torch.bfloat16)
+    assert torch.equal(yb.cpu(), want)
+    # (b) decision-table LUT, float32: 4097 rows x 16 B + the 4 KB table > 64 KiB
+    rows, C = 500, 4099
+    lut = LUTS["l16"]
+    thr = rng.uniform(0.05, 4.0, size=C).astype(np.float32)
+    x_np = _lut_inputs(rng, (rows, C), thr.reshape(1, C))
+    x, t_d, tab = _dev(x_np), _dev(thr), _table(lut)
+    y = torch.empty_like(x)
+    rc = lib.mctq_lutt_per_channel_f32(x.data_ptr(), y.data_ptr(), rows, C, 1, t_d.data_ptr(), 1e-8, tab.data_ptr(),
+                                       tab.shape[0] - 1, 128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    assert native.last_launch().startswith("window_kernel<vector><LutTableOp,in4B,out4B,U=1,"), native.last_launch()
+    want = O.lut_quantize(x_np, lut, thr, True, 8, 1e-8, per_channel=True, channel_axis=1)
+    assert bits_equal(y.cpu().numpy(), want), first_mismatch(y.cpu().numpy(), want, x_np)
+    # (c) literal scan (single-variant op), same shape: registers-codebook kernel through the same branch
+    lut_d = _dev(np.asarray(lut, dtype=np.float32))
+    y2 = torch.empty_like(x)
+    rc = lib.mctq_lut_per_channel_f32(x.data_ptr(), y2.data_ptr(), rows, C, 1, t_d.data_ptr(), 1e-8, lut_d.data_ptr(), len(lut),
+                                      128.0, -128.0, 127.0, _stream())
+    assert rc == 0, lib.mctq_last_error()
+    assert native.last_launch() == "window_kernel<vector><LutOp<registers>,in4B,out4B,U=1,NT=1>", native.last_launch()
+    assert bits_equal(y2.cpu().numpy(), want)
+
+
 def test_cached_store_threshold_does_not_change_results(lib):
     import mct_quantizers_amd as mq
     from mct_quantizers_amd.hip import native
