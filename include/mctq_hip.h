@@ -76,7 +76,9 @@ const char* mctq_last_error(void);
 
 /* Diagnostic: which kernel variant the calling thread's last successful elementwise launch used, e.g.
  * "rows_kernel<AffineOp,in4B,out4B,U=4,NT=1>" ("" before the first launch).  Benchmarks use it to tie profiler
- * counters (profiles/pmc_traffic.json) to the variant they were measured on.  Valid until the next call. */
+ * counters (profiles/pmc_traffic.json) to the variant they were measured on.  Valid until the next call.
+ * With MCTQ_LAUNCH_LOG=<file> in the environment when the library is loaded, every variant is also appended to that file
+ * the first time the process takes it (the evidence the set of instantiated kernels was cut against). */
 const char* mctq_last_launch(void);
 
 /* Diagnostic: number of kernel launches the library has enqueued from the calling thread since it was loaded (every

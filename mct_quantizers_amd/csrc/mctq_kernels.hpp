@@ -842,13 +842,17 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const TI* __restrict__ x
 // 32 bytes in flight per lane; here a block takes U consecutive steps of the dense [rows][innerv] storage whatever row they
 // fall in (64 bytes in flight per lane, one contiguous 16 KiB read per block), and each step -- which lies inside ONE row --
 // gets that row's parameters by scalar loads, as in rows_kernel.
-// The kernel is sensitive to its instruction schedule in ways that did not transfer between shapes
-// (profiles/r04/rowsteps_forced.log): sharing one parameter fetch between the steps of a row (uniform branch) cost the
-// 4096 x 4096 bfloat16 launch 11.84 -> 12.6 us; compiling the all-steps-present path separately from the guarded one (what
-// one_tile does, and what helps this kernel when it is FORCED onto config 2: 23.5 -> 22.8 us, still behind rows_kernel's
-// 22.3) cost it 11.84 -> 12.8-13.0 us; eight steps per block on config 2 / 5 (one round of blocks) 22.2 / 94 us against
-// rows_kernel's 22.3 / 83; all loads -> all results -> all stores 13.1.  The form below is the one the dispatcher's window was
-// measured with (its compiled schedule starts staggered: three loads, the fourth when the first has returned).
+// Where it is taken (launch_channels): only where its grid is ONE round of resident blocks (8 per CU) -- 64 MiB-class launches
+// such as 4096 x 4096 bfloat16, 8192 x 2048 bfloat16, 4096 x 2048 / 2048 x 3072 float32: 6-15 % faster than rows_kernel there on
+// three boxes, 3-12 % slower at half a round or several rounds (profiles/r05/rowsteps_sched.log, profiles/r04/rowsteps_probe_sustained.log).
+// What makes it fast is a property of the COMPILED code: the block's first three loads are issued before anything of the
+// parameter fetch (row division, scalar loads, IEEE reciprocal), the fourth once the first has landed (16-bit storage) and all
+// stores at the end.  Round 5 tried to WRITE that schedule (tools/experiments/rowsteps_sched/: nine source forms -- explicit
+// 3 + 1 and 2 + 2 staggers, stores early or late, compile-time steps per row): every one compiles to something 2-10 % slower,
+// because LLVM commons the row division of the full and the guarded path above the loads or sinks the loads to their first
+// use (sched_barrier binds one basic block; volatile or asm-pinned loads force s_waitcnt vmcnt(0)).  So the source below is
+// the form the window was measured with, and tests/test_abi_exports.py ASSERTS the schedule on the code hipcc generates from
+// it: a compiler or source change that moves it fails the suite instead of silently removing the window's reason.
 // ------------------------------------------------------------------------------------------
 template <class Op, class TI, class TO, int U, int NT>
 __global__ __launch_bounds__(kThreads) void rowsteps_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,

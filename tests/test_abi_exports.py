@@ -215,3 +215,62 @@ def test_a_stale_binary_is_rebuilt_whatever_its_modification_time(tmp_path, monk
     # a flag change is a source change too
     monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DX=1"])
     assert build.needs_build()
+
+
+def test_rowsteps_kernel_keeps_the_schedule_its_dispatch_window_was_measured_with(tmp_path):
+    """rowsteps_kernel (csrc/mctq_kernels.hpp) is taken where its grid is one round of resident blocks because it measured
+    6-15 % faster there than rows_kernel (profiles/r05/rowsteps_sched.log: 4 of 4 shapes in the window, three boxes) -- and what
+    makes it fast is a property of the COMPILED code, not of its source: the block's first three 16-byte loads are issued
+    before any of the parameter fetch (row arithmetic, scalar loads, the IEEE reciprocal), the fourth once the first has
+    landed.  Nine source forms that try to WRITE that schedule compile to something slower (LLVM commons the row division
+    above the loads, or sinks the loads to their first use; tools/experiments/rowsteps_sched/).  So the schedule is ASSERTED
+    here, on the code hipcc generates from the shipped source with the shipped flags: if a compiler or source change moves
+    it, this test fails and the window (tuning key "rowsteps", default 2) has to be re-measured instead of silently losing
+    its reason."""
+    import shutil
+    import subprocess
+    from mct_quantizers_amd.hip import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "affine.s"
+    subprocess.run([hipcc, *B.FLAGS, "-I", os.path.join(REPO, "include"), "-I", B.CSRC, "--cuda-device-only", "-S", "-o", str(asm),
+                    os.path.join(B.CSRC, "mctq_affine.hip")], check=True, capture_output=True)
+    text = asm.read_text()
+    names = re.findall(r"^(_ZN4mctq15rowsteps_kernel\w+):", text, flags=re.M)
+    assert len(names) == 6, names                             # float32 / float16 / bfloat16 x two cache policies
+    for name in names:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        ins = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        ins = [ln for ln in ins if ln and not ln.startswith(".") or re.match(r"\.LBB\d+_\d+:", ln)]
+        # basic blocks of the function, in layout order
+        blocks, cur = [], []
+        for ln in ins:
+            if re.match(r"\.LBB\d+_\d+:", ln):
+                blocks.append(cur)
+                cur = []
+                continue
+            cur.append(ln)
+            if ln.startswith(("s_cbranch", "s_branch")):
+                blocks.append(cur)
+                cur = []
+        blocks.append(cur)
+        # the hot (all four steps present) path: the first block that issues three data loads in a row
+        hot = next((i for i, b in enumerate(blocks) if sum(x.startswith("global_load_dwordx4") for x in b) >= 3), None)
+        assert hot is not None, f"{name}: no block with three back-to-back data loads"
+        before = [x for b in blocks[:hot] for x in b] + blocks[hot][:max(i for i, x in enumerate(blocks[hot]) if x.startswith("global_load_dwordx4"))]
+        # nothing of the parameter fetch in front of them: no scalar load of a table element, no reciprocal
+        def is_fetch(x):                                      # a table element by scalar load (kernel arguments come from s[0:1]), a reciprocal
+            return bool(re.match(r"s_load_dword s\d+, s\[(?!0:1\])", x)) or x.startswith(("v_rcp_f32", "v_div_fixup_f32"))
+        assert not [x for x in before if is_fetch(x)], f"{name}: parameter fetch scheduled in front of the data loads"
+        after = [x for b in blocks[hot:] for x in b]
+        loads = [i for i, x in enumerate(after) if x.startswith("global_load_dwordx4")]
+        assert len(loads) >= 4
+        between = after[loads[2] + 1:loads[3]]
+        assert not [x for x in between if is_fetch(x)], f"{name}: parameter fetch in front of the fourth data load"
+        if "Eff" not in name:
+            # 16-bit storage: the fourth load waits for the first one (at most two loads outstanding in front of it)
+            assert any(re.match(r"s_waitcnt vmcnt\([012]\)", x) for x in between), f"{name}: the fourth load is not staggered"
+        # the parameter fetch (scalar loads, IEEE reciprocal) runs under the loads' latency
+        assert any(is_fetch(x) for x in after[loads[3]:]), name

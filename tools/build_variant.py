@@ -4,7 +4,8 @@ experiment translation units under tools/experiments/ added, everything else lin
 Output: tools/ablate/libmctq_hip_<NAME>.so (git-ignored, travels to the GPU box); run with
     MCTQ_HIP_LIB=tools/ablate/libmctq_hip_<NAME>.so MCTQ_BINDING=ctypes python tools/...
 Usage: python tools/build_variant.py NAME [-DFLAG ...] [--units=a.hip,b.hip]
-       python tools/build_variant.py lut_compact          (regular objects + tools/experiments/lut_compact/mctq_lut_compact.hip)"""
+       python tools/build_variant.py lut_compact          (regular objects + tools/experiments/lut_compact/mctq_lut_compact.hip)
+       python tools/build_variant.py lut_conflicts | rowsteps_sched   (regular objects + tools/experiments/<name>/<name>.hip)"""
 import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,6 +17,9 @@ def main():
     if name == "lut_compact":
         units, xdir = [], os.path.join(REPO, "tools", "experiments", "lut_compact")
         extra = [(os.path.join(xdir, "mctq_lut_compact.hip"), ["-I", xdir])]
+    elif name in ("lut_conflicts", "rowsteps_sched"):
+        units, xdir = [], os.path.join(REPO, "tools", "experiments", name)
+        extra = [(os.path.join(xdir, name + ".hip"), ["-I", xdir])]
     for a in sys.argv[2:]:
         if a.startswith("--units"):
             units = a.split("=", 1)[1].split(",")

@@ -74,4 +74,40 @@ newtests() {      # the tests this round added, verbose (the versioned check pri
   tail -15 $O/pytest_new_tests.log
 }
 
+lutconf() {       # LDS layouts of the decision table (experiment library: python tools/build_variant.py lut_conflicts)
+  timeout 600 python tools/experiments/lut_conflicts/run.py 2>&1 | grep -v amdgpu.ids > $O/lut_conflicts_timing.log
+  cat $O/lut_conflicts_timing.log
+  rm -rf /tmp/lutconf; mkdir -p $O/lutconf
+  i=0
+  for grp in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS" \
+             "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/lutconf/$i -- python3 $R/tools/experiments/lut_conflicts/run.py pmc > $O/lutconf/run_$i.log 2>&1
+    f=$(find /tmp/lutconf/$i -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then head -1 $f > $O/lutconf/group_$i.csv; grep -E "LutTableXOp" $f >> $O/lutconf/group_$i.csv; else echo "group $i: no counter file"; tail -3 $O/lutconf/run_$i.log; fi
+  done
+  python - <<'PYEOF'
+import csv, glob, os, re
+O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r05")
+acc = {}
+for path in sorted(glob.glob(os.path.join(O, "lutconf", "group_*.csv"))):
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"LutTableXOp<(\d)>", r["Kernel_Name"])
+        if m:
+            acc.setdefault(r["Counter_Name"], {}).setdefault(int(m.group(1)), []).append(float(r["Counter_Value"]))
+with open(os.path.join(O, "lut_conflicts_counters.csv"), "w") as f:
+    f.write("counter,mode0_shipped,mode1_swizzle,mode2_planes,mode3_one_cell,mode4_T_only\n")
+    for c in sorted(acc):
+        f.write(c + "," + ",".join(f"{sum(acc[c].get(m, [0])) / max(1, len(acc[c].get(m, []))):.0f}" for m in range(5)) + "\n")
+print(open(os.path.join(O, "lut_conflicts_counters.csv")).read())
+PYEOF
+}
+
+rowsched() {      # the rowsteps kernel with a written schedule (experiment library: python tools/build_variant.py rowsteps_sched)
+  timeout 900 python tools/experiments/rowsteps_sched/run.py 2>&1 | grep -v amdgpu.ids > $O/rowsteps_sched.log
+  cat $O/rowsteps_sched.log
+  timeout 900 python tools/rowsteps_probe.py 2>&1 | grep -v amdgpu.ids > $O/rowsteps_probe_sustained.log     # 30 shapes x 3 storage types
+  tail -5 $O/rowsteps_probe_sustained.log
+}
+
 for s in "$@"; do echo "=== $s"; $s; done
