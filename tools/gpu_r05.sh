@@ -110,4 +110,9 @@ rowsched() {      # the rowsteps kernel with a written schedule 
   tail -5 $O/rowsteps_probe_sustained.log
 }
 
+pmc() {           # rocprof stats + FETCH / WRITE passes of every bench configuration -> gpurun_out/pmc (then: MCTQ_ROUND=r05 python tools/pmc_summarize.py)
+  bash tools/gpu_pmc_traffic.sh > $O/pmc_traffic_run.log 2>&1
+  tail -30 $O/pmc_traffic_run.log | cut -c1-220
+}
+
 for s in "$@"; do echo "=== $s"; $s; done
