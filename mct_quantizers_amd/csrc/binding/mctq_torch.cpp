@@ -568,6 +568,16 @@ PyTypeObject LutPlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 //      relaunches the whole plan.  (A write through `x.data` does not move x's version counter: plan.invalidate() forces
 //      the next call to launch.)  Never skipped while the stream is being captured.
 struct BatchWatch { PyObject* dict; PyObject* name; PyObject* obj; int64_t version; };
+// Consecutive watch entries of ONE dictionary (a quantizer's __dict__).  CPython < 3.12 stamps every dictionary with a version
+// tag that changes on ANY modification: while the tag is the one seen at the last full check, every dict[name] is still the
+// object it was, so only the tensors' in-place version counters are re-read (54 weights: 324 dictionary lookups saved per
+// call).  tag 0 = not valid (a dictionary's tag is never 0 once it has been modified; newer Pythons: always the full check).
+struct WatchGroup { size_t first, count; uint64_t tag; };
+#if PY_VERSION_HEX < 0x030C0000
+inline uint64_t dict_tag(PyObject* d) { return ((PyDictObject*)d)->ma_version_tag; }
+#else
+inline uint64_t dict_tag(PyObject*) { return 0; }
+#endif
 
 struct BatchPlan {
   PyObject_HEAD
@@ -575,8 +585,10 @@ struct BatchPlan {
   std::vector<mctq_fq_item>* items;
   std::vector<PyObject*>* refs;          // 4 per item: x, y, scales, zero_points (or Py_None)
   std::vector<std::vector<int64_t>>* sizes;
+  std::vector<std::vector<int64_t>>* strides;   // x's strides when the item was packed: same sizes AND strides = same (outer, channels, inner)
   std::vector<int64_t>* axes;            // -1: per tensor
   std::vector<BatchWatch>* watch;
+  std::vector<WatchGroup>* groups;
   std::vector<uint8_t>* host_table;
   at::Tensor* dev_table;
   // LUT items (decision-table quantizers): ("lut", x, y, thresholds | None, table, axis | None, eps, thr_div, thr_mul,
@@ -638,12 +650,22 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
     return nullptr;
   }
   if (torch::jit::tracer::isTracing()) return not_implemented();
-  for (const BatchWatch& w : *p->watch) {
-    PyObject* cur = PyDict_GetItemWithError(w.dict, w.name);          // borrowed
-    if (!cur) { if (PyErr_Occurred()) return nullptr; return not_implemented(); }
-    if (cur != w.obj) return not_implemented();
-    if (w.version >= 0 && (!THPVariable_Check(cur) || (int64_t)THPVariable_Unpack(cur)._version() != w.version))
-      return not_implemented();
+  for (WatchGroup& g : *p->groups) {
+    const BatchWatch* w0 = p->watch->data() + g.first;
+    const uint64_t tag = dict_tag(w0->dict);
+    const bool same_dict = g.tag != 0 && tag == g.tag;               // untouched since the last full check: identities hold
+    for (size_t k = 0; k < g.count; ++k) {
+      const BatchWatch& w = w0[k];
+      PyObject* cur = w.obj;
+      if (!same_dict) {
+        cur = PyDict_GetItemWithError(w.dict, w.name);                // borrowed
+        if (!cur) { if (PyErr_Occurred()) return nullptr; return not_implemented(); }
+        if (cur != w.obj) return not_implemented();
+      }
+      if (w.version >= 0 && (!THPVariable_Check(cur) || (int64_t)THPVariable_Unpack(cur)._version() != w.version))
+        return not_implemented();
+    }
+    g.tag = tag;
   }
   const size_t n = p->items->size();
   bool dirty = !p->uploaded;
@@ -661,12 +683,14 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
         !x.unsafeGetTensorImpl()->is_non_overlapping_and_dense() || x.strides() != y.strides() ||
         dtype_code(x.scalar_type()) != d.dtype || y.scalar_type() != x.scalar_type())
       return not_implemented();
-    int64_t outer, c, inner;
     const int64_t axis = (*p->axes)[i];
-    if (axis < 0) { outer = 1; c = 1; inner = x.numel(); }
-    else channel_view(x, axis, &outer, &c, &inner);
-    if (outer != d.outer || c != d.channels || inner != d.inner) return not_implemented();   // same sizes, other strides
-    const int64_t want = axis < 0 ? 1 : c;
+    if (x.strides() != c10::IntArrayRef((*p->strides)[i])) {         // same sizes, other strides: is the channel view the same?
+      int64_t outer, c, inner;
+      if (axis < 0) { outer = 1; c = 1; inner = x.numel(); }
+      else channel_view(x, axis, &outer, &c, &inner);
+      if (outer != d.outer || c != d.channels || inner != d.inner) return not_implemented();
+    }
+    const int64_t want = axis < 0 ? 1 : d.channels;
     if (sc.scalar_type() != c10::ScalarType::Float || !sc.is_contiguous() || sc.device() != x.device() || sc.numel() != want)
       return not_implemented();
     const void* zp = nullptr;
@@ -753,7 +777,7 @@ void batchplan_dealloc(PyObject* self) {
   if (p->refs) for (PyObject* o : *p->refs) Py_XDECREF(o);
   if (p->watch) for (BatchWatch& w : *p->watch) { Py_XDECREF(w.dict); Py_XDECREF(w.name); Py_XDECREF(w.obj); }
   if (p->lut_refs) for (PyObject* o : *p->lut_refs) Py_XDECREF(o);
-  delete p->items; delete p->refs; delete p->sizes; delete p->axes; delete p->watch; delete p->host_table; delete p->dev_table;
+  delete p->items; delete p->refs; delete p->sizes; delete p->strides; delete p->axes; delete p->watch; delete p->groups; delete p->host_table; delete p->dev_table;
   delete p->lut_items; delete p->lut_refs; delete p->lut_sizes; delete p->lut_axes; delete p->lut_host_table; delete p->lut_dev_table;
   delete p->seen;
   Py_TYPE(self)->tp_free(self);
@@ -805,8 +829,10 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   if (!p) { Py_DECREF(seq); return nullptr; }
   p->vectorcall = batchplan_vectorcall;
   p->items = new std::vector<mctq_fq_item>(); p->refs = new std::vector<PyObject*>();
-  p->sizes = new std::vector<std::vector<int64_t>>(); p->axes = new std::vector<int64_t>();
-  p->watch = new std::vector<BatchWatch>(); p->host_table = new std::vector<uint8_t>(); p->dev_table = new at::Tensor();
+  p->sizes = new std::vector<std::vector<int64_t>>(); p->strides = new std::vector<std::vector<int64_t>>();
+  p->axes = new std::vector<int64_t>();
+  p->watch = new std::vector<BatchWatch>(); p->groups = new std::vector<WatchGroup>();
+  p->host_table = new std::vector<uint8_t>(); p->dev_table = new at::Tensor();
   p->lut_items = new std::vector<mctq_lut_item>(); p->lut_refs = new std::vector<PyObject*>();
   p->lut_sizes = new std::vector<std::vector<int64_t>>(); p->lut_axes = new std::vector<int64_t>();
   p->lut_host_table = new std::vector<uint8_t>(); p->lut_dev_table = new at::Tensor();
@@ -901,6 +927,7 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
     d.flags = axis_o == Py_None ? MCTQ_FQ_ITEM_PER_TENSOR : 0;
     p->items->push_back(d);
     p->sizes->push_back(xp->sizes().vec());
+    p->strides->push_back(xp->strides().vec());
     p->axes->push_back(axis_o == Py_None ? -1 : axis);
     for (int k = 0; k < 4; ++k) { PyObject* o = PyTuple_GET_ITEM(it, k); Py_INCREF(o); p->refs->push_back(o); }
     if (PyTuple_GET_SIZE(it) == 8) err = batchplan_add_watch(p, PyTuple_GET_ITEM(it, 7));
@@ -908,6 +935,12 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   Py_DECREF(seq);
   if (err) { Py_DECREF(p); PyErr_Format(PyExc_TypeError, "BatchPlan: %s", err); return nullptr; }
   p->seen->assign(2 * (p->items->size() + p->lut_items->size()), 0u);
+  for (size_t i = 0; i < p->watch->size();) {                       // runs of entries that watch the same dictionary
+    size_t j = i;
+    while (j < p->watch->size() && (*p->watch)[j].dict == (*p->watch)[i].dict) ++j;
+    p->groups->push_back(WatchGroup{i, j - i, 0});
+    i = j;
+  }
   return (PyObject*)p;
   END_HANDLE_TH_ERRORS
 }
