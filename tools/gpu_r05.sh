@@ -115,4 +115,10 @@ pmc() {           # rocprof stats + FETCH / WRITE passes of every bench configur
   tail -30 $O/pmc_traffic_run.log | cut -c1-220
 }
 
+modes() {         # the GPU suite through the other binding / with roctx ranges, and the seeded fuzz suites on further seeds
+  MCTQ_BINDING=ctypes timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu_ctypes.log 2>&1; echo "rc=$?" >> $O/pytest_gpu_ctypes.log; tail -2 $O/pytest_gpu_ctypes.log
+  MCTQ_ROCTX=1 timeout 1800 python -m pytest tests -m gpu -q -k "not every_float and not 2_32" > $O/pytest_gpu_roctx.log 2>&1; echo "rc=$?" >> $O/pytest_gpu_roctx.log; tail -2 $O/pytest_gpu_roctx.log
+  MCTQ_ROUND=r05 SEEDS="31 32 33 34" bash tools/gpu_fuzz_soak.sh
+}
+
 for s in "$@"; do echo "=== $s"; $s; done
