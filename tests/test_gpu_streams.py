@@ -219,6 +219,7 @@ def test_captures_survive_an_aggressive_garbage_collector(lib):
     dropped WITHOUT release() in a loop, half of the rounds with the collector at its most eager, half with it lazy."""
     import gc
     import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native
     Q = mq.pytorch_quantizers
 
     def model():
@@ -238,7 +239,8 @@ def test_captures_survive_an_aggressive_garbage_collector(lib):
                 want = m(x)
                 for _ in range(3):
                     assert torch.equal(m(x), want)
-            assert m.__dict__["_mctq_auto_capture"]._graphs
+            if native.fast() is not None:                                      # (the replay reads the pre-packed plan's buffers: compiled binding)
+                assert m.__dict__["_mctq_auto_capture"]._graphs
             cf = mq.capture_forward(model(), x)                              # CapturedForward
             assert cf(x).shape == (4, 16)
             lutq = Q.ActivationLutPOTInferableQuantizer(3, [-128.0, -64.0, -20.0, -5.0, 0.0, 5.0, 20.0, 64.0], [4.0], True)
