@@ -104,10 +104,21 @@ def accelerate_loaded(obj):
     model that was saved with it (a re-saved accelerated model): the switch means the reference's per-layer calls."""
     if isinstance(obj, nn.Module):
         if auto_batch_enabled():
-            accelerate(obj, capture=auto_capture_enabled())
+            accelerate(obj, capture=auto_capture_enabled(), reuse=auto_reuse())
         else:
             decelerate(obj)
     return obj
+
+
+def auto_reuse() -> Optional[str]:
+    """``MCTQ_AUTO_REUSE=versioned`` (default: unset): loaded models get ``accelerate(model, reuse="versioned")`` -- no weight
+    launch at all while no weight changed.  Opt-in because of its one blind spot (in-place writes through ``weight.data``)."""
+    v = os.environ.get("MCTQ_AUTO_REUSE", "").strip().lower()
+    if v in ("", "0", "off", "false", "no"):
+        return None
+    if v != "versioned":
+        raise ValueError('MCTQ_AUTO_REUSE must be unset or "versioned"')
+    return "versioned"
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -186,6 +186,20 @@ def test_the_switch_set_to_zero_takes_the_hook_off_a_model_that_was_saved_with_i
         assert torch.equal(off(x), on(x))
 
 
+def test_loader_takes_the_versioned_form_from_the_environment(tmp_path, monkeypatch):
+    monkeypatch.setenv("TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD", "1")
+    path = tmp_path / "m.pth"
+    torch.save(_small_model(), path)
+    monkeypatch.setenv("MCTQ_AUTO_BATCH", "1")
+    monkeypatch.delenv("MCTQ_AUTO_REUSE", raising=False)
+    assert mq.accelerated(mq.pytorch_load_quantized_model(path)).versioned is False
+    monkeypatch.setenv("MCTQ_AUTO_REUSE", "versioned")
+    assert mq.accelerated(mq.pytorch_load_quantized_model(path)).versioned is True
+    monkeypatch.setenv("MCTQ_AUTO_REUSE", "sometimes")
+    with pytest.raises(ValueError):
+        mq.pytorch_load_quantized_model(path)
+
+
 def test_accelerate_reuse_argument():
     net = _small_model()
     with pytest.raises(ValueError):
