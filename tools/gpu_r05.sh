@@ -121,4 +121,13 @@ modes() {         # the GPU suite through the other binding / with roctx ranges,
   MCTQ_ROUND=r05 SEEDS="31 32 33 34" bash tools/gpu_fuzz_soak.sh
 }
 
+e2e() {           # bench.py --config resnet50 --e2e lines on this round's library (AutoCapture now checks hooks / autocast / strides per call)
+  for v in "resnet50" "resnet50_lut --e2e-lut" "resnet50_64px --e2e-side 64" "resnet50_b32 --batch 32 --steps 50"; do
+    set -- $v; name=$1; shift
+    timeout 600 python bench.py --config resnet50 --e2e --steps 100 "$@" 2>>$O/e2e.err | tail -1 > $O/bench_e2e_$name.json
+    python -c "
+import json; d=json.load(open('$O/bench_e2e_$name.json')); print('$name', {k: round(v, 3) if isinstance(v, float) else v for k, v in d.items() if k in ('value', 'ms_per_step') or k.startswith('ms_')}, {k: d[k] for k in d if 'ms' in k and k not in ('ms_per_step',)} if False else '')" 2>/dev/null || head -c 600 $O/bench_e2e_$name.json
+  done
+}
+
 for s in "$@"; do echo "=== $s"; $s; done
