@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--evidence-launches", type=int, default=200,
                     help="launches of the per-launch event-pair pass after the timed region (0 = skip)")
     ap.add_argument("--nt", type=int, default=None)
+    ap.add_argument("--cached-store-max-mb", type=int, default=None,
+                    help="tuning key cached_store_max_mb: outputs up to this size are stored through the caches (default 32)")
     ap.add_argument("--unroll", type=int, default=None)
     ap.add_argument("--heavy-unroll", type=int, default=None)
     ap.add_argument("--rowsteps", type=int, default=None, help="tuning key rowsteps (include/mctq_hip.h): 1 = rowsteps_kernel for short whole-step rows")
@@ -241,7 +243,8 @@ def main():
     from mct_quantizers_amd.hip import native
     if not dry:
         native.load()
-        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll), ("rowsteps", args.rowsteps)):
+        for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll), ("rowsteps", args.rowsteps),
+                         ("cached_store_max_mb", args.cached_store_max_mb)):
             if val is not None:
                 native.set_tuning(key, val)
 
