@@ -130,4 +130,12 @@ import json; d=json.load(open('$O/bench_e2e_$name.json')); print('$name', {k: ro
   done
 }
 
+soak() {          # closing soak at the final head: the whole GPU suite three times in a row, four more fuzz seeds, the judged command three times
+  : > $O/closing_soak.log
+  for i in 1 2 3; do timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -1 | sed "s/^/suite run $i: /" >> $O/closing_soak.log; done
+  MCTQ_ROUND=r05 SEEDS="41 42 43 44" bash tools/gpu_fuzz_soak.sh > /dev/null 2>&1; sed "s/^/fuzz /" $O/fuzz_soak.log >> $O/closing_soak.log
+  for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 | line "bench --steps 20 run $i" >> $O/closing_soak.log; done
+  cat $O/closing_soak.log
+}
+
 for s in "$@"; do echo "=== $s"; $s; done
