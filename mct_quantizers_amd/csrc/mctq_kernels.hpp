@@ -1282,7 +1282,11 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
 
   // lastaxis shape.
   if (vec_ok && inner == 1 && (channels % io::N) == 0 && channels <= 0x7fffffffLL && op.tables_aligned16()) {
-    constexpr int LU = sizeof(TI) == 4 ? 4 : 8;
+    // rows per lane: 4 for every storage type.  (16-bit tensors had 8 until round 5 -- twice the rows to spread a lane's N
+    // reciprocals over; measured, 4 is 3-5 % faster on 8 of 10 channel-last shapes and equal on the others but one (16
+    // channels: +0.5 ... +5 %): 90 -> ~50 VGPRs, and twice the blocks, so a 64 MiB launch is two rounds of resident blocks
+    // instead of one whose reads and writes separate into phases; 2 is slower everywhere: profiles/r05/lastaxis_lu_probe.log)
+    constexpr int LU = 4;
     const int64_t vc = channels / io::N;                              // lane vectors per row
     // rows per step: enough lanes (>= 2048) that the idle tail of the last block is small; among the next few
     // candidates take the one that wastes the fewest lanes

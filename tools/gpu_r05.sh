@@ -138,4 +138,40 @@ soak() {          # closing soak at the final head: the whole GPU suite three ti
   cat $O/closing_soak.log
 }
 
+lastaxis() {      # counters of the channel-last kernel beside the row kernels on the same tensor
+  timeout 300 python tools/lastaxis_vs_rows.py 2>&1 | grep -v amdgpu.ids > $O/lastaxis_vs_rows.log; cat $O/lastaxis_vs_rows.log
+  rm -rf /tmp/lax; mkdir -p $O/lax; i=0
+  for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+             "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_LEVEL_WAVES" \
+             "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum" \
+             "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_32B_sum" \
+             "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/lax/$i -- python3 $R/tools/lastaxis_vs_rows.py pmc > $O/lax/run_$i.log 2>&1
+    f=$(find /tmp/lax/$i -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then head -1 $f > $O/lax/group_$i.csv; grep -E "mctq" $f >> $O/lax/group_$i.csv; else echo "group $i: no counter file"; tail -3 $O/lax/run_$i.log; fi
+  done
+  python - <<'PYEOF'
+import csv, glob, os, re
+O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r05")
+acc = {}
+def short(n):
+    m = re.search(r"(rows_kernel|rowsteps_kernel|lastaxis_kernel)", n)
+    t = "bf16" if "DF16b" in n else "f32"
+    return f"{m.group(1)}/{t}" if m else None
+for path in sorted(glob.glob(os.path.join(O, "lax", "group_*.csv"))):
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if k:
+            acc.setdefault(r["Counter_Name"], {}).setdefault(k, []).append(float(r["Counter_Value"]))
+ks = sorted({k for v in acc.values() for k in v})
+with open(os.path.join(O, "lastaxis_vs_rows_counters.csv"), "w") as f:
+    f.write("counter," + ",".join(ks) + "\n")
+    for c in sorted(acc):
+        f.write(c + "," + ",".join(f"{sum(acc[c].get(k, [0])) / max(1, len(acc[c].get(k, []))):.0f}" for k in ks) + "\n")
+print(open(os.path.join(O, "lastaxis_vs_rows_counters.csv")).read())
+PYEOF
+}
+
 for s in "$@"; do echo "=== $s"; $s; done
