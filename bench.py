@@ -104,6 +104,9 @@ def parse():
     ap.add_argument("--no-eager-extra", action="store_true",
                     help="config 3: skip the eager per-call figure (profiler passes: only the judged kernel's dispatches)")
     ap.add_argument("--gather", action="store_true", help="run the sharded config-5 + all-gather leg even at N = 1 (needs torchrun)")
+    ap.add_argument("--no-sharded-extra", action="store_true",
+                    help="N = 1 without a launcher: skip the sharded config-5 + all-gather leg (a process group of one rank formed "
+                         "in-process after everything else, so that the three series of SURVEY 8(e) exist at every N)")
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
     ap.add_argument("--extras", action="store_true",
                     help="after the judged region also measure: two-stream overlap, warm-cache rate, ATen's HIP operator")
@@ -237,6 +240,16 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         sys.exit(5)
+    # which physical device every rank computes on (uuid | PCI address | name): a line that claims N GPUs shows N distinct ones
+    wrapped = bool(os.environ.get("MCTQ_BENCH_WRAP_DEVICES")) and not dry
+    rank_devs, devices_distinct = bench_dist.rank_devices(dist, control_plane, device)
+    if world > 1 and (wrapped or not devices_distinct) and not args.allow_gloo:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus}: the ranks do not sit on {args.gpus} distinct devices "
+                  f"({'MCTQ_BENCH_WRAP_DEVICES is set; ' if wrapped else ''}rank_devices = {rank_devs}) and --allow-gloo was not "
+                  f"given: exiting with status {bench_dist.EXIT_SHARED_DEVICE}", file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        sys.exit(bench_dist.EXIT_SHARED_DEVICE)
 
     import mct_quantizers_amd as mq
     from mct_quantizers_amd import workloads
@@ -413,6 +426,8 @@ def main():
         "unit": "elems/s",
         "n_gpus": world,
         "ranks_seen": ranks_seen,
+        "rank_devices": rank_devs,                            # uuid | PCI domain:bus:device | name of every rank's device
+        "devices_distinct": devices_distinct and not wrapped,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps,
@@ -648,17 +663,21 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["batched_16x4096"] = {"error": repr(e)[:300]}
 
-    # ---- N > 1 (or --gather under torchrun): config 5 sharded by dim 0 + ONE all-gather -----------------
+    # ---- config 5 sharded by dim 0 + ONE all-gather (three series at every N) -----------------
+    # N > 1 (or --gather under torchrun): here, on the job's process group.  N = 1 without a launcher: after the CPU baseline,
+    # on a group of one rank formed in-process (RCCL's all_gather_into_tensor on HIP memory; no link is crossed).
     sharded_failed = None
-    if dist is not None and (args.gather or world > 1):
-        with bench_dist.Watchdog(300.0 if control_plane == "gloo" and not dry else 120.0, rank, lambda: json.dumps(result)):
+
+    def run_sharded_leg(group, control, watchdog_s, watchdog_status):
+        nonlocal sharded_failed
+        with bench_dist.Watchdog(watchdog_s, rank, lambda: json.dumps(result), status=watchdog_status):
             try:
                 kw = dict(rows=64, cols=128, reps=3, gather_reps=2) if dry else {}
-                leg = bench_dist.sharded_cfg5_leg(dist, rank, world, device, control=control_plane, **kw)
+                leg = bench_dist.sharded_cfg5_leg(group, rank, world, device, control=control, **kw)
                 result["sharded_cfg5"] = leg
                 result["sharded_cfg5_compute_elems_per_s"] = leg["compute_elems_per_s"]
                 result["sharded_cfg5_compute_plus_allgather_elems_per_s"] = leg["compute_plus_allgather_elems_per_s"]
-                result["sharded_cfg5_allgather_gbs_per_link"] = leg["allgather_gbs_per_link"]
+                result["sharded_cfg5_allgather_gbs_per_link"] = leg["allgather_gbs_per_link"]     # null at N = 1: no link is crossed
                 bad = [k for k in ("gathered_rows_match_local",) if leg.get(k) is not True]
                 if any(v is False for v in leg["ranks_shard_digest_ok"]) or leg.get("gathered_equals_reference_digest") is False:
                     bad.append("digest")
@@ -667,6 +686,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["sharded_cfg5"] = {"error": repr(e)[:300]}
                 sharded_failed = repr(e)[:300]
+
+    if dist is not None and (args.gather or world > 1):
+        run_sharded_leg(dist, control_plane, 300.0 if control_plane == "gloo" and not dry else 120.0, 4)
 
     # CPU baseline: on rank 0, at every N (the other ranks are done; they leave through destroy_process_group below)
     if rank == 0 and not args.no_cpu and not dry and model_mode:
@@ -734,6 +756,22 @@ def main():
                                   "gpu_output_checked": "output of the last timed step"}
         if not same:
             result["parity_error"] = "GPU output differs from the CPU oracle"
+
+    if dist is None and world == 1 and not args.no_sharded_extra and not model_mode and "sharded_cfg5" not in result:
+        # N = 1, no launcher: the same leg on a process group of one rank.  A failure here (no RCCL, a stuck init) costs the
+        # leg, not the line: the watchdog prints the line as it stands and leaves with status 0.
+        try:
+            group, own_control = bench_dist.init_single_rank_group(device)
+        except Exception as e:  # noqa: BLE001
+            result["sharded_cfg5"] = {"error": "process group of one rank: " + repr(e)[:260]}
+        else:
+            run_sharded_leg(group, own_control, 240.0, 0)
+            if isinstance(result.get("sharded_cfg5"), dict) and "error" not in result["sharded_cfg5"]:
+                result["sharded_cfg5"]["process_group"] = "one rank, formed in-process (tcp://127.0.0.1), backend " + own_control
+            try:
+                group.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
 
     if rank == 0:
         print(json.dumps(result), flush=True)

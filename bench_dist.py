@@ -39,6 +39,57 @@ def self_launch(script: str, n: int, argv) -> int:
 
 EXIT_NO_RCCL = 6          # --gpus N > 1 without a working RCCL group and without --allow-gloo
 EXIT_NO_SHARDED_LEG = 7   # --gpus N > 1 whose sharded config-5 + all-gather leg did not run (or failed) without --allow-gloo
+EXIT_SHARED_DEVICE = 8    # --gpus N > 1 whose ranks do not sit on N distinct devices (or MCTQ_BENCH_WRAP_DEVICES is set) without --allow-gloo
+
+
+def device_identity(device: torch.device) -> str:
+    """What tells one physical device from another in a bench line: ``<uuid>|<pci domain:bus:device>|<name>`` of the HIP
+    device this rank computes on (``torch.cuda.get_device_properties``); for the CPU dry run the process itself
+    (``cpu|pid``).  MCTQ_BENCH_FAKE_DEVICE_ID replaces it (tests: two ranks that claim the same device)."""
+    fake = os.environ.get("MCTQ_BENCH_FAKE_DEVICE_ID")
+    if fake:
+        return fake
+    if device.type != "cuda":
+        return f"cpu|pid {os.getpid()}"
+    p = torch.cuda.get_device_properties(device)
+    uuid = str(getattr(p, "uuid", "no-uuid"))
+    bus = "%04x:%02x:%02x" % (int(getattr(p, "pci_domain_id", 0)), int(getattr(p, "pci_bus_id", 0)), int(getattr(p, "pci_device_id", 0)))
+    return f"{uuid}|{bus}|{p.name}"
+
+
+def gather_strings(dist, text: str, control: Optional[str], device: torch.device, width: int = 256):
+    """[text of rank 0, text of rank 1, ...] on every rank (fixed-width byte tensors: works on RCCL and on gloo alike)."""
+    if dist is None:
+        return [text]
+    raw = text.encode("utf-8", "replace")[:width]
+    t = torch.zeros(width, dtype=torch.uint8)
+    t[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    t = t.to(device if control == "nccl" else "cpu")
+    got = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    return [bytes(v.cpu().tolist()).rstrip(b"\0").decode("utf-8", "replace") for v in got]
+
+
+def rank_devices(dist, control: Optional[str], device: torch.device):
+    """(identities of every rank's device, are they pairwise distinct)."""
+    ids = gather_strings(dist, device_identity(device), control, device)
+    return ids, len(set(ids)) == len(ids)
+
+
+def init_single_rank_group(device: torch.device):
+    """A process group of ONE rank formed in-process (no launcher): lets the N = 1 line run the same sharded config-5 +
+    all-gather leg the N > 1 lines run, so the three series of SURVEY 8(e) exist at every N.  RCCL on a GPU, gloo on the
+    CPU dry run.  Returns (dist, control) or raises."""
+    import torch.distributed as dist
+    method = f"tcp://127.0.0.1:{free_port()}"
+    if device.type == "cuda":
+        dist.init_process_group("nccl", init_method=method, rank=0, world_size=1, device_id=device)
+        probe = torch.zeros(1, device=device)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize(device)
+        return dist, "nccl"
+    dist.init_process_group("gloo", init_method=method, rank=0, world_size=1)
+    return dist, "gloo"
 
 
 def init_process_group(backend: str, device: torch.device, force_gloo: bool = False, allow_gloo: bool = False):
@@ -317,19 +368,20 @@ def traffic_fields(pmc_path: str, key: str, kernel_variant: str, build_id: Optio
 
 class Watchdog:
     """A stuck collective must not cost the main result -- but it must not look like success either: prints the
-    line it was given and exits with status 4."""
+    line it was given and exits with status 4 (``status``: the N = 1 line's optional leg on a one-rank group passes 0 --
+    there the leg is an extra, and the line without it is complete)."""
 
-    def __init__(self, seconds: float, rank: int, line_fn: Callable[[], str]):
+    def __init__(self, seconds: float, rank: int, line_fn: Callable[[], str], status: int = 4):
         import threading
         self._t = threading.Timer(seconds, self._fire)
         self._t.daemon = True
-        self.rank, self.line_fn = rank, line_fn
+        self.rank, self.line_fn, self.status = rank, line_fn, status
 
     def _fire(self):
         if self.rank == 0:
             print(self.line_fn(), flush=True)
-        print("[bench] watchdog: the multi-GPU extras did not finish; exiting with status 4", file=sys.stderr, flush=True)
-        os._exit(4)
+        print(f"[bench] watchdog: the sharded config-5 extras did not finish; exiting with status {self.status}", file=sys.stderr, flush=True)
+        os._exit(self.status)
 
     def __enter__(self):
         self._t.start()

@@ -174,3 +174,59 @@ def test_a_rank_whose_output_differs_from_the_reference_digest_fails_the_job(tmp
             assert out["sharded_cfg5"]["ranks_shard_digest_ok"] == [True, False] and out["ranks_parity_ok"] == [True, True]
         else:
             assert out["ranks_parity_ok"] == [False, False] and out["sharded_cfg5"]["ranks_shard_digest_ok"] == [True, True]
+
+
+def _bench(args, **env):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "bench.py", *args], cwd=repo, env=_clean_env(**env), capture_output=True, text=True, timeout=600)
+
+
+def _line(r):
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
+    return json.loads(lines[0])
+
+
+def test_the_multi_rank_line_names_every_ranks_device_and_refuses_shared_ones():
+    """the N > 1 line proves N devices.  Every rank reports the identity of the device it computes on
+    (uuid | PCI address | name on a GPU; the process on the CPU dry run) -> ``rank_devices`` / ``devices_distinct``; two ranks
+    on ONE device (forced here through MCTQ_BENCH_FAKE_DEVICE_ID) end the job with status 8 unless --allow-gloo marks the run as
+    a rehearsal, and then the line says ``devices_distinct: false``."""
+    import re
+    base = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--device", "cpu"]
+    out = _line(_bench(base))
+    assert len(out["rank_devices"]) == 2 and len(set(out["rank_devices"])) == 2 and out["devices_distinct"] is True
+    assert all(d.startswith("cpu|pid ") for d in out["rank_devices"])
+    r = _bench(base, MCTQ_BENCH_FAKE_DEVICE_ID="GPU-feed|0000:05:00|one device for both ranks")
+    assert r.returncode != 0 and re.search(r"exitcode\s*:\s*8\b", r.stderr), (r.returncode, r.stderr[-1500:])
+    assert "do not sit on 2 distinct devices" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = _bench(base + ["--allow-gloo"], MCTQ_BENCH_FAKE_DEVICE_ID="GPU-feed|0000:05:00|one device for both ranks")
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = _line(r)
+    assert out["devices_distinct"] is False and out["rank_devices"] == ["GPU-feed|0000:05:00|one device for both ranks"] * 2
+
+
+def test_the_single_rank_line_carries_the_three_sharded_series_too():
+    """compute-only, compute + all-gather and per-link figures at EVERY N.  At N = 1 without a launcher bench.py
+    forms a process group of one rank in-process and runs the same leg (per-link: null, no link is crossed); --no-sharded-extra
+    skips it."""
+    out = _line(_bench(["--steps", "3", "--warmup", "1", "--device", "cpu"]))
+    assert out["n_gpus"] == 1 and out["rank_devices"] and out["devices_distinct"] is True
+    leg = out["sharded_cfg5"]
+    assert leg["ranks"] == 1 and leg["gathered_rows_match_local"] is True and leg["ranks_shard_digest_ok"] == [True]
+    assert leg["gathered_equals_reference_digest"] is True and "one rank" in leg["process_group"]
+    assert out["sharded_cfg5_compute_elems_per_s"] > 0 and out["sharded_cfg5_compute_plus_allgather_elems_per_s"] > 0
+    assert "sharded_cfg5_allgather_gbs_per_link" in out and out["sharded_cfg5_allgather_gbs_per_link"] is None
+    out = _line(_bench(["--steps", "3", "--warmup", "1", "--device", "cpu", "--no-sharded-extra"]))
+    assert "sharded_cfg5" not in out
+
+
+def test_device_identity_helpers():
+    import bench_dist
+    assert bench_dist.device_identity(torch.device("cpu")).startswith("cpu|pid ")
+    assert bench_dist.gather_strings(None, "abc", None, torch.device("cpu")) == ["abc"]
+    ids, distinct = bench_dist.rank_devices(None, None, torch.device("cpu"))
+    assert len(ids) == 1 and distinct is True

@@ -17,7 +17,7 @@ def main():
     if name == "lut_compact":
         units, xdir = [], os.path.join(REPO, "tools", "experiments", "lut_compact")
         extra = [(os.path.join(xdir, "mctq_lut_compact.hip"), ["-I", xdir])]
-    elif name in ("lut_conflicts", "rowsteps_sched"):
+    elif name in ("lut_conflicts", "rowsteps_sched", "chanlast2"):
         units, xdir = [], os.path.join(REPO, "tools", "experiments", name)
         extra = [(os.path.join(xdir, name + ".hip"), ["-I", xdir])]
     for a in sys.argv[2:]:
