@@ -49,7 +49,15 @@ extern "C" {
 /* v8 (round 5): the compact-decision-table entry points (mctq_lut_compact_words, mctq_lut_build_compact, mctq_lutc_*) and the
  * tuning keys "heavy_persistent", "nt" = 0, "unroll" / "heavy_unroll" = 8 and the experiment codes of "ql_variant" left the
  * library with the kernels behind them (measured, not adopted: tools/experiments/); nothing else changed. */
-#define MCTQ_ABI_VERSION 8
+/* Size limit (since v8): a tensor of more than 2^32 - 8192 elements whose per-channel rows are shorter than 256 lane-vectors is
+ * taken in ONE launch by the affine fake-quantizers only (16-byte aligned x / y); the LUT, integer-code and export-grid entry
+ * points return MCTQ_E_ARG for it ("per-channel rows shorter than 256 lane-vectors above 2^32 elements: affine quantizers
+ * only") -- the Python layer (hip/ops.py: _split_rows) cuts such a tensor into row blocks below the limit and issues one launch
+ * per block, which is what a caller of the C ABI has to do as well.  Long rows and per-tensor launches have no such limit. */
+/* v9 (round 6): + mctq_selftest_reciprocal, + tuning key "gather16"; the channel-last (lastaxis) launch and the per-lane-vector
+ * (gather) launch invert a lane's own scales with a five-instruction exact reciprocal, and 16-bit short / ragged rows take the
+ * gather launch (no signature changed; results are bit-identical). */
+#define MCTQ_ABI_VERSION 9
 #define MCTQ_E_ARG (-10001)
 
 /* storage types of x (and of y for the affine entry points); arithmetic is always float32 */
@@ -474,6 +482,9 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  2544, 2548 (wave-wide tiles), 2560 (256 x 256 ping-pong)
  *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
+ *   key "gather16" : float16 / bfloat16 per-channel rows shorter than 256 lane-vectors through the per-lane-vector (gather) launch
+ *                  instead of the LDS parameter window: 0 = never, 1 (default) = rows that are not whole 8-element vectors or
+ *                  are shorter than 64 elements (measured faster there), 2 = every such tensor
  * Only variants a default dispatcher can select are instantiated; every value of every key is exercised by the GPU tests.
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */
@@ -488,6 +499,14 @@ int mctq_set_tuning(const char* key, int32_t value);
  * out saturated low: the kernels test the input itself for NaN).
  */
 int mctq_selftest_division(const float* divisors, int32_t n_div, uint64_t* mismatches, void* stream);
+
+/*
+ * Diagnostic: checks the five-instruction reciprocal the channel-last and short-row launches use for a lane's own scales
+ * (v_rcp_f32 + two Newton steps with exact FMA residuals; csrc/mctq_kernels.hpp: recip_exact) against the compiler's IEEE
+ * 1.0f / d for EVERY float32 bit pattern with 2^-100 <= |d| <= 2^100 (outside that range the kernels use the IEEE division).
+ * out3 (device uint64[3], zeroed by the caller) receives {patterns checked, mismatches, one mismatching pattern + 1}.
+ */
+int mctq_selftest_reciprocal(uint64_t* out3, void* stream);
 
 #ifdef __cplusplus
 }

@@ -604,6 +604,11 @@ struct BatchPlan {
   bool versioned;                          // skip the launch when nothing changed since the last one
   bool fresh;                              // the outputs hold the quantization of the inputs as recorded below
   std::vector<uint32_t>* seen;             // per item (affine items first, then LUT items): x version, y version after the launch
+  // versioned reuse: the storages the last launch READ stay referenced until the next launch, so that the caching allocator
+  // cannot hand their device pointers to a tensor that later becomes a planned weight (`w.data = tmp; w.data = fresh` with no
+  // forward in between: same sizes, dtype and version counter; without the reference `fresh` could sit where the launch read)
+  std::vector<c10::Storage>* held;
+  hipStream_t last_stream;                 // the stream of the last launch: a skip is only valid for work queued behind it
   int64_t launches, skips;
 };
 
@@ -740,7 +745,8 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
   if (n > 0 || nl > 0) {
     DeviceScope scope(p->device);
     hipStream_t st = c10::hip::getCurrentHIPStream(p->device).stream();
-    if (p->versioned && !changed && !dirty && !lut_dirty && !stream_is_capturing(st)) {
+    // (a call on ANOTHER stream is not ordered behind the launch that filled the outputs: it launches again, on its stream)
+    if (p->versioned && !changed && !dirty && !lut_dirty && st == p->last_stream && !stream_is_capturing(st)) {
       ++p->skips;                                    // the outputs ARE the quantization of these inputs: nothing to launch
       Py_RETURN_NONE;
     }
@@ -757,14 +763,18 @@ PyObject* batchplan_vectorcall(PyObject* self, PyObject* const*, size_t nargsf, 
       if (rc) return raise_rc(rc, "mctq_lutt_batch_run");
     }
     p->uploaded = true;
+    p->last_stream = st;
     ++p->launches;
     // the kernels rewrote every output in place: say so to autograd, and remember what this launch read and wrote
+    if (p->versioned) p->held->clear();
     for (size_t i = 0; i < n + nl; ++i) {
       PyObject* const* r = i < n ? &(*p->refs)[4 * i] : &(*p->lut_refs)[4 * (i - n)];
+      const at::Tensor& x = THPVariable_Unpack(r[0]);
       const at::Tensor& y = THPVariable_Unpack(r[1]);
       if (!y.is_inference()) y.unsafeGetTensorImpl()->bump_version();
-      seen[2 * i] = version_of(THPVariable_Unpack(r[0]));
+      seen[2 * i] = version_of(x);
       seen[2 * i + 1] = version_of(y);
+      if (p->versioned) p->held->push_back(x.storage());
     }
     p->fresh = true;
   }
@@ -780,6 +790,7 @@ void batchplan_dealloc(PyObject* self) {
   delete p->items; delete p->refs; delete p->sizes; delete p->strides; delete p->axes; delete p->watch; delete p->groups; delete p->host_table; delete p->dev_table;
   delete p->lut_items; delete p->lut_refs; delete p->lut_sizes; delete p->lut_axes; delete p->lut_host_table; delete p->lut_dev_table;
   delete p->seen;
+  delete p->held;
   Py_TYPE(self)->tp_free(self);
 }
 
@@ -840,6 +851,8 @@ PyObject* batchplan_new(PyTypeObject* type, PyObject* args, PyObject*) {
   p->device = -1;
   p->versioned = versioned != 0; p->fresh = false; p->launches = 0; p->skips = 0;
   p->seen = new std::vector<uint32_t>();
+  p->held = new std::vector<c10::Storage>();
+  p->last_stream = nullptr;
   const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
   const char* err = nullptr;
   for (Py_ssize_t i = 0; i < n && !err; ++i) {

@@ -120,6 +120,30 @@ struct IO {
 
 struct NoBook {};
 
+// 1 / d, correctly rounded, for a POSITIVE d in [2^-100, 2^100] in five VALU instructions: v_rcp_f32 (1 ulp) and two Newton
+// steps whose residuals 1 - d * r are exact FMAs -- against the eleven of the compiler's IEEE expansion (two v_div_scale,
+// v_rcp, five FMAs, v_div_fmas, v_div_fixup), which only differs in how it treats the exponent range and the special values
+// excluded here.  Equal to `1.0f / d` for every one of the 3 355 443 202 float32 bit patterns of that range and its negative
+// mirror (mctq_selftest_reciprocal, tests/test_gpu_parity.py; profiles/r06/chanlast2_a.log).  Used where a LANE owns its own
+// divisors (channel-last and short-row launches: N reciprocals per lane); wave-uniform divisors keep the plain division.
+__device__ __forceinline__ float recip_exact(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+// every one of M values is a positive float in [2^-100, 2^100]: compared as raw bit patterns (negative values, NaNs and
+// infinities are large unsigned numbers) -- M min / max operations and two compares
+constexpr uint32_t kRecipLo = 0x0d800000u, kRecipHi = 0x71800000u;
+template <int M>
+__device__ __forceinline__ bool recip_all_in_range(const float (&v)[M]) {
+  uint32_t lo = __float_as_uint(v[0]), hi = lo;
+#pragma unroll
+  for (int j = 1; j < M; ++j) { const uint32_t b = __float_as_uint(v[j]); lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+  return lo >= kRecipLo && hi <= kRecipHi;
+}
+
 struct AffineOp {
   static constexpr const char* kName = "AffineOp";
   const float* __restrict__ scales;    // [C] (per-channel launches only)
@@ -151,6 +175,29 @@ struct AffineOp {
       if (zps) z4 = *reinterpret_cast<const i32x4*>(zps + c + j);       // NULL = all zero (symmetric)
 #pragma unroll
       for (int i = 0; i < 4; ++i) p[j + i] = make(s4[i], z4[i]);
+    }
+  }
+  // The same N channels for a lane that owns them (channel-last launches): the N reciprocals by recip_exact when every
+  // active lane of the wave qualifies (wave-uniform branch), and -- ZP false: the launch has no zero-point table -- zf a
+  // compile-time zero, so that the shifted bounds lo - zf / hi - zf of apply() stay the two scalar registers.
+  template <int N, bool ZP>
+  __device__ __forceinline__ void fetch_lane(uint32_t c, Param* p) const {
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    float sv[N];
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(scales + c + j);
+      i32x4 z4 = {0, 0, 0, 0};
+      if (ZP) z4 = *reinterpret_cast<const i32x4*>(zps + c + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sv[j + i] = s4[i]; p[j + i].s = s4[i]; p[j + i].zf = ZP ? (float)z4[i] : 0.0f; }
+    }
+    if (__builtin_amdgcn_ballot_w64(!recip_all_in_range(sv)) == 0) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) p[j].inv = recip_exact(sv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) p[j].inv = 1.0f / sv[j];
     }
   }
   __host__ bool tables_aligned16() const { return (((uintptr_t)scales | (uintptr_t)zps) & 15u) == 0; }
@@ -890,43 +937,95 @@ __global__ __launch_bounds__(kThreads) void rowsteps_kernel(const TI* __restrict
     }
 }
 
+// n / d for n < 2^24 (exactly representable in float32) and a wave-uniform d with r = 1.0f / d: the float quotient
+// is off by at most one, two integer corrections make it exact -- 7 VALU ops instead of the ~25 of a 32-bit
+// unsigned division.  The window kernel's positions are offsets inside one tile (+ one row).
+__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t d, float r) {
+  uint32_t q = (uint32_t)((float)n * r);
+  q -= (q * d > n) ? 1u : 0u;
+  q += ((q + 1u) * d <= n) ? 1u : 0u;
+  return q;
+}
+
 // ------------------------------------------------------------------------------------------
 // lastaxis: the channel axis is the fastest-varying one (inner == 1: NHWC activations, [tokens, hidden],
 // weights quantized along their last axis) and C % N == 0.  A lane's N consecutive elements are N
-// consecutive channels.  The lanes of `bps` neighbouring blocks are laid over k whole rows (k * vc lane
-// vectors, contiguous in memory) and step DOWN the tensor k rows at a time, so every lane keeps the same N
-// channels: their parameters are fetched (16-byte table loads) and inverted once per lane, not per element.
+// consecutive channels.  The tensor is cut into SLABS of k whole rows (k * vc lane-vectors, contiguous in
+// memory, >= 2048 of them); grid (x, y, z) = (256-lane pieces of a slab, groups of U slabs): the block's lanes
+// are laid over one piece of the slab and step DOWN the tensor a slab at a time, so every lane keeps the same
+// N channels: their parameters are fetched (16-byte table loads) and inverted once per lane, not per element.
+// Round 6 (profiles/r06/chanlast2_*.log, tools/experiments/chanlast2/): the lane's offset inside the slab IS its
+// memory offset, so nothing stands in front of the data loads -- the column, which only the parameter fetch needs,
+// is divided out under their latency (the round-5 form ran two integer divisions and four exec-masked loads with
+// 64-bit multiplies first); N reciprocals per lane by recip_exact (5 instead of 11 VALU instructions each); a launch
+// without zero points keeps its clamp bounds in scalar registers; every result first, then the stores back to back.
+// Together 3-7 % on 10 of 10 channel-last shapes x 3 storage types, 11 % with zero points; two rows per lane (four
+// with zero points: more parameter work per lane to spread) measured best -- looping blocks and a software pipeline
+// over the slabs lost 3-10 % everywhere, rotating the pieces over the XCDs or a group-major grid bought nothing.
 // ------------------------------------------------------------------------------------------
-template <class Op, class TI, class TO, int U, int NT>
-__global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict__ xs, TO* __restrict__ ys,
-                                                            uint64_t rows, uint32_t vc, uint32_t k, uint32_t bps, Op op) {
+template <class Op, class TI, class TO, int U, int NT, bool ZP, bool FULL>
+__device__ __forceinline__ void lastaxis_body(const Op& op, float* smem, const TI* __restrict__ xs, TO* __restrict__ ys,
+                                              uint64_t rows_left, uint32_t vc, uint32_t k, float rvc, uint32_t g,
+                                              uint32_t slab) {
   typedef IO<TI, TO> io;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const uint32_t g = (blockIdx.x % bps) * kThreads + threadIdx.x;      // lane inside the k-row group
-  const uint32_t ro = g / vc, col = g - ro * vc;
-  const bool lane_ok = ro < k;
-  const uint64_t row0 = (uint64_t)(blockIdx.x / bps) * ((uint64_t)U * k) + ro;
+  if constexpr (std::is_same<typename Op::Book, NoBook>::value) {
+    if (g >= slab) return;                                   // idle lanes of the slab's last piece (ops with a table stay for its barrier)
+  }
+  // lanes of slab u that hold a row of the tensor (wave-uniform bound; the last group of a launch may be short)
+  uint32_t lim[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (FULL) lim[u] = slab;
+    else {
+      const uint64_t r = rows_left > (uint64_t)u * k ? rows_left - (uint64_t)u * k : 0;
+      lim[u] = (r >= k ? k : (uint32_t)r) * vc;
+    }
+  }
   typename io::VI v[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint64_t row = row0 + (uint64_t)u * k;
-    if (lane_ok && row < rows) v[u] = io::template load<NT>(xs + (row * vc + col) * io::N);
-  }
-  const typename Op::Book book = op.setup(smem);
-  if (!lane_ok) return;
+  for (int u = 0; u < U; ++u)
+    if ((FULL && std::is_same<typename Op::Book, NoBook>::value) || g < lim[u])
+      v[u] = io::template load<NT>(xs + ((size_t)u * slab + g) * io::N);
+  __builtin_amdgcn_sched_barrier(0);                         // the loads first; everything below runs under their latency
+  const typename Op::Book book = op.setup(smem);             // every thread of the block (a LUT op's table goes to LDS)
+  if (g >= slab) return;
+  const uint32_t col = g - div_small(g, vc, rvc) * vc;       // slab < 2^24 lane-vectors (launch_channels)
   typename Op::Param p[io::N];
-  op.template fetch_vec<io::N>(col * io::N, p);
+  if constexpr (std::is_base_of<AffineOp, Op>::value) op.template fetch_lane<io::N, ZP>(col * io::N, p);
+  else op.template fetch_vec<io::N>(col * io::N, p);
+  typename io::VO r[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint64_t row = row0 + (uint64_t)u * k;
-    if (row < rows) {
+  for (int u = 0; u < U; ++u)
+    if (g < lim[u]) {
       float in[io::N], out[io::N];
       io::unpack(v[u], in);
 #pragma unroll
       for (int j = 0; j < io::N; ++j) out[j] = op.template apply<false>(in[j], p[j], book);
-      io::template store<NT>(ys + (row * vc + col) * io::N, io::pack(out));
+      r[u] = io::pack(out);
     }
-  }
+  __builtin_amdgcn_sched_barrier(0);                         // every result, then the stores back to back
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (g < lim[u]) io::template store<NT>(ys + ((size_t)u * slab + g) * io::N, r[u]);
+}
+
+template <class Op, class TI, class TO, int U, int NT, bool ZP>
+__global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict__ xs, TO* __restrict__ ys, uint64_t rows,
+                                                            uint32_t vc, uint32_t k, float rvc, uint32_t groups, Op op) {
+  typedef IO<TI, TO> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t slab = k * vc;
+  const uint32_t g = blockIdx.x * kThreads + threadIdx.x;    // lane-vector inside the slab == its offset in memory
+  const uint32_t group = blockIdx.y + blockIdx.z * gridDim.y;
+  if (group >= groups) return;                               // (uniform: the y x z grid may overshoot)
+  const uint64_t row0 = (uint64_t)group * (uint32_t)(U * k);
+  const uint64_t rows_left = rows - row0;
+  const TI* x0 = xs + row0 * vc * io::N;
+  TO* y0 = ys + row0 * vc * io::N;
+  if (rows_left >= (uint64_t)U * k)
+    lastaxis_body<Op, TI, TO, U, NT, ZP, true>(op, smem, x0, y0, rows_left, vc, k, rvc, g, slab);
+  else
+    lastaxis_body<Op, TI, TO, U, NT, ZP, false>(op, smem, x0, y0, rows_left, vc, k, rvc, g, slab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -938,16 +1037,6 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict
 // (channel-last layouts: inner == 1, C small) the whole table is staged instead and indexed
 // modulo C.
 // ------------------------------------------------------------------------------------------
-// n / d for n < 2^24 (exactly representable in float32) and a wave-uniform d with r = 1.0f / d: the float quotient
-// is off by at most one, two integer corrections make it exact -- 7 VALU ops instead of the ~25 of a 32-bit
-// unsigned division.  The window kernel's positions are offsets inside one tile (+ one row).
-__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t d, float r) {
-  uint32_t q = (uint32_t)((float)n * r);
-  q -= (q * d > n) ? 1u : 0u;
-  q += ((q + 1u) * d <= n) ? 1u : 0u;
-  return q;
-}
-
 template <class Op, class TI, class TO, int U, bool VEC, int NT, typename IdxT>
 __global__ __launch_bounds__(kThreads) void window_kernel(const TI* __restrict__ xs, TO* __restrict__ ys, IdxT n,
                                                           uint32_t inner, uint32_t channels,
@@ -1066,7 +1155,8 @@ struct LaunchNote { const char* shape; const char* op; int unroll, nt, in_bytes,
 extern thread_local LaunchNote g_note;
 // MCTQ_LAUNCH_LOG=<file> in the environment when the library is loaded: every launch VARIANT (the text of
 // mctq_last_launch()) is appended to that file the first time the process takes it -- the evidence the set of
-// instantiated kernels is pruned against (tools/launch_log_summary.py).  Off: one predictable branch per launch.
+// instantiated kernels is pruned against (profiles/r05/launch_variants_all.log: the file itself, sorted).  Off: one predictable
+// branch per launch.
 extern int g_launch_log;
 void log_launch();
 template <class Op, class TI, class TO>
@@ -1156,6 +1246,13 @@ inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st,
       }                                                                                     \
     }                                                                                       \
   } while (0)
+
+// does the launch carry a zero-point table?  (affine ops: NULL = symmetric quantizers; everything else: not a question)
+template <class Op>
+static bool has_zero_points(const Op& op) {
+  if constexpr (std::is_base_of<AffineOp, Op>::value) return op.zps != nullptr;
+  else return true;
+}
 
 template <class TI, class TO, class Op>
 static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv, void* yv, int64_t n,
@@ -1282,13 +1379,8 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
 
   // lastaxis shape.
   if (vec_ok && inner == 1 && (channels % io::N) == 0 && channels <= 0x7fffffffLL && op.tables_aligned16()) {
-    // rows per lane: 4 for every storage type.  (16-bit tensors had 8 until round 5 -- twice the rows to spread a lane's N
-    // reciprocals over; measured, 4 is 3-5 % faster on 8 of 10 channel-last shapes and equal on the others but one (16
-    // channels: +0.5 ... +5 %): 90 -> ~50 VGPRs, and twice the blocks, so a 64 MiB launch is two rounds of resident blocks
-    // instead of one whose reads and writes separate into phases; 2 is slower everywhere: profiles/r05/lastaxis_lu_probe.log)
-    constexpr int LU = 4;
     const int64_t vc = channels / io::N;                              // lane vectors per row
-    // rows per step: enough lanes (>= 2048) that the idle tail of the last block is small; among the next few
+    // rows per slab: enough lanes (>= 2048) that the idle tail of the slab's last block is small; among the next few
     // candidates take the one that wastes the fewest lanes
     int64_t k = (2048 + vc - 1) / vc, best_waste = -1;
     for (int64_t c = k; c < k + 16; ++c) {
@@ -1296,14 +1388,31 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       if (best_waste < 0 || waste < best_waste) { best_waste = waste; k = c; }
     }
     const int64_t bps = (k * vc + kThreads - 1) / kThreads;
-    const int64_t blocks = bps * ((outer + LU * k - 1) / (LU * k));
-    if (blocks <= 0x7fffffffLL && k * vc <= 0x7fffffffLL) {
-      MCTQ_WITH_OP_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
-        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, LU, NT>), dim3((unsigned)blocks), dim3(kThreads), book_bytes, st,
-                           x, y, (uint64_t)outer, (uint32_t)vc, (uint32_t)k, (uint32_t)bps, op);
-        note<Op, TI, TO>("lastaxis_kernel", LU, NT);
-      });
-      return check_launch("lastaxis launch");
+    if (k * vc < (1 << 24) && bps <= 0x7fffffffLL) {                  // the kernel divides slab offsets through float32
+      // slabs per lane: two; four for the affine quantizers with a zero-point table (twice the parameter work per lane to
+      // spread: 4096^2 bfloat16 13.7 vs 14.2 us) -- measured on 14 shapes x 3 storage types, profiles/r06/chanlast2_sched.log
+      const bool zp4 = std::is_same<Op, AffineOp>::value && has_zero_points(op);
+      const int64_t LU = zp4 ? 4 : 2;
+      const int64_t groups = (outer + LU * k - 1) / (LU * k);
+      const int64_t gy = groups < 65535 ? groups : 65535, gz = (groups + gy - 1) / gy;
+      if (groups <= 0xffffffffLL && gz <= 65535) {
+        const dim3 grid((unsigned)bps, (unsigned)gy, (unsigned)gz);
+        const float rvc = 1.0f / (float)vc;
+#define MCTQ_LASTAXIS(U_, NT_, ZP_)                                                                                   \
+        hipLaunchKernelGGL((lastaxis_kernel<Op, TI, TO, U_, NT_, ZP_>), grid, dim3(kThreads), book_bytes, st, x, y,   \
+                           (uint64_t)outer, (uint32_t)vc, (uint32_t)k, rvc, (uint32_t)groups, op)
+        MCTQ_WITH_OP_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
+          if constexpr (std::is_same<Op, AffineOp>::value) {
+            if (zp4) MCTQ_LASTAXIS(4, NT, true);
+            else MCTQ_LASTAXIS(2, NT, false);
+          } else {
+            MCTQ_LASTAXIS(2, NT, true);
+          }
+          note<Op, TI, TO>("lastaxis_kernel", (int)LU, NT);
+        });
+#undef MCTQ_LASTAXIS
+        return check_launch("lastaxis launch");
+      }
     }
   }
 

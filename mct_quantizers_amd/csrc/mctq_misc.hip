@@ -17,6 +17,7 @@ int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggrega
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_rowsteps = 2;           // 2: rowsteps_kernel only where it measured faster (see launch_channels)
+int g_gather16 = 1;           // 16-bit short / ragged rows through the per-lane-vector path: 0 never, 1 the measured rule, 2 always (mctq_affine.hip)
 int g_ql_variant = 0;
 int g_ql_band = 0;
 int g_ql_stagger = 0;         // tiled consumer kernel: half of the waves copy after multiplying (experiment: no gain)
@@ -74,6 +75,21 @@ __global__ __launch_bounds__(kThreads) void selftest_division_kernel(const float
     }
     if (bad) atomicAdd(&mismatches[j], (unsigned long long)bad);
   }
+}
+
+// Self-test: recip_exact against the compiler's IEEE 1.0f / d for EVERY float32 bit pattern of its range (both signs).
+__global__ __launch_bounds__(kThreads) void selftest_reciprocal_kernel(unsigned long long* __restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+  unsigned long long bad = 0, seen = 0, first = 0;
+  for (uint64_t b = (uint64_t)blockIdx.x * kThreads + threadIdx.x; b < (1ull << 32); b += stride) {
+    const uint32_t mag = (uint32_t)b & 0x7fffffffu;
+    if (mag < kRecipLo || mag > kRecipHi) continue;
+    ++seen;
+    const float d = __uint_as_float((uint32_t)b);
+    if (__float_as_uint(1.0f / d) != __float_as_uint(recip_exact(d))) { ++bad; if (!first) first = b + 1; }
+  }
+  if (seen) atomicAdd(&out[0], seen);
+  if (bad) { atomicAdd(&out[1], bad); atomicMax(&out[2], first); }
 }
 
 }  // namespace mctq
@@ -148,6 +164,11 @@ int mctq_set_tuning(const char* key, int32_t value) {
     g_heavy_unroll = value;
     return 0;
   }
+  if (!strcmp(key, "gather16")) {
+    if (value != 0 && value != 1 && value != 2) return fail_arg("gather16 must be 0, 1 or 2");
+    g_gather16 = value;
+    return 0;
+  }
   if (!strcmp(key, "rowsteps")) {
     if (value != 0 && value != 1 && value != 2) return fail_arg("rowsteps must be 0, 1 or 2");
     g_rowsteps = value;
@@ -184,6 +205,13 @@ int mctq_selftest_division(const float* divisors, int32_t n_div, uint64_t* misma
   if (!divisors || !mismatches || n_div < 1) return fail_arg("bad selftest arguments");
   hipLaunchKernelGGL(selftest_division_kernel, dim3(cu_count() * 8), dim3(kThreads), 0, (hipStream_t)stream,
                      divisors, (int)n_div, reinterpret_cast<unsigned long long*>(mismatches));
+  return check_launch("selftest launch");
+}
+
+int mctq_selftest_reciprocal(uint64_t* out3, void* stream) {
+  if (!out3) return fail_arg("bad selftest arguments");
+  hipLaunchKernelGGL(selftest_reciprocal_kernel, dim3(cu_count() * 8), dim3(kThreads), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long*>(out3));
   return check_launch("selftest launch");
 }
 

@@ -14,7 +14,7 @@ import ctypes
 import os
 import threading
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
 CODE_I8, CODE_U8, CODE_I4, CODE_U4 = 0, 1, 2, 3
 FQ_ITEM_PER_TENSOR = 1
@@ -59,6 +59,7 @@ SIGNATURES = {
     "mctq_launch_count": (ctypes.c_int64, []),
     "mctq_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
     "mctq_selftest_division": (ctypes.c_int, [_c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "mctq_selftest_reciprocal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mctq_fq_per_tensor_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mctq_fq_per_channel_f32": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,

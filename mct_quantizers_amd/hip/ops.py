@@ -72,6 +72,42 @@ def _channel_view(x: torch.Tensor, axis: int) -> Tuple[int, int, int]:
     return outer, c, inner
 
 
+# What ONE launch of the non-affine per-channel entry points takes when the rows are short (include/mctq_hip.h, "Size limit"):
+# larger tensors are cut into row blocks below it, one launch each.  A module constant so that tests can lower it.
+_SPLIT_ELEMS = (1 << 32) - 8192
+
+
+def _split_rows(x: torch.Tensor, axis: int, params, out_dtype, call, limit: int = None) -> torch.Tensor:
+    """``call`` applied block by block to a DENSE tensor too large for one launch.  x is walked in storage order as
+    [outer][channels][inner]; a block is a run of whole outer slices, or -- when one slice alone exceeds ``limit`` elements -- a
+    run of whole channel rows of one slice, with the per-channel ``params`` (1-D tensors of ``channels`` entries) sliced
+    alike.  ``call(x_block [k, ch, inner] contiguous, params_block, 1)`` returns that block's result (same dense order).
+    Returns the result with x's sizes and strides."""
+    limit = _SPLIT_ELEMS if limit is None else limit
+    n = x.numel()
+    outer, c, inner = _channel_view(x, axis)
+    flat = torch.as_strided(x, (n,), (1,), x.storage_offset())
+    y = torch.empty(n, dtype=out_dtype, device=x.device)
+    per_slice = c * inner
+    if per_slice <= limit:
+        k = max(1, limit // per_slice)
+        for o0 in range(0, outer, k):
+            o1 = min(outer, o0 + k)
+            piece = flat[o0 * per_slice:o1 * per_slice].view(o1 - o0, c, inner)
+            y[o0 * per_slice:o1 * per_slice] = call(piece, tuple(params), 1).reshape(-1)
+    else:
+        if inner > limit:
+            raise NotImplementedError(f"a single channel row of {inner} elements exceeds what one launch takes ({limit})")
+        rows = max(1, limit // inner)
+        for o in range(outer):
+            for ch0 in range(0, c, rows):
+                ch1 = min(c, ch0 + rows)
+                a, b = (o * c + ch0) * inner, (o * c + ch1) * inner
+                piece = flat[a:b].view(1, ch1 - ch0, inner)
+                y[a:b] = call(piece, tuple(p[ch0:ch1] for p in params), 1).reshape(-1)
+    return torch.as_strided(y, x.shape, x.stride())
+
+
 _raw_stream = torch._C._cuda_getCurrentRawStream      # (device index) -> hipStream_t as int
 _current_device = torch._C._cuda_getDevice
 
@@ -354,6 +390,10 @@ def _hip_lut_per_channel(x, lut, thresholds, eps: float, axis: int, mult: float,
         x = x.to(torch.float32)          # as in _hip_lut_per_tensor
     dt = _dtype_code(x, "lut_per_channel")
     _check_axis(x, thresholds.numel(), axis)
+    if x.numel() > _SPLIT_ELEMS and thresholds.numel() > 1:            # more than one launch of the short-row kernels takes
+        y = _split_rows(_dense_input(x), axis, (thresholds,), torch.float32,
+                        lambda xp, ps, ax: _hip_lut_per_channel(xp, lut, ps[0], eps, ax, mult, cmin, cmax, table, steps))
+        return _lut_result(x, y)
     if dt != native.DT_F64 and table is not None and native.TRACE is False:
         f = _FAST if _FAST_READY else _fast_mod()
         if f is not None:
@@ -409,6 +449,9 @@ def _hip_grid_per_channel(x, los, his, steps, axis: int, shifted: bool):
     _check_axis(x, steps.numel(), axis)
     lib = native.load()
     x = _dense_input(x)
+    if x.numel() > _SPLIT_ELEMS and steps.numel() > 1:
+        return _split_rows(x, axis, (los.reshape(-1), his.reshape(-1), steps.reshape(-1)), torch.float32,
+                           lambda xp, ps, ax: _hip_grid_per_channel(xp, ps[0], ps[1], ps[2], ax, shifted))
     y = torch.empty_like(x)
     outer, c, inner = _channel_view(x, axis)
     los, his, steps = (t.to(device=x.device, dtype=torch.float32).contiguous() for t in (los, his, steps))
@@ -488,6 +531,9 @@ def fq_codes(x, scales, zero_points, axis, qmin: int, qmax: int, scale0: float =
     lib = native.load()
     if not x.is_contiguous():
         x = _dense_input(x)
+    if axis is not None and not packed4 and x.numel() > _SPLIT_ELEMS and scales.numel() > 1:
+        return _split_rows(x, axis, (scales.reshape(-1), zero_points.reshape(-1)), tdt,
+                           lambda xp, ps, ax: fq_codes(xp, ps[0], ps[1], ax, qmin, qmax))
     if packed4:
         code = native.CODE_I4 if qmin < 0 else native.CODE_U4
         y = torch.empty(_packed_shape(x), dtype=torch.uint8, device=x.device)

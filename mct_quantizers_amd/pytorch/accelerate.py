@@ -70,8 +70,11 @@ def accelerate(model: nn.Module, example_inputs: Optional[Sequence[torch.Tensor]
         if example_inputs is not None:
             raise ValueError('reuse="versioned" does not combine with example_inputs (a captured forward replays its launch)')
         handle = model.__dict__.get(_KEY)
-        if handle is not None and not handle.versioned:
-            decelerate(model)                              # re-install in the versioned form
+        # (getattr: a handle un-pickled from a model saved by a build without versioned reuse has no such attribute)
+        if handle is not None and not getattr(handle, "versioned", False):
+            # re-install in the versioned form; a forward replay the caller had installed (capture=True) comes back with it
+            capture = capture or model.__dict__.get("_mctq_auto_capture") is not None
+            decelerate(model)
     if capture and example_inputs is None:
         return auto_capture(model, reuse=reuse)
     if example_inputs is not None:

@@ -19,7 +19,12 @@ are replaced or edited quantizer parameters, ``model.half()`` / ``.to(device)`` 
 re-checks its tensors and the quantizers' public attributes on every call and is rebuilt when something changed.
 Only adding / removing wrappers needs ``handle.refresh()``.  Every launch bumps the in-place version counter of the
 persistent outputs it rewrites, so autograd notices a quantized weight saved for a backward and overwritten by a later
-forward exactly as it notices any other in-place write.
+forward exactly as it notices any other in-place write.  A forward that autograd may record -- grad mode on and an input
+of the model or one of its parameters requiring a gradient -- does NOT get the persistent tensors at all: a wrapped layer
+saves its quantized weight for the input gradient, two forwards before one backward (``(model(a) + model(b)).sum()
+.backward()``) would then find the first forward's saved weight overwritten by the second, where the reference, which
+returns fresh tensors, works.  Such forwards take the fresh-tensor launch below (still one launch per storage type);
+forwards under ``torch.no_grad()`` / ``torch.inference_mode()`` or of a fully frozen model keep the one-C-call path.
 ``versioned=True`` (``accelerate(model, reuse="versioned")``) adds plan-level versioned reuse: a forward whose weights are
 what the last launch read issues NO launch at all (the reference's ``enable_reuse_quantizer`` idea,
 base_pytorch_inferable_quantizer.py:34-49, without its staleness: an optimizer step, ``load_state_dict``, a ``.data``
@@ -74,6 +79,8 @@ class BatchedWeightQuantization:
         state = dict(self.__dict__)
         state["_plan"] = None
         state["_wrappers"] = None
+        state["_params"] = None
+        state["_installed"] = None
         state["_cell"] = [0, False]
         state.pop("_auto_failed", None)
         return state
@@ -175,7 +182,8 @@ class BatchedWeightQuantization:
         for wrapper, outs in per_wrapper.items():
             wrapper.__dict__["_prequantized_plan"] = (self._cell, outs)
             wrapper.__dict__.pop("_prequantized_seen", None)
-        return plan, len(entries)
+        self.__dict__["_installed"] = "plan"
+        return plan, len(entries), per_wrapper
 
     def refresh(self):
         """Rebuild the pre-packed plan at the next forward.  Not needed after changing quantizer parameters or moving /
@@ -197,18 +205,54 @@ class BatchedWeightQuantization:
     def _drop_plan(self):
         self._plan = None
         self.__dict__["_wrappers"] = None
+        self.__dict__["_params"] = None
+        self.__dict__["_installed"] = None
         for m in self.model.modules():
             if isinstance(m, PytorchQuantizationWrapper):
                 m.__dict__.pop("_prequantized_plan", None)
                 m.__dict__.pop("_prequantized_seen", None)
 
-    def quantize_now(self) -> int:
+    def _recorded_by_autograd(self, args) -> bool:
+        """May this forward's quantized weights be SAVED for a backward?  Grad mode on and a tensor among the model's
+        inputs, or a parameter of the model, requires a gradient (a layer saves its -- constant -- weight whenever its input
+        requires one).  The persistent buffers of the pre-packed plan must not be handed to such a forward."""
+        if not torch.is_grad_enabled():
+            return False
+        for a in args or ():
+            if isinstance(a, torch.Tensor):
+                if a.requires_grad:
+                    return True
+            elif isinstance(a, (list, tuple)):
+                if any(isinstance(t, torch.Tensor) and t.requires_grad for t in a):
+                    return True
+        params = self.__dict__.get("_params")
+        if params is None:                # refresh() / a rebuilt plan re-reads the list; requires_grad itself is read per call
+            params = self.__dict__["_params"] = list(self.model.parameters())
+        for p in params:
+            if p.requires_grad:
+                return True
+        return False
+
+    def _install(self, per_wrapper, kind):
+        """Point every wrapper at the tensors of THIS forward (``kind``: "plan" persistent buffers, "fresh" new tensors); a
+        wrapper without an entry loses whatever an earlier forward of the other kind left it."""
+        cell = self._cell
+        for m in self.__dict__.get("_wrappers") or ():
+            ready = per_wrapper.get(m)
+            if ready is None:
+                m.__dict__.pop("_prequantized_plan", None)
+            else:
+                m.__dict__["_prequantized_plan"] = (cell, ready)
+        self.__dict__["_installed"] = kind
+
+    def quantize_now(self, args=None) -> int:
         """Quantize every participating weight in one batched launch and hand the results to the wrappers.
-        Returns the number of tensors quantized."""
+        Returns the number of tensors quantized.  ``args``: the model's inputs (the forward pre-hook passes them)."""
         cell = self._cell
         if self.auto and self._plan is None and not self._auto_applies():
             return 0
-        if self.reuse_buffers and not torch.jit.is_tracing():
+        # (a direct call -- no ``args`` -- is not a forward: nothing it prepares can be saved for a backward)
+        if self.reuse_buffers and not torch.jit.is_tracing() and not (args is not None and self._recorded_by_autograd(args)):
             for _ in range(2):                                       # a stale plan is rebuilt once, then given up
                 plan = self._plan
                 if plan is None:
@@ -217,6 +261,8 @@ class BatchedWeightQuantization:
                 if plan is None:
                     break
                 if plan[0]() is None:                                # ONE C call: tensors re-checked, one launch
+                    if self.__dict__.get("_installed") != "plan":    # a recorded forward in between handed out fresh tensors
+                        self._install(plan[2], "plan")
                     cell[0] += 1
                     cell[1] = True
                     return plan[1]
@@ -234,8 +280,7 @@ class BatchedWeightQuantization:
         per_wrapper = {}
         for (wrapper, name, _, _), y in zip(entries, outs):
             per_wrapper.setdefault(wrapper, {})[name] = y
-        for wrapper, ready in per_wrapper.items():
-            wrapper.__dict__["_prequantized_plan"] = (cell, ready)
+        self._install(per_wrapper, "fresh")
         cell[0] += 1
         cell[1] = True
         return len(entries)
@@ -251,14 +296,14 @@ class BatchedWeightQuantization:
 
     def _before_forward(self, module, args):
         if not self.auto:
-            self.quantize_now()
+            self.quantize_now(args)
             return None
         # auto mode was installed on a model nobody asked to batch: whatever goes wrong here must not become the forward's
         # problem -- the per-layer calls are always there (and raise what the reference would raise, if anything)
         if self.__dict__.get("_auto_failed"):
             return None
         try:
-            self.quantize_now()
+            self.quantize_now(args)
         except Exception as e:  # noqa: BLE001
             self.__dict__["_auto_failed"] = True
             self._cell[1] = False

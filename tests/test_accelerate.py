@@ -140,7 +140,7 @@ def test_an_error_inside_the_auto_hook_never_reaches_the_forward(caplog):
     x = torch.randn(2, 3, 10, 10)
     want = net(x)
 
-    def boom():
+    def boom(args=None):
         raise RuntimeError("synthetic")
     handle.quantize_now = boom
     assert torch.equal(net(x), want) and handle.__dict__.get("_auto_failed") is True      # stood down, forward unchanged
@@ -214,6 +214,23 @@ def test_accelerate_reuse_argument():
     with torch.no_grad():
         assert torch.equal(net(x), _small_model()(x))
     h.invalidate()                                           # harmless without a plan
+    mq.decelerate(net)
+
+
+def test_versioned_reinstall_keeps_a_capture_and_reads_old_handles():
+    """accelerate(model, reuse="versioned") on a model that already replays its forward (capture=True) used to
+    drop the AutoCapture silently; and a handle un-pickled from a build without versioned reuse has no ``versioned`` attribute."""
+    net = _small_model()
+    mq.accelerate(net, capture=True)
+    assert net.__dict__.get("_mctq_auto_capture") is not None and mq.accelerated(net).versioned is False
+    mq.accelerate(net, reuse="versioned")
+    assert mq.accelerated(net).versioned is True and net.__dict__.get("_mctq_auto_capture") is not None
+    mq.decelerate(net)
+    assert net.__dict__.get("_mctq_auto_capture") is None
+    mq.accelerate(net)
+    del mq.accelerated(net).__dict__["versioned"]            # what an older build pickled
+    mq.accelerate(net, reuse="versioned")
+    assert mq.accelerated(net).versioned is True
     mq.decelerate(net)
 
 
@@ -745,6 +762,48 @@ def test_versioned_reuse_skips_the_weight_launch_until_something_changes(compile
 
 
 @pytest.mark.gpu
+def test_versioned_reuse_follows_the_stream_and_a_double_data_swap(compiled_binding):
+    """ADVICE r05 (low).  (a) A skip is valid only for work queued behind the launch that filled the outputs: a forward on
+    ANOTHER stream launches again, on its stream (then skips there).  (b) ``w.data = tmp; w.data = fresh`` with no forward in
+    between keeps sizes, dtype and version counter; the plan keeps the storages its last launch read alive, so the caching
+    allocator cannot place ``fresh`` where that launch read and the changed device pointer gives the swap away."""
+    model = mq.accelerate(_small_model("cuda").eval(), reuse="versioned")
+    ref = _small_model("cuda").eval()
+    h = mq.accelerated(model)
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+
+    def same_as_ref():
+        with torch.no_grad():
+            ref(x)
+        a, b = _quantized_weights(model), _quantized_weights(ref)
+        return all(bits_equal(a[k], b[k]) for k in b)
+
+    _forward_launches(model, x)
+    assert _forward_launches(model, x)[0] == 1 and h.stats() == (1, 1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        assert _forward_launches(model, x)[0] == 3 and h.stats()[0] == 2      # relaunched on the side stream
+        assert _forward_launches(model, x)[0] == 1 and h.stats()[0] == 2      # ... and skipped there
+    torch.cuda.current_stream().wait_stream(side)
+    assert _forward_launches(model, x)[0] == 3 and h.stats()[0] == 3 and same_as_ref()
+    # (b) the double swap, repeated so that an allocator that could reuse the freed block would
+    for k in range(4):
+        launches = h.stats()[0]
+        old = model.conv.weight
+        shape = old.shape
+        tmp = torch.zeros(shape, device="cuda")
+        model.conv.weight.data = tmp
+        del tmp
+        fresh = torch.full(shape, 0.01 * (k + 1), device="cuda") * torch.randn(shape, device="cuda").sign()
+        model.conv.weight.data = fresh
+        ref.conv.weight.data = fresh.clone()
+        assert _forward_launches(model, x)[0] == 3 and h.stats()[0] == launches + 1 and same_as_ref(), k
+        assert _forward_launches(model, x)[0] == 1
+    mq.decelerate(model)
+
+
+@pytest.mark.gpu
 def test_versioned_reuse_on_the_wrapped_resnet50_and_the_cost_of_the_check(compiled_binding):
     """54 weights: forward 2..N of an accelerated inference model issue 0 weight launches; the check is one C call."""
     import time
@@ -785,31 +844,64 @@ def test_versioned_reuse_on_the_wrapped_resnet50_and_the_cost_of_the_check(compi
 
 
 @pytest.mark.gpu
-def test_a_launch_bumps_the_version_of_the_persistent_outputs_so_autograd_sees_the_overwrite(compiled_binding):
-    """the batched launch rewrites the quantized weights in place.  A forward whose graph saved such a weight,
-    followed by a weight update and another forward, must fail its backward with autograd's in-place error (as any in-place
-    write would) instead of silently using the newer values."""
+def test_a_forward_autograd_records_gets_fresh_tensors_and_a_no_grad_forward_the_persistent_ones(compiled_binding):
+    """a wrapped layer saves its quantized weight for the input gradient.  The pre-packed launch rewrites
+    ONE persistent tensor per weight, so two forwards before one backward -- ``(model(a).sum() + model(b).sum()).backward()`` --
+    used to raise autograd's "modified by an inplace operation" where the reference (fresh tensors) works.  Now a forward that
+    autograd may record (grad mode on and an input or a parameter requiring a gradient) takes the fresh-tensor launch; gradients
+    equal those of the per-layer path, also with a weight update between the two forwards.  Forwards under no_grad keep the
+    persistent tensors, and every launch still bumps their in-place version."""
+    from mct_quantizers_amd.hip import native
     torch.manual_seed(5)
     conv = nn.Conv2d(3, 8, 3).cuda()
     thr = [float(v) for v in conv.weight.detach().abs().amax(dim=(1, 2, 3))]
-    model = nn.Sequential(mq.PytorchQuantizationWrapper(conv, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)}))
-    mq.accelerate(model.eval())                                                 # (no holder behind it: holders cut the graph)
+
+    def build():
+        c = copy.deepcopy(conv)
+        return nn.Sequential(mq.PytorchQuantizationWrapper(c, {"weight": Q.WeightsSymmetricInferableQuantizer(8, thr, True, 0)})).eval()
+    model, per_layer = build(), build()                                         # (no holder behind it: holders cut the graph)
+    mq.accelerate(model)
     wrapper = model[0]
-    x = torch.randn(2, 3, 10, 10, device="cuda", requires_grad=True)
-    out1 = model(x).sum()
-    assert out1.grad_fn is not None
-    w_q = wrapper.layer.weight
-    w_q_version = w_q._version
+    a = torch.randn(2, 3, 10, 10, device="cuda", requires_grad=True)
+    b = torch.randn(2, 3, 10, 10, device="cuda", requires_grad=True)
+    a2, b2 = a.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    # two forwards, one backward; the weights move between the two forwards
+    n0 = native.launch_count()
+    out_a = model(a).sum()
+    assert native.launch_count() - n0 == 1                                      # still ONE launch for the wrapped weights
+    w_first = wrapper.layer.weight
+    ref_a = per_layer(a2).sum()
     with torch.no_grad():
-        wrapper.weight.add_(0.25)
-    model(x)                                                                    # rewrites the same tensor in place
-    assert wrapper.layer.weight is w_q and w_q._version > w_q_version
-    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
-        out1.backward()                                                         # grad wrt x needs the weight out1 was computed with
-    x.grad = None
-    out2 = model(x).sum()                                                       # a forward followed by its own backward is fine
-    out2.backward()
-    assert x.grad is not None and torch.isfinite(x.grad).all()
+        wrapper.weight.add_(0.25); per_layer[0].weight.add_(0.25)
+    out_b = model(b).sum()
+    assert wrapper.layer.weight is not w_first                                  # fresh tensors, as the reference returns
+    ref_b = per_layer(b2).sum()
+    (out_a + out_b).backward()
+    (ref_a + ref_b).backward()
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+    # a bias that requires a gradient is enough (the NEXT layer would save its weight)
+    wrapper.layer.bias.requires_grad_(True)
+    x = torch.randn(2, 3, 10, 10, device="cuda")
+    model(x); w1 = wrapper.layer.weight
+    model(x)
+    assert wrapper.layer.weight is not w1
+    wrapper.layer.bias.requires_grad_(False)
+    # nothing can be recorded: the persistent tensors, rewritten in place, version bumped by every launch
+    with torch.no_grad():
+        model(x); w_q = wrapper.layer.weight; v0 = w_q._version
+        model(x)
+        assert wrapper.layer.weight is w_q and w_q._version > v0
+    model(x)                                                                    # grad mode on, fully frozen model, plain input
+    assert wrapper.layer.weight is w_q
+    # and back: a recorded forward after persistent ones, then a persistent one again -- each sees its own tensors
+    out = model(a).sum()
+    assert wrapper.layer.weight is not w_q
+    with torch.no_grad():
+        model(x)
+    assert wrapper.layer.weight is w_q
+    a.grad = None
+    out.backward()
+    assert a.grad is not None and torch.isfinite(a.grad).all()
 
 
 @pytest.mark.gpu

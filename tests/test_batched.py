@@ -660,3 +660,29 @@ def test_batch_plan_holds_and_releases_its_references():
     owner["flag"] = True                                       # a watched object replaced: the plan declines
     plan = fast.BatchPlan([(x, y, s, None, 0, -128, 127, (owner, (("flag", False, -1),)))])
     assert plan() is NotImplemented
+
+
+def test_a_recorded_forward_is_told_apart_from_an_inference_forward():
+    """pytorch/batching.py::_recorded_by_autograd (ADVICE r05): grad mode on AND (an input tensor, also inside a list / tuple,
+    or a parameter of the model requires a gradient) -- only then may a layer save its quantized weight for a backward."""
+    import torch.nn as nn
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.pytorch.batching import batch_weight_quantization
+    lin = nn.Linear(4, 3)
+    model = nn.Sequential(mq.PytorchQuantizationWrapper(lin, {"weight": mq.pytorch_quantizers.WeightsSymmetricInferableQuantizer(8, [1.0], False)}))
+    h = batch_weight_quantization(model, reuse_buffers=True, auto=True)
+    x = torch.randn(2, 4)
+    assert h._recorded_by_autograd((x,)) is True                     # the bias requires a gradient
+    for p in model.parameters():
+        p.requires_grad_(False)
+    assert h._recorded_by_autograd((x,)) is False
+    assert h._recorded_by_autograd((x.clone().requires_grad_(),)) is True
+    assert h._recorded_by_autograd(([x, x.clone().requires_grad_()],)) is True
+    assert h._recorded_by_autograd(None) is False
+    with torch.no_grad():
+        assert h._recorded_by_autograd((x.clone().requires_grad_(),)) is False
+    lin.bias.requires_grad_(True)                                    # read per call, not cached
+    assert h._recorded_by_autograd((x,)) is True
+    y = model(x)                                                     # and the CPU forward is what it was
+    assert y.shape == (2, 3)
+    h.remove()

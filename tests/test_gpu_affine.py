@@ -459,3 +459,102 @@ def test_error_behaviour_follows_aten_for_axis_zero_points_and_tensor_qparams(li
         q(x.clone())
     with pytest.raises(RuntimeError, match="`zero_point` must be between `quant_min` and `quant_max`."):
         torch.fake_quantize_per_channel_affine(x, q.scales, q.zero_points, 1, 0, 255)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: the channel-last launch (slab grid, exact five-instruction reciprocal, no zero-point table) and the per-lane-vector
+# launch of short / ragged rows in every storage type
+# ---------------------------------------------------------------------------------------------
+
+def test_fast_reciprocal_is_exact(lib):
+    """recip_exact (csrc/mctq_kernels.hpp) == the compiler's IEEE 1.0f / d for EVERY float32 bit pattern of its range."""
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    assert lib.mctq_selftest_reciprocal(out.data_ptr(), _stream()) == 0, lib.mctq_last_error()
+    torch.cuda.synchronize()
+    seen, bad, first = [int(v) for v in out.cpu()]
+    assert seen == 2 * (0x71800000 - 0x0d800000 + 1) and bad == 0, (seen, bad, hex(max(first - 1, 0)))
+
+
+R6_SHAPES = [  # (outer, C, inner): lastaxis (inner 1, C % N == 0) ...
+    (37, 64, 1), (4099, 4096, 1), (5, 4096, 1), (1029, 200, 1), (70000, 16, 1), (3, 20480, 1), (2051, 768, 1), (1, 8, 1),
+    # ... short and ragged rows (gather / window): whole vectors, crossing vectors, rows longer than a tile, wrapping channels
+    (1, 4000, 16), (1, 4000, 20), (3, 50, 1020), (2, 7, 4100), (1, 3, 4099), (5, 33, 12), (2, 1000, 40), (1, 2000, 64), (7, 9, 8),
+    (1, 300, 576), (4, 2, 9000)]
+
+
+@pytest.mark.parametrize("dt", ["float32", "float16", "bfloat16"])
+@pytest.mark.parametrize("with_zp", [False, True])
+def test_channel_last_and_short_row_launches_vs_oracle(lib, dt, with_zp):
+    """Every shape x {symmetric (NULL zero-point table), zero points} x the three routes of 16-bit short rows (tuning key
+    "gather16"), scales that include values outside recip_exact's range (the wave falls back to the IEEE division) -- against
+    the oracle, bit for bit."""
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    code = {"float32": 0, "float16": 1, "bfloat16": 2}[dt]
+    tdt = getattr(torch, dt)
+    seen = set()
+    try:
+        for route in ((1,) if dt == "float32" else (0, 1, 2)):
+            native.set_tuning("gather16", route)
+            for k, (outer, C, inner) in enumerate(R6_SHAPES):
+                rng = np.random.default_rng(1000 * k + 7 * route + with_zp)
+                qmin, qmax = (-8, 7) if k % 3 == 0 else (-128, 127)
+                scales = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+                if k % 4 == 1:                                   # one channel per wave-sized stretch leaves the exact range
+                    scales[::97] = np.float32(3e-33)
+                    scales[5::211] = np.float32(2e31)
+                zps = rng.integers(-5, 6, size=C).astype(np.int32) if with_zp else np.zeros(C, dtype=np.int32)
+                shape = (outer, C, inner)
+                x32 = _tie_heavy_r6(rng, shape, scales.reshape(1, C, 1), zps.reshape(1, C, 1).astype(np.float32), qmin, qmax)
+                xh = _dev(x32).to(tdt)
+                x_np = xh.float().cpu().numpy()
+                y = torch.full_like(xh, 300.0)
+                s_d, z_d = _dev(scales), _dev(zps)
+                rc = lib.mctq_fq_per_channel(xh.data_ptr(), y.data_ptr(), outer, C, inner, code, s_d.data_ptr(),
+                                             z_d.data_ptr() if with_zp else None, qmin, qmax, _stream())
+                assert rc == 0, lib.mctq_last_error()
+                seen.add(native.last_launch().split("<")[0])
+                want = O.narrow(O.fake_quant_affine(x_np, scales, zps, qmin, qmax, axis=1), dt)
+                got = y.float().cpu().numpy()
+                assert finite_equal(got, want, x_np), (shape, route, native.last_launch(), first_mismatch(got, want, x_np))
+    finally:
+        native.set_tuning("gather16", 1)
+    assert {"lastaxis_kernel", "gather_kernel"} <= seen, seen
+
+
+def _tie_heavy_r6(rng, shape, s_b, zp_b, qmin, qmax):
+    n = int(np.prod(shape))
+    with np.errstate(all="ignore"):
+        x = (rng.standard_normal(n).astype(np.float32).reshape(shape) * np.minimum(s_b, np.float32(1.0)) * np.float32(0.4 * (qmax - qmin)))
+        k = rng.integers(qmin - 2, qmax + 3, size=shape).astype(np.float32) - zp_b
+        kind = rng.integers(0, 6, size=shape)
+        x = np.where(kind == 0, (k + np.float32(0.5)) * s_b, x)
+        x = np.where(kind == 1, k * s_b, x)
+    return np.nan_to_num(x.astype(np.float32), nan=0.0, posinf=3e38, neginf=-3e38)
+
+
+def test_a_tensor_above_the_launch_limit_of_the_short_row_kernels_is_cut_into_row_blocks(lib, monkeypatch):
+    """include/mctq_hip.h "Size limit" / ADVICE r05: the LUT, integer-code and export-grid launches of short per-channel rows take
+    fewer than 2^32 elements at a time; hip/ops.py cuts larger tensors into row blocks.  With the limit lowered to a few thousand
+    elements the block-wise results equal the one-launch results bit for bit."""
+    import mct_quantizers_amd as mq
+    from mct_quantizers_amd.hip import native, ops
+    Q = mq.pytorch_quantizers
+    torch.manual_seed(4)
+    x = torch.randn(6, 50, 7, 9, device="cuda")
+    thr = [0.5 + 0.01 * i for i in range(50)]
+    lut = Q.WeightsLUTSymmetricInferableQuantizer(4, [-100.0, -50.0, -10.0, 0.0, 10.0, 50.0, 100.0, 127.0], thr, True, 1, 4)
+    s = torch.rand(50, device="cuda") * 0.1 + 0.01
+    z = torch.zeros(50, dtype=torch.int32, device="cuda")
+    want_lut, want_codes = lut(x), ops.fq_codes(x, s, z, 1, -128, 127)
+    want_grid = ops.grid_per_channel(x, -s * 100, s * 100, s, 1)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    want_lut_cl = lut(xcl)
+    for limit in (2000, 400, 70):
+        monkeypatch.setattr(ops, "_SPLIT_ELEMS", limit)
+        n0 = native.launch_count()
+        assert torch.equal(lut(x), want_lut) and native.launch_count() - n0 > 1
+        assert torch.equal(ops.fq_codes(x, s, z, 1, -128, 127), want_codes)
+        assert torch.equal(ops.grid_per_channel(x, -s * 100, s * 100, s, 1), want_grid)
+        got = lut(xcl)
+        assert torch.equal(got, want_lut_cl) and got.is_contiguous()

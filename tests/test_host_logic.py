@@ -540,3 +540,34 @@ def test_bench_emits_measured_traffic_only_for_the_build_the_counters_were_taken
     assert stale["traffic"] is None and "stale" in stale["traffic_source"] and "traffic_build_id_mismatch" not in stale
     assert bench_dist.traffic_fields(str(path), "cfg9", v, "x")["traffic"] is None
     assert bench_dist.traffic_fields(str(tmp_path / "none.json"), "cfg2", v, "x")["traffic_source"].endswith("missing")
+
+
+def test_split_rows_cuts_a_tensor_into_row_blocks_below_the_launch_limit():
+    """hip/ops.py::_split_rows (ADVICE r05, include/mctq_hip.h "Size limit"): whole outer slices when a slice fits the limit,
+    runs of channel rows of one slice otherwise; per-channel parameters sliced alike; the result keeps x's strides."""
+    from mct_quantizers_amd.hip import ops
+    torch.manual_seed(0)
+    calls = []
+
+    def call(xp, ps, ax):
+        assert xp.dim() == 3 and ax == 1 and xp.is_contiguous() and ps[0].numel() == xp.shape[1]
+        calls.append(tuple(xp.shape))
+        return xp * ps[0].view(1, -1, 1) + ps[1].view(1, -1, 1)
+    for shape, axis, limit in (((5, 7, 3), 1, 50), ((5, 7, 3), 1, 8), ((5, 7, 3), 0, 40), ((6, 4), 1, 9), ((2, 3, 4, 5), 1, 31),
+                               ((2, 3, 4, 5), 3, 17), ((5, 7, 3), 1, 10 ** 6)):
+        for permuted in (False, True):
+            x = torch.randn(*shape)
+            ax = axis
+            if permuted and x.dim() == 4:
+                x = x.to(memory_format=torch.channels_last)
+            c = x.shape[ax]
+            a, b = torch.randn(c), torch.randn(c)
+            view = [1] * x.dim()
+            view[ax] = -1
+            calls.clear()
+            y = ops._split_rows(x, ax, (a, b), torch.float32, call, limit=limit)
+            assert y.shape == x.shape and y.stride() == x.stride()
+            assert torch.equal(y, x * a.view(view) + b.view(view)), (shape, axis, limit, permuted)
+            assert all(k * ch * inner <= max(limit, inner) for k, ch, inner in calls) and len(calls) >= 1
+    with pytest.raises(NotImplementedError):
+        ops._split_rows(torch.randn(2, 3, 40), 1, (torch.randn(3),), torch.float32, lambda xp, ps, ax: xp, limit=16)
