@@ -54,9 +54,9 @@ extern "C" {
  * points return MCTQ_E_ARG for it ("per-channel rows shorter than 256 lane-vectors above 2^32 elements: affine quantizers
  * only") -- the Python layer (hip/ops.py: _split_rows) cuts such a tensor into row blocks below the limit and issues one launch
  * per block, which is what a caller of the C ABI has to do as well.  Long rows and per-tensor launches have no such limit. */
-/* v9 (round 6): + mctq_selftest_reciprocal, + tuning key "gather16"; the channel-last (lastaxis) launch and the per-lane-vector
- * (gather) launch invert a lane's own scales with a five-instruction exact reciprocal, and 16-bit short / ragged rows take the
- * gather launch (no signature changed; results are bit-identical). */
+/* v9 (round 6): + mctq_selftest_reciprocal, + tuning key "shortrows"; the channel-last (lastaxis) launch and the new launch of
+ * short / ragged per-channel rows (shortrows) invert a lane's own scales with a five-instruction exact reciprocal (no signature
+ * changed; results are bit-identical). */
 #define MCTQ_ABI_VERSION 9
 #define MCTQ_E_ARG (-10001)
 
@@ -482,9 +482,10 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  2544, 2548 (wave-wide tiles), 2560 (256 x 256 ping-pong)
  *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
- *   key "gather16" : float16 / bfloat16 per-channel rows shorter than 256 lane-vectors through the per-lane-vector (gather) launch
- *                  instead of the LDS parameter window: 0 = never, 1 (default) = rows that are not whole 8-element vectors or
- *                  are shorter than 64 elements (measured faster there), 2 = every such tensor
+ *   key "shortrows" : affine per-channel rows shorter than a tile through shortrows_kernel (per-lane parameter reads, no LDS
+ *                  window) instead of window_kernel: 0 = never, 1 (default) = where it measured faster (16-bit rows that are
+ *                  not whole 8-element vectors or are shorter than 64 elements; float32 rows of 4 ... 31 elements), 2 = every
+ *                  eligible tensor
  * Only variants a default dispatcher can select are instantiated; every value of every key is exercised by the GPU tests.
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */

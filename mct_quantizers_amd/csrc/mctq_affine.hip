@@ -7,10 +7,10 @@ namespace mctq {        // mctq_f64.hip
 int fq64_per_tensor(const void* x, void* y, int64_t n, float scale, int32_t zp, int32_t qmin, int32_t qmax, hipStream_t st);
 int fq64_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
                      const int32_t* zps, int32_t qmin, int32_t qmax, bool wide, hipStream_t st);
-// mctq_batched.hip: one tensor through the batched grid's tile code (per-lane-vector parameters)
-int fq_gather_one(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
-                  const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st);
-extern int g_gather16;
+// mctq_batched.hip: one float32 tensor through the batched grid's tile code (per-lane-vector parameters)
+int fq_gather_one_f32(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
+                      const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st);
+extern int g_shortrows;
 }
 
 extern "C" {
@@ -53,22 +53,9 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
     const int64_t innerv = inner / 4, tiles = (innerv + kThreads - 1) / kThreads;
     if ((tiles * kThreads - innerv) * 12 > tiles * kThreads) long_rows = false;      // > 1/12 of the row's lanes idle
   }
-  // Round 6: with the lanes' reciprocals by recip_exact the same path also takes float32 rows of 4 ... 31 elements
-  // (1048576 x 16: 23.9 -> 22.1 us) and 16-bit storage -- rows that are not whole 8-element vectors (16384 x 1020 bfloat16
-  // 13.7 -> 12.5 us, 4096 x 4100 13.3 -> 12.3) and whole-vector rows shorter than 64 elements; longer whole-vector 16-bit rows
-  // stay with the window kernel or rows_kernel (equal or better: profiles/r06/chanlast2_a.log, sweep_routes.log).
-  // Tuning key "gather16": 0 = 16-bit tensors never, 1 = that rule (default), 2 = every eligible 16-bit tensor.
-  const bool aligned16 = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
-  if (dtype == MCTQ_DT_F32 && inner >= 4 && channels > 1 && !long_rows && aligned16 && n < (1ll << 31) - 4096 &&
-      channels <= 0x7fffffffLL) {
-    return fq_gather_one(dtype, x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
-  }
-  if ((dtype == MCTQ_DT_F16 || dtype == MCTQ_DT_BF16) && g_gather16 != 0 && inner >= 8 && channels > 1 && aligned16 &&
-      n < (1ll << 31) - 8192 && channels <= 0x7fffffffLL) {
-    const bool whole = inner % 8 == 0;
-    const bool rows_shape = whole && inner / 8 >= kThreads;          // long whole-vector rows: rows_kernel / rowsteps_kernel
-    if (g_gather16 == 2 ? !rows_shape : (!whole || inner < 64))
-      return fq_gather_one(dtype, x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
+  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !long_rows && g_shortrows < 2 &&
+      (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && n < (1ll << 31) - 4096 && channels <= 0x7fffffffLL) {
+    return fq_gather_one_f32(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
   }
   AffineOp op;
   op.scales = scales; op.zps = zero_points;

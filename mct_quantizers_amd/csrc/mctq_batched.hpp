@@ -49,6 +49,9 @@ constexpr uint32_t kMaxChunksT = 16384;  // chunk-map entries of a packed table 
 #define MCTQ_BATCH_U 4                   // lane-vectors per lane and tile; 2 / 8 are timing experiments (tools/batched_unroll_probe.py)
 #endif
 constexpr int kBatchU = MCTQ_BATCH_U;
+#ifndef MCTQ_BATCH_EXACT_RECIP
+#define MCTQ_BATCH_EXACT_RECIP 1         // 0: timing experiment (tools/build_variant.py): per-lane scales inverted by the IEEE division as until round 5
+#endif
 
 struct __attribute__((aligned(16))) BatchItem {   // 64 bytes
   const void* x;
@@ -126,18 +129,18 @@ struct AffinePol {
   __device__ __forceinline__ void init(float*) {}
   __device__ __forceinline__ Param uniform(uint32_t c) const { return AffineOp::make(s_uniform[c], z_uniform ? z_uniform[c] : 0); }
   __device__ __forceinline__ Param lane(uint32_t c) const { return AffineOp::make(s_lane[c], z_lane ? z_lane[c] : 0); }
-  // per-lane parameters in two steps, so that a tile can issue ALL its table reads back to back and decide ONCE (wave-uniform)
-  // whether the lanes' reciprocals may take recip_exact (5 VALU instructions) instead of the IEEE expansion (11)
+  // The parameter sets of a tile's U lane-vectors in two steps (round 6): raws() issues all table reads back to back and decides
+  // ONCE per wave whether the lanes may invert their scales with recip_exact (5 VALU instructions instead of the 11 of the IEEE
+  // expansion); finish() builds one set right where it is used, so that no reciprocal is kept alive across the tile.
   struct Raw { float s, zf; };
-  __device__ __forceinline__ Raw raw(uint32_t c) const { Raw r; r.s = s_lane[c]; r.zf = z_lane ? (float)z_lane[c] : 0.0f; return r; }
-  template <int M>
-  __device__ __forceinline__ static bool exact_ok(const Raw (&r)[M]) {
-    float v[M];
+  template <int U>
+  __device__ __forceinline__ bool raws(const uint32_t (&c)[U], Raw (&r)[U]) const {
+    float sv[U];
 #pragma unroll
-    for (int j = 0; j < M; ++j) v[j] = r[j].s;
-    return recip_all_in_range(v);
+    for (int u = 0; u < U; ++u) { sv[u] = s_lane[c[u]]; r[u].s = sv[u]; r[u].zf = z_lane ? (float)z_lane[c[u]] : 0.0f; }
+    return MCTQ_BATCH_EXACT_RECIP && __builtin_amdgcn_ballot_w64(!recip_all_in_range(sv)) == 0;
   }
-  __device__ __forceinline__ Param make(const Raw& r, bool exact /* wave-uniform */) const {
+  __device__ __forceinline__ static Param finish(const Raw& r, bool exact /* wave-uniform */) {
     Param p; p.s = r.s; p.zf = r.zf;
     p.inv = exact ? recip_exact(r.s) : 1.0f / r.s;
     return p;
@@ -212,14 +215,14 @@ struct LutPol {
     const float t = t_lane[c];
     return LutCommon::make(t + op.eps, t, op.mult);
   }
-  struct Raw { float t; };
-  __device__ __forceinline__ Raw raw(uint32_t c) const { Raw r; r.t = t_lane ? t_lane[c] : 0.0f; return r; }
-  template <int M>
-  __device__ __forceinline__ static bool exact_ok(const Raw (&)[M]) { return false; }
-  __device__ __forceinline__ Param make(const Raw& r, bool) const {
-    if (!t_lane) return LutCommon::make(thr_div, thr_mul, op.mult);
-    return LutCommon::make(r.t + op.eps, r.t, op.mult);
+  typedef Param Raw;                       // (nothing to gain here: the LUT sets carry their own divisions)
+  template <int U>
+  __device__ __forceinline__ bool raws(const uint32_t (&c)[U], Raw (&r)[U]) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = lane(c[u]);
+    return false;
   }
+  __device__ __forceinline__ static Param finish(const Raw& r, bool) { return r; }
   template <bool UNI, int N>
   __device__ __forceinline__ void run(const float* in, float* out, const Param& p) const {
     // the exact reciprocal division (LutCommon::divide_fast) is per element: it works with per-lane divisors too, as long
@@ -320,17 +323,14 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, Pol& pol, floa
 
   // ---- several rows in the tile (inner < tile / 2): per lane-vector parameters ----
   // Pass 1 finds every vector's row (positions inside the tile are < 2^24: one float multiply + two integer
-  // corrections) and issues its table reads -- and, where vectors can cross a row boundary (rows that are not whole
-  // vectors), the NEXT row's as well: read behind the data they would arrive a memory round trip after it (round 6:
-  // bfloat16 16384 x 1020 13.7 -> 12.5 us) -- then decides once per wave how the lanes invert their scales; pass 2 applies.
+  // corrections) and builds its parameter set (table reads issued back to back); pass 2 applies.
   const float r_inner = 1.0f / (float)inner;
   const uint32_t nrows = (rem0 + count - 1) / inner + 1;      // uniform
   const bool wraps = c0 + nrows > channels;                   // uniform: some row of the tile starts a new outer slice
   const bool small_c = (uint64_t)channels + nrows < (1u << 24);
   const float r_channels = 1.0f / (float)channels;
-  const bool crossing = inner >= N && (inner % N) != 0;       // uniform: a vector may cross exactly one boundary
   uint32_t cc[U], rr[U];
-  typename Pol::Raw ra[U], rb[U];
+  typename Pol::Raw pv[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
@@ -340,11 +340,8 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, Pol& pol, floa
     uint32_t c = c0 + lrow;
     if (wraps) c = small_c ? c - div_small(c, channels, r_channels) * channels : c % channels;
     cc[u] = c;
-    ra[u] = pol.raw(c);
-    rb[u] = ra[u];
-    if (crossing) rb[u] = pol.raw(c + 1 == channels ? 0 : c + 1);
   }
-  const bool exact = __builtin_amdgcn_ballot_w64(!(Pol::exact_ok(ra) && (!crossing || Pol::exact_ok(rb)))) == 0;
+  const bool exact = pol.template raws<U>(cc, pv);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
@@ -353,12 +350,11 @@ __device__ __forceinline__ void batched_tile(const BatchItem& it, Pol& pol, floa
     if (FULL || off + N <= count) {
       float in[N], out[N];
       io::unpack(v[u], in);
-      const Param pa = pol.make(ra[u], exact);
       if (rem + N <= inner) {                               // the vector lies in one row
-        pol.template run<false, (int)N>(in, out, pa);
+        pol.template run<false, (int)N>(in, out, Pol::finish(pv[u], exact));
       } else if (inner >= N) {                              // it crosses exactly one row boundary: two sets, chosen per element
         const uint32_t split = inner - rem;
-        const Param pb = pol.make(rb[u], exact);
+        const Param pa = Pol::finish(pv[u], exact), pb = pol.lane(c + 1 == channels ? 0 : c + 1);
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) pol.template run<false, 1>(in + j, out + j, Pol::pick(j < split, pa, pb));
       } else {
@@ -522,27 +518,20 @@ static int launch_lut_batch(const LutTableSrc& src, uint32_t grid, size_t lds, i
 #endif
 
 #if MCTQ_BATCHED_PART == 1
-// [rows][inner] with per-channel parameters, x / y 16-byte aligned, n < 2^31 - tile (checked by the caller)
-template <class T>
-static int fq_gather_one_t(const void* x, void* y, int64_t n, int64_t channels, int64_t inner, const float* scales,
-                           const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st) {
-  constexpr uint32_t tile_e = kThreads * kBatchU * IO<T, T>::N;
-  const uint32_t grid = (uint32_t)((n + tile_e - 1) / tile_e);
-  MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(T)), {
-    hipLaunchKernelGGL((batched_one_kernel<T, T, kBatchU, NT>), dim3(grid), dim3(kThreads), 0, st,
-                       static_cast<const T*>(x), static_cast<T*>(y), scales, zps, (uint32_t)n, (uint32_t)inner,
-                       (uint32_t)channels, (float)qmin, (float)qmax);
-    note<AffineOp, T, T>("gather_kernel", kBatchU, NT);
-  });
-  return check_launch("gather launch");
-}
-int fq_gather_one(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
-                  const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st) {
+// float32 [rows][inner] with per-channel parameters, x / y 16-byte aligned, n < 2^31 - tile (checked by the caller)
+int fq_gather_one_f32(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
+                      const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st) {
   const int64_t n = outer * channels * inner;
   if (n == 0) return 0;
-  if (dtype == MCTQ_DT_F32) return fq_gather_one_t<float>(x, y, n, channels, inner, scales, zps, qmin, qmax, st);
-  if (dtype == MCTQ_DT_F16) return fq_gather_one_t<_Float16>(x, y, n, channels, inner, scales, zps, qmin, qmax, st);
-  return fq_gather_one_t<__bf16>(x, y, n, channels, inner, scales, zps, qmin, qmax, st);
+  constexpr uint32_t tile_e = kThreads * kBatchU * 4;
+  const uint32_t grid = (uint32_t)((n + tile_e - 1) / tile_e);
+  MCTQ_WITH_MODE(nt_mode(n * 4), {
+    hipLaunchKernelGGL((batched_one_kernel<float, float, kBatchU, NT>), dim3(grid), dim3(kThreads), 0, st,
+                       static_cast<const float*>(x), static_cast<float*>(y), scales, zps, (uint32_t)n, (uint32_t)inner,
+                       (uint32_t)channels, (float)qmin, (float)qmax);
+    note<AffineOp, float, float>("gather_kernel", kBatchU, NT);
+  });
+  return check_launch("gather launch");
 }
 
 // ---- host: which tensors one grid can take, and how the grid is cut ---------------------------------------

@@ -78,11 +78,19 @@ template <> struct VecT<_Float16, 4> { typedef f16x4 type; };
 template <> struct VecT<__bf16, 8> { typedef b16x8 type; };
 template <> struct VecT<__bf16, 4> { typedef b16x4 type; };
 
+// 16-bit input widened to float32 output (the LUT quantizers): 0 = four elements per lane access (8-byte loads, one 16-byte
+// store), 1 = eight (one 16-byte load, two 16-byte stores) -- timing experiment of round 6
+#ifndef MCTQ_LUT16_WIDE
+#define MCTQ_LUT16_WIDE 0
+#endif
+struct f32x8w { f32x4 lo, hi; };
+
 template <class TI, class TO>
 struct IO {
-  static constexpr int N = 16 / (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
+  static constexpr bool kWide = MCTQ_LUT16_WIDE && sizeof(TI) == 2 && sizeof(TO) == 4;
+  static constexpr int N = kWide ? 8 : 16 / (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
   typedef typename VecT<TI, N>::type VI;
-  typedef typename VecT<TO, N>::type VO;
+  typedef typename std::conditional<kWide, f32x8w, typename VecT<typename std::conditional<kWide, float, TO>::type, kWide ? 4 : N>::type>::type VO;
 
   // NT: 1 = non-temporal loads and stores (streaming: the default),
   //     2 = non-temporal loads, cached stores (the output is consumed right away and fits the aggregate L2)
@@ -93,22 +101,35 @@ struct IO {
   }
   template <int NT>
   __device__ __forceinline__ static void store(TO* p, VO v) {
-    VO* q = reinterpret_cast<VO*>(p);
-    if (NT == 1) __builtin_nontemporal_store(v, q);
-    else *q = v;
+    if constexpr (kWide) {
+      f32x4* q = reinterpret_cast<f32x4*>(p);
+      if (NT == 1) { __builtin_nontemporal_store(v.lo, q); __builtin_nontemporal_store(v.hi, q + 1); }
+      else { q[0] = v.lo; q[1] = v.hi; }
+    } else {
+      VO* q = reinterpret_cast<VO*>(p);
+      if (NT == 1) __builtin_nontemporal_store(v, q);
+      else *q = v;
+    }
   }
   __device__ __forceinline__ static void unpack(VI v, float* f) {
 #pragma unroll
     for (int i = 0; i < N; ++i) f[i] = (float)v[i];            // exact widening
   }
   __device__ __forceinline__ static VO pack(const float* f) {
-    VO o;
+    if constexpr (kWide) {
+      VO o;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      if constexpr (sizeof(TO) == 1) o[i] = (TO)(int32_t)f[i];  // integer codes in [-128, 255]: the low byte (int8 and uint8 alike)
-      else o[i] = (TO)f[i];                                     // round-to-nearest-even narrowing
+      for (int i = 0; i < 4; ++i) { o.lo[i] = f[i]; o.hi[i] = f[4 + i]; }
+      return o;
+    } else {
+      VO o;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if constexpr (sizeof(TO) == 1) o[i] = (TO)(int32_t)f[i];  // integer codes in [-128, 255]: the low byte (int8 and uint8 alike)
+        else o[i] = (TO)f[i];                                     // round-to-nearest-even narrowing
+      }
+      return o;
     }
-    return o;
   }
 };
 
@@ -763,9 +784,14 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
                                             int64_t limit, bool full) {
   typedef IO<TI, TO> io;
   if (full) {
-    if constexpr (HasTile<Op>::value) {
+#ifndef MCTQ_TILE_SCHEDULE
+#define MCTQ_TILE_SCHEDULE 0     // timing experiments (round 6): 1 = every result, then the stores; 2 = also wait for ALL loads first
+#endif
+    if constexpr (MCTQ_TILE_SCHEDULE == 2) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), nothing else
+    if constexpr (HasTile<Op>::value || MCTQ_TILE_SCHEDULE != 0) {
       typename io::VO r[U];
       run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
+      if constexpr (MCTQ_TILE_SCHEDULE != 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
     } else {
@@ -1029,6 +1055,97 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// shortrows (affine quantizers): per-channel rows shorter than a tile that are at least one lane-vector long -- 16-bit
+// tensors whose rows are not whole 8-element vectors (1020- or 4100-wide) or are shorter than 64 elements, float32 rows of
+// 4 ... 31 elements.  Block b owns elements [b * TILE, (b + 1) * TILE) of the dense [rows][inner] storage; a lane-vector
+// lies in one row or crosses exactly one row boundary.  No LDS window, no block barrier: after the tile's data loads every
+// lane reads its own row's scale (and, where vectors can cross, the next row's) from the L1 / L2-resident tables -- all
+// table reads issued back to back -- and inverts it with recip_exact (wave-uniform fallback to the IEEE division).
+// Measured against window_kernel (tools/experiments/chanlast2/, profiles/r06/chanlast2_a.log): bfloat16 16384 x 1020
+// 13.7 -> 12.5 us, 4096 x 4100 13.3 -> 12.3, 1048576 x 16 13.5 -> 13.0, float32 1048576 x 16 23.9 -> 22.1; whole-vector
+// 16-bit rows of 64 ... 2040 elements are equal or slower and stay with the window.  Reading the parameters BEFORE the data
+// (vector loads return in order) was slower in every case: the data loads must not wait for the row arithmetic.
+// ------------------------------------------------------------------------------------------
+template <class TI, int U, int NT, bool ZP, bool WHOLE>
+__global__ __launch_bounds__(kThreads) void shortrows_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n,
+                                                             uint32_t inner, uint32_t channels, float r_inner, float r_channels,
+                                                             uint32_t shift /* log2(inner), or 32 */, AffineOp op) {
+  typedef IO<TI, TI> io;
+  constexpr uint32_t N = io::N;
+  constexpr uint32_t TILE = kThreads * U * N;
+  const uint32_t e0 = blockIdx.x * TILE;
+  const uint32_t left = n - e0;
+  const uint32_t count = left < TILE ? left : TILE;
+  const bool full = left >= TILE;                                    // wave-uniform
+  typename io::VI v[U];
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = io::template load<NT>(xs + e0 + (u * kThreads + threadIdx.x) * N);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((u * kThreads + threadIdx.x) * N + N <= count) v[u] = io::template load<NT>(xs + e0 + (u * kThreads + threadIdx.x) * N);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t row0, rem0;
+  if (shift < 32) { row0 = e0 >> shift; rem0 = e0 & (inner - 1); }
+  else { row0 = e0 / inner; rem0 = e0 - row0 * inner; }
+  const uint32_t c0 = row0 < channels ? row0 : row0 % channels;
+  const uint32_t nrows = (rem0 + count - 1) / inner + 1;
+  const bool wraps = c0 + nrows > channels;                          // some row of the tile starts a new outer slice
+  uint32_t split[U];
+  float sa[U], sb[U], za[U], zb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t off = (u * kThreads + threadIdx.x) * N;
+    const uint32_t pos = rem0 + ((full || off < count) ? off : 0);   // < 2^24 (launch_channels): exact through float32
+    const uint32_t lrow = shift < 32 ? pos >> shift : div_small(pos, inner, r_inner);
+    uint32_t c = c0 + lrow;
+    if (wraps) c -= div_small(c, channels, r_channels) * channels;
+    split[u] = inner - (pos - lrow * inner);                         // elements of the vector that belong to row c (>= N: all)
+    sa[u] = op.scales[c];
+    if (ZP) za[u] = (float)op.zps[c];
+    if (!WHOLE) {
+      const uint32_t cn = c + 1 == channels ? 0 : c + 1;
+      sb[u] = op.scales[cn];
+      if (ZP) zb[u] = (float)op.zps[cn];
+    }
+  }
+  bool in_range = recip_all_in_range(sa);
+  if (!WHOLE) in_range = in_range && recip_all_in_range(sb);
+  const bool exact = __builtin_amdgcn_ballot_w64(!in_range) == 0;    // wave-uniform
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t off = (u * kThreads + threadIdx.x) * N;
+    if (!full && off >= count) continue;
+    AffineOp::Param pa;
+    pa.s = sa[u]; pa.inv = exact ? recip_exact(sa[u]) : 1.0f / sa[u]; pa.zf = ZP ? za[u] : 0.0f;
+    if (full || off + N <= count) {
+      float in[N], out[N];
+      io::unpack(v[u], in);
+      if (WHOLE || split[u] >= N) {
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], pa, NoBook());
+      } else {
+        AffineOp::Param pb;
+        pb.s = sb[u]; pb.inv = exact ? recip_exact(sb[u]) : 1.0f / sb[u]; pb.zf = ZP ? zb[u] : 0.0f;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], j < split[u] ? pa : pb, NoBook());
+      }
+      io::template store<NT>(ys + e0 + off, io::pack(out));
+    } else {
+      // the tensor's last, partial lane-vector: element by element
+      uint32_t rem = inner - split[u], c = c0 + (shift < 32 ? (rem0 + off) >> shift : div_small(rem0 + off, inner, r_inner));
+      if (wraps) c -= div_small(c, channels, r_channels) * channels;
+      for (uint32_t j = 0; j < N && off + j < count; ++j) {
+        ys[e0 + off + j] = narrow_to<TI>(op.apply((float)xs[e0 + off + j], op.fetch(c), NoBook()));
+        if (++rem == inner) { rem = 0; if (++c == channels) c = 0; }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // window: block b owns elements [b*TILE, (b+1)*TILE), TILE = 256*U*V (V = lane-vector width, or
 // 1 for unaligned tensors).  The tile touches rows row0 .. row0+nrows-1 of the [outer*C][inner]
 // view; their parameters are staged in LDS (structure-of-arrays, so lanes that read different rows
@@ -1166,6 +1283,7 @@ inline void note(const char* shape, int unroll, int nt) {
   ++g_note.count;
   if (g_launch_log) log_launch();
 }
+extern int g_shortrows;      // rows shorter than a tile through shortrows_kernel: 0 never, 1 (default) where it measured faster, 2 whenever eligible
 extern int g_rowsteps;       // short whole-step rows: 0 rows_kernel, 1 rowsteps_kernel, 2 (default) rowsteps_kernel when its grid is one round
 extern int g_heavy_unroll;   // 0 = automatic
 int fail_arg(const char* msg);
@@ -1174,7 +1292,8 @@ int cu_count();
 template <class TI, class TO>
 static bool vec_aligned(const void* x, const void* y) {
   typedef IO<TI, TO> io;
-  return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % (io::N * sizeof(TO))) == 0;
+  constexpr size_t ya = io::N * sizeof(TO) > 16 ? 16 : io::N * sizeof(TO);       // (a wide output goes out as two 16-byte stores)
+  return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % ya) == 0;
 }
 
 // Launch through hipModuleLaunchKernel with the kernel's hipFunction_t resolved once per (kernel, device): skips
@@ -1308,7 +1427,9 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   const bool vec_ok = vec_aligned<TI, TO>(x, y);
 
   // rows shape: long, vector-divisible rows.
-  if (vec_ok && (inner % io::N) == 0 && inner / io::N >= kThreads && channels <= 0xffffffffLL && rows <= 0xffffffffLL) {
+  const bool shortrows_everywhere = std::is_same<Op, AffineOp>::value && g_shortrows == 3;      // (timing experiment)
+  if (!shortrows_everywhere && vec_ok && (inner % io::N) == 0 && inner / io::N >= kThreads && channels <= 0xffffffffLL &&
+      rows <= 0xffffffffLL) {
     const int64_t innerv = inner / io::N;
     if constexpr (Op::kHeavy) {
       // Lane-vectors per lane per tile: the widest of {4, 2, 1} whose idle lanes in the last tile
@@ -1413,6 +1534,30 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
 #undef MCTQ_LASTAXIS
         return check_launch("lastaxis launch");
       }
+    }
+  }
+
+  // shortrows shape (affine quantizers only; tuning key "shortrows": 0 never, 1 the measured rule, 2 every eligible tensor).
+  if constexpr (std::is_same<Op, AffineOp>::value && std::is_same<TI, TO>::value) {
+    constexpr int64_t TILE = (int64_t)kThreads * 4 * io::N;
+    const bool whole = inner % io::N == 0;
+    const bool rule = sizeof(TI) == 2 ? (!whole || inner < 64) : inner < 32;
+    if (vec_ok && g_shortrows != 0 && (g_shortrows >= 2 || rule) && inner >= io::N && channels > 1 &&
+        n < (1ll << 32) - TILE && inner + TILE < (1 << 24) && channels + TILE < (1 << 24)) {
+      uint32_t shift = 32;
+      if ((inner & (inner - 1)) == 0) { shift = 0; while ((1ll << shift) < inner) ++shift; }
+      const float ri = 1.0f / (float)inner, rc = 1.0f / (float)channels;
+      const unsigned grid = (unsigned)((n + TILE - 1) / TILE);
+#define MCTQ_SHORTROWS(NT_, ZP_, W_)                                                                                   \
+      hipLaunchKernelGGL((shortrows_kernel<TI, 4, NT_, ZP_, W_>), dim3(grid), dim3(kThreads), 0, st, x, y, (uint32_t)n,  \
+                         (uint32_t)inner, (uint32_t)channels, ri, rc, shift, op)
+      MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
+        if (op.zps) { if (whole) MCTQ_SHORTROWS(NT, true, true); else MCTQ_SHORTROWS(NT, true, false); }
+        else { if (whole) MCTQ_SHORTROWS(NT, false, true); else MCTQ_SHORTROWS(NT, false, false); }
+        note<Op, TI, TO>("shortrows_kernel", 4, NT);
+      });
+#undef MCTQ_SHORTROWS
+      return check_launch("shortrows launch");
     }
   }
 

@@ -17,7 +17,7 @@ int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggrega
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_rowsteps = 2;           // 2: rowsteps_kernel only where it measured faster (see launch_channels)
-int g_gather16 = 1;           // 16-bit short / ragged rows through the per-lane-vector path: 0 never, 1 the measured rule, 2 always (mctq_affine.hip)
+int g_shortrows = 1;          // short / ragged rows through shortrows_kernel: 0 never, 1 the measured rule, 2 whenever eligible (launch_channels)
 int g_ql_variant = 0;
 int g_ql_band = 0;
 int g_ql_stagger = 0;         // tiled consumer kernel: half of the waves copy after multiplying (experiment: no gain)
@@ -164,9 +164,9 @@ int mctq_set_tuning(const char* key, int32_t value) {
     g_heavy_unroll = value;
     return 0;
   }
-  if (!strcmp(key, "gather16")) {
-    if (value != 0 && value != 1 && value != 2) return fail_arg("gather16 must be 0, 1 or 2");
-    g_gather16 = value;
+  if (!strcmp(key, "shortrows")) {
+    if (value < 0 || value > 3) return fail_arg("shortrows must be 0, 1, 2 (or 3: timing experiment)");
+    g_shortrows = value;
     return 0;
   }
   if (!strcmp(key, "rowsteps")) {

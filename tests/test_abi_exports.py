@@ -274,3 +274,84 @@ def test_rowsteps_kernel_keeps_the_schedule_its_dispatch_window_was_measured_wit
             assert any(re.match(r"s_waitcnt vmcnt\([012]\)", x) for x in between), f"{name}: the fourth load is not staggered"
         # the parameter fetch (scalar loads, IEEE reciprocal) runs under the loads' latency
         assert any(is_fetch(x) for x in after[loads[3]:]), name
+
+
+# ---- the headline kernel's generated code ---------------------------------------------------------------
+
+HEADLINE = "_ZN4mctq11rows_kernelINS_8AffineOpEffLi4ELi1EEEvPKT0_PT1_jjjT_"       # rows_kernel<AffineOp, float, float, 4, 1>
+
+
+def _compile_affine_asm(tmp_path, src_dir=None):
+    import shutil
+    import subprocess
+    from mct_quantizers_amd.hip import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    asm = tmp_path / f"affine_{len(list(tmp_path.iterdir()))}.s"
+    inc = ["-I", os.path.join(REPO, "include"), "-I", B.CSRC]
+    # (a quoted #include is looked up beside the including file first: a doctored header needs the unit beside it)
+    src = os.path.join(str(src_dir) if src_dir else B.CSRC, "mctq_affine.hip")
+    subprocess.run([hipcc, *B.FLAGS, *inc, "--cuda-device-only", "-S", "-o", str(asm), src], check=True, capture_output=True)
+    return asm.read_text()
+
+
+def check_headline_schedule(text):
+    """What config 2's 0.76 of the HBM roofline rests on, asserted on the ISA of rows_kernel<AffineOp, float, float, 4, 1>:
+    the tile's four 16-byte non-temporal loads are issued before anything of the parameter fetch (the channel's scale / zero
+    point by scalar loads, the reciprocal); per element exactly v_mul (x * inv), v_rndne, v_med3 and one v_fma (q * s + 0) --
+    no per-element division, ONE IEEE reciprocal per tile; four non-temporal 16-byte stores; no LDS, no scratch, at most 64
+    VGPRs (8 waves per SIMD)."""
+    assert HEADLINE + ":" in text, "rows_kernel<AffineOp, float, float, 4, 1> is not instantiated"
+    body = text[text.index(HEADLINE + ":"):]
+    meta = body[body.index("s_endpgm"):]
+    body = body[:body.index("s_endpgm")]
+    ins = [ln.split(";")[0].strip() for ln in body.splitlines()]
+    ins = [ln for ln in ins if ln and not ln.startswith(".") and not ln.endswith(":")]
+    loads = [i for i, x in enumerate(ins) if x.startswith("global_load_dwordx4")]
+    stores = [i for i, x in enumerate(ins) if x.startswith("global_store_dwordx4")]
+    assert len(loads) >= 4 and len(stores) >= 4
+    # (1) the hot tile's four loads: non-temporal, back to back as far as the parameter fetch is concerned
+    head = ins[:loads[3] + 1]
+    assert all(ins[i].rstrip().endswith(" nt") for i in loads[:4]), "the tile's loads are not non-temporal"
+
+    def is_fetch(x):          # a table element by a ONE-dword scalar load (kernel arguments arrive as x2 / x4 / x8), a reciprocal, a division
+        return bool(re.match(r"s_load_dword s\d+,", x)) or x.startswith(("v_rcp_f32", "v_div_"))
+    first_load = loads[0]
+    kernarg_dwords = [x for x in ins[:first_load] if re.match(r"s_load_dword s\d+,", x)]
+    fetch_before = [x for x in head[first_load:] if is_fetch(x)] + [x for x in ins[:first_load] if x.startswith(("v_rcp_f32", "v_div_"))]
+    assert not fetch_before, f"parameter fetch scheduled in front of the tile's fourth data load: {fetch_before}"
+    assert len(kernarg_dwords) <= 1, kernarg_dwords            # (one scalar kernel argument may arrive by a dword load)
+    # (2) the hot path's arithmetic: from the fourth load to the fourth store
+    hot = ins[loads[3] + 1:stores[3] + 1]
+    count = lambda pat: sum(bool(re.match(pat, x)) for x in hot)
+    assert count(r"v_rndne_f32") == 16 and count(r"v_med3_f32") == 16, (count(r"v_rndne_f32"), count(r"v_med3_f32"))
+    assert count(r"v_fma_f32 v\d+, v\d+, s\d+, 0$") == 16, "one v_fma (q * s + 0) per element"
+    # (x * inv per element; one more v_mul belongs to the tile's IEEE reciprocal; 0x4f7ffffe marks the row-index division)
+    assert sum(x.startswith("v_mul_f32") and "0x4f7ffffe" not in x for x in hot) == 16 + 1, "one v_mul (x * inv) per element"
+    assert count(r"v_div_fixup_f32") == 1 and count(r"v_rcp_f32") == 1, "ONE reciprocal per tile, none per element"
+    assert sum(x.startswith("global_store_dwordx4") and x.rstrip().endswith(" nt") for x in hot) == 4, "non-temporal stores"
+    assert any(is_fetch(x) for x in hot), "the parameter fetch runs under the loads' latency"
+    # (3) resources
+    assert not [x for x in ins if x.startswith(("ds_", "scratch_", "buffer_"))]
+    m = re.search(re.escape(HEADLINE) + r"\.num_vgpr, (\d+)", meta)
+    assert m and int(m.group(1)) <= 64, m and m.group(1)
+
+
+def test_headline_kernel_keeps_the_schedule_its_roofline_figure_rests_on(tmp_path):
+    """... and the check has teeth: the same translation unit compiled against a copy of the kernel header in which the
+    parameter fetch is written IN FRONT of the tile's loads fails it."""
+    from mct_quantizers_amd.hip import build as B
+    check_headline_schedule(_compile_affine_asm(tmp_path))
+    hdr = open(os.path.join(B.CSRC, "mctq_kernels.hpp")).read()
+    a = "  typename Op::Book book;\n  if constexpr (HasPrefetch<Op>::value) {"
+    b = "  const typename Op::Param p = get_param();\n  const bool fast = __builtin_amdgcn_readfirstlane"
+    assert hdr.count(a) == 1 and hdr.count(b) == 1
+    bad = hdr.replace(a, "  const typename Op::Param p = get_param();\n  __builtin_amdgcn_sched_barrier(0);\n" + a)
+    bad = bad.replace(b, "  const bool fast = __builtin_amdgcn_readfirstlane")
+    d = tmp_path / "reordered"
+    d.mkdir()
+    (d / "mctq_kernels.hpp").write_text(bad)
+    (d / "mctq_affine.hip").write_text(open(os.path.join(B.CSRC, "mctq_affine.hip")).read())
+    with pytest.raises(AssertionError, match="in front of the tile's fourth data load"):
+        check_headline_schedule(_compile_affine_asm(tmp_path, src_dir=d))

@@ -256,6 +256,7 @@ def _model(dtype=torch.float32):
 
 
 @pytest.mark.gpu
+@torch.no_grad()      # inference forwards: a forward autograd may record gets fresh tensors, not the plan (pytorch/batching.py)
 def test_plan_follows_parameter_edits_casts_and_storage_swaps_by_itself():
     """after model.half(), an edited / replaced quantizer parameter or a re-pointed weight the
     pre-packed plan must not raise and must not quantize with stale state -- it is rebuilt or re-pointed without
@@ -549,6 +550,7 @@ def test_fuzz_batched_lut_launch_random_shapes_axes_dtypes_codebooks_against_ora
 
 
 @pytest.mark.gpu
+@torch.no_grad()      # inference forwards: a forward autograd may record gets fresh tensors, not the plan (pytorch/batching.py)
 def test_model_with_lut_and_affine_weights_batches_both_in_plan_mode():
     """reuse_buffers=True: affine AND decision-table LUT weights quantizers ride the pre-packed plan (two table launches),
     results equal the per-layer calls; editing a LUT quantizer's attribute (its `_stale` flag) rebuilds the plan."""

@@ -486,7 +486,7 @@ R6_SHAPES = [  # (outer, C, inner): lastaxis (inner 1, C % N == 0) ...
 @pytest.mark.parametrize("with_zp", [False, True])
 def test_channel_last_and_short_row_launches_vs_oracle(lib, dt, with_zp):
     """Every shape x {symmetric (NULL zero-point table), zero points} x the three routes of 16-bit short rows (tuning key
-    "gather16"), scales that include values outside recip_exact's range (the wave falls back to the IEEE division) -- against
+    "shortrows"), scales that include values outside recip_exact's range (the wave falls back to the IEEE division) -- against
     the oracle, bit for bit."""
     from mct_quantizers_amd.hip import native
     from oracle import mctq_oracle as O
@@ -495,7 +495,7 @@ def test_channel_last_and_short_row_launches_vs_oracle(lib, dt, with_zp):
     seen = set()
     try:
         for route in ((1,) if dt == "float32" else (0, 1, 2)):
-            native.set_tuning("gather16", route)
+            native.set_tuning("shortrows", route)
             for k, (outer, C, inner) in enumerate(R6_SHAPES):
                 rng = np.random.default_rng(1000 * k + 7 * route + with_zp)
                 qmin, qmax = (-8, 7) if k % 3 == 0 else (-128, 127)
@@ -518,8 +518,8 @@ def test_channel_last_and_short_row_launches_vs_oracle(lib, dt, with_zp):
                 got = y.float().cpu().numpy()
                 assert finite_equal(got, want, x_np), (shape, route, native.last_launch(), first_mismatch(got, want, x_np))
     finally:
-        native.set_tuning("gather16", 1)
-    assert {"lastaxis_kernel", "gather_kernel"} <= seen, seen
+        native.set_tuning("shortrows", 1)
+    assert {"lastaxis_kernel", "shortrows_kernel"} <= seen, seen
 
 
 def _tie_heavy_r6(rng, shape, s_b, zp_b, qmin, qmax):

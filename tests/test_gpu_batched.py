@@ -141,6 +141,7 @@ def test_batched_weight_quantization_of_a_model_is_bit_identical(lib):
     assert torch.equal(model(x), after) and not torch.equal(after, want)
 
 
+@torch.no_grad()      # inference forwards: a forward autograd may record gets fresh tensors, not the plan (pytorch/batching.py)
 def test_batched_weight_quantization_with_persistent_buffers(lib):
     """reuse_buffers=True: pre-packed BatchPlan + persistent outputs.  Same values as per-layer quantization on every
     forward, in-place weight updates followed, sub-module calls past the hook fall back to the quantizer, refresh()

@@ -9,7 +9,7 @@ then paid torch's allocator -- hipMalloc -- for every fresh output, which is wha
 5 repeats of 100 launches between HIP events: min / median / max of the repeat means, the launch variant per line.
 
     python tools/sweep_shapes.py [--dtypes f32,bf16,f16] [--routes 0,1,2] [--explain-outlier] [--quick]
-`--routes`: tuning key "gather16" values to sweep for 16-bit storage (default: the library's default only)."""
+`--routes`: tuning key "shortrows" values to sweep for 16-bit storage (default: the library's default only)."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -103,13 +103,13 @@ for name in args.dtypes.split(","):
         b, xs = ring_for(x)
         for route in routes:
             if route is not None:
-                native.set_tuning("gather16", route)
+                native.set_tuning("shortrows", route)
             lo, med, hi = measure(q, xs)
-            tag = "" if route is None else f" gather16={route}"
+            tag = "" if route is None else f" shortrows={route}"
             flag = "  <-- spread > 1.3x" if hi > 1.3 * lo else ""
             print(f"{name:9s} {str(shape):22s} {axis:4d}  {lo:7.2f} /{med:7.2f} /{hi:7.2f}   {b / med / 1e3:7.0f}      {b / med / 8e6:.3f}  "
                   f"{hi / lo:5.2f}x  {native.last_launch()}{tag}{flag}", flush=True)
         if routes != [None]:
-            native.set_tuning("gather16", 1)
+            native.set_tuning("shortrows", 1)
         del xs
         torch.cuda.empty_cache()
