@@ -81,9 +81,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "resnet50", "linear16"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "resnet50", "linear16", "sym"],
                     help="cfg1..cfg5: the BASELINE configurations; resnet50 / linear16: ALL weights of that model re-quantized "
-                         "in one batched launch per step (what a wrapped model does per forward)")
+                         "in one batched launch per step (what a wrapped model does per forward); sym: WeightsSymmetric 8 bit "
+                         "per channel along --axis of a tensor of --shape (the launch shapes no BASELINE configuration has: "
+                         "channel-last, short and ragged rows)")
+    ap.add_argument("--shape", default="4096x4096", help="--config sym: the tensor's shape, e.g. 4096x4096 or 64x56x56x256")
+    ap.add_argument("--axis", type=int, default=0, help="--config sym: the channel axis")
     ap.add_argument("--batched", type=int, default=0,
                     help="T > 0: a step is ONE batched launch over T tensors of the configuration (affine configs)")
     ap.add_argument("--batch", type=int, default=64, help="N of config 3")
@@ -136,6 +140,19 @@ def parse():
 
 
 DTYPE_NAMES = {"f32": "fp32", "bf16": "bf16", "f16": "fp16"}
+
+
+def cpu_model() -> str:
+    """The host CPU's model string (BASELINE.md section 3 asks for it beside the CPU baseline): /proc/cpuinfo, else platform."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith(("model name", "hardware", "cpu model")):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
 
 
 def metric_label(config: str, wl, batched: int, dtype: str = "f32") -> str:
@@ -276,8 +293,12 @@ def main():
         x_np, quantizer = None, quantizers[0]
         args.batched = len(weights)
     else:
-        x_np = workloads.make_input(args.config, batch=args.batch)
-        wl = workloads.make_workload(args.config, x_np)
+        if args.config == "sym":
+            x_np = workloads.make_input("sym", shape=tuple(int(d) for d in args.shape.lower().split("x")))
+            wl = workloads.make_workload("sym", x_np, axis=args.axis)
+        else:
+            x_np = workloads.make_input(args.config, batch=args.batch)
+            wl = workloads.make_workload(args.config, x_np)
         quantizer = getattr(mq.pytorch_quantizers, wl.quantizer)(**wl.kwargs)
     tdtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     is_lut = "LUT" in wl.quantizer or "Lut" in wl.quantizer
@@ -527,6 +548,8 @@ def main():
     # ---- measured HBM traffic per launch (rocprofv3 PMC passes committed under profiles/) ----------------
     if not dry:
         key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
+        if args.config == "sym":
+            key = f"sym_{args.shape.lower()}_axis{args.axis % len(wl.shape)}"
         if args.batched and not model_mode:
             key = f"{key}_batched{tensors}"
         if stream_on:
@@ -708,6 +731,7 @@ def main():
             if el >= args.cpu_seconds or n >= 2000:
                 break
         result["cpu_baseline"] = {"value": elems * n / el, "unit": "elems/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "cpu_model": cpu_model(), "host_threads": os.cpu_count(),
                                   "sample": f"{n} passes over all {len(weights)} weight tensors with the ATen CPU operator the "
                                             f"reference calls (oracle/torch_cpu.py parameters), {el:.1f} s",
                                   "ms_per_call": el * 1e3 / n, "gpu_output_bit_equal": same,
@@ -746,6 +770,7 @@ def main():
             if el >= args.cpu_seconds or n >= 2000:
                 break
         result["cpu_baseline"] = {"value": wl.numel * n / el, "unit": "elems/s", "cores": best, "kind": "port",
+                                  "cpu_model": cpu_model(), "host_threads": ncpu,
                                   "sample": f"{n} calls on one {wl.name} tensor of the ATen CPU operator the "
                                             f"reference calls, parameters from the oracle restatement "
                                             f"(oracle/torch_cpu.py), {el:.1f} s at the best of "

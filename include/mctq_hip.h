@@ -482,10 +482,10 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  2544, 2548 (wave-wide tiles), 2560 (256 x 256 ping-pong)
  *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
- *   key "shortrows" : affine per-channel rows shorter than a tile through shortrows_kernel (per-lane parameter reads, no LDS
- *                  window) instead of window_kernel: 0 = never, 1 (default) = where it measured faster (16-bit rows that are
- *                  not whole 8-element vectors or are shorter than 64 elements; float32 rows of 4 ... 31 elements), 2 = every
- *                  eligible tensor
+ *   key "shortrows" : affine per-channel tensors through shortrows_kernel (per-lane parameter reads behind the tile's data loads,
+ *                  no LDS window): 0 = never, 1 (default) = where it measured faster (16-bit storage: every short or ragged row
+ *                  shape, and long rows while the launch is at most one round of resident blocks; float32: rows of 4 ... 31
+ *                  elements), 2 = every eligible tensor (rows of at least one lane-vector, fewer than 2^24 elements per row)
  * Only variants a default dispatcher can select are instantiated; every value of every key is exercised by the GPU tests.
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.
  */

@@ -53,7 +53,7 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
     const int64_t innerv = inner / 4, tiles = (innerv + kThreads - 1) / kThreads;
     if ((tiles * kThreads - innerv) * 12 > tiles * kThreads) long_rows = false;      // > 1/12 of the row's lanes idle
   }
-  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !long_rows && g_shortrows < 2 &&
+  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !long_rows && g_shortrows != 2 &&
       (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && n < (1ll << 31) - 4096 && channels <= 0x7fffffffLL) {
     return fq_gather_one_f32(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
   }

@@ -78,19 +78,11 @@ template <> struct VecT<_Float16, 4> { typedef f16x4 type; };
 template <> struct VecT<__bf16, 8> { typedef b16x8 type; };
 template <> struct VecT<__bf16, 4> { typedef b16x4 type; };
 
-// 16-bit input widened to float32 output (the LUT quantizers): 0 = four elements per lane access (8-byte loads, one 16-byte
-// store), 1 = eight (one 16-byte load, two 16-byte stores) -- timing experiment of round 6
-#ifndef MCTQ_LUT16_WIDE
-#define MCTQ_LUT16_WIDE 0
-#endif
-struct f32x8w { f32x4 lo, hi; };
-
 template <class TI, class TO>
 struct IO {
-  static constexpr bool kWide = MCTQ_LUT16_WIDE && sizeof(TI) == 2 && sizeof(TO) == 4;
-  static constexpr int N = kWide ? 8 : 16 / (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
+  static constexpr int N = 16 / (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
   typedef typename VecT<TI, N>::type VI;
-  typedef typename std::conditional<kWide, f32x8w, typename VecT<typename std::conditional<kWide, float, TO>::type, kWide ? 4 : N>::type>::type VO;
+  typedef typename VecT<TO, N>::type VO;
 
   // NT: 1 = non-temporal loads and stores (streaming: the default),
   //     2 = non-temporal loads, cached stores (the output is consumed right away and fits the aggregate L2)
@@ -101,35 +93,22 @@ struct IO {
   }
   template <int NT>
   __device__ __forceinline__ static void store(TO* p, VO v) {
-    if constexpr (kWide) {
-      f32x4* q = reinterpret_cast<f32x4*>(p);
-      if (NT == 1) { __builtin_nontemporal_store(v.lo, q); __builtin_nontemporal_store(v.hi, q + 1); }
-      else { q[0] = v.lo; q[1] = v.hi; }
-    } else {
-      VO* q = reinterpret_cast<VO*>(p);
-      if (NT == 1) __builtin_nontemporal_store(v, q);
-      else *q = v;
-    }
+    VO* q = reinterpret_cast<VO*>(p);
+    if (NT == 1) __builtin_nontemporal_store(v, q);
+    else *q = v;
   }
   __device__ __forceinline__ static void unpack(VI v, float* f) {
 #pragma unroll
     for (int i = 0; i < N; ++i) f[i] = (float)v[i];            // exact widening
   }
   __device__ __forceinline__ static VO pack(const float* f) {
-    if constexpr (kWide) {
-      VO o;
+    VO o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { o.lo[i] = f[i]; o.hi[i] = f[4 + i]; }
-      return o;
-    } else {
-      VO o;
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        if constexpr (sizeof(TO) == 1) o[i] = (TO)(int32_t)f[i];  // integer codes in [-128, 255]: the low byte (int8 and uint8 alike)
-        else o[i] = (TO)f[i];                                     // round-to-nearest-even narrowing
-      }
-      return o;
+    for (int i = 0; i < N; ++i) {
+      if constexpr (sizeof(TO) == 1) o[i] = (TO)(int32_t)f[i];  // integer codes in [-128, 255]: the low byte (int8 and uint8 alike)
+      else o[i] = (TO)f[i];                                     // round-to-nearest-even narrowing
     }
+    return o;
   }
 };
 
@@ -784,14 +763,9 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
                                             int64_t limit, bool full) {
   typedef IO<TI, TO> io;
   if (full) {
-#ifndef MCTQ_TILE_SCHEDULE
-#define MCTQ_TILE_SCHEDULE 0     // timing experiments (round 6): 1 = every result, then the stores; 2 = also wait for ALL loads first
-#endif
-    if constexpr (MCTQ_TILE_SCHEDULE == 2) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), nothing else
-    if constexpr (HasTile<Op>::value || MCTQ_TILE_SCHEDULE != 0) {
+    if constexpr (HasTile<Op>::value) {
       typename io::VO r[U];
       run_vectors<FAST, Op, TI, TO, U>(op, w, r, p, book);
-      if constexpr (MCTQ_TILE_SCHEDULE != 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) io::template store<NT>(y + (first + u * kThreads) * io::N, r[u]);
     } else {
@@ -815,6 +789,18 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
   }
 }
 
+// Timing experiment (round 6): a wave delays its first loads by its slot number on the SIMD x MCTQ_STAGGER x 64 cycles, so that
+// the 8 waves of a SIMD -- which a one-round launch starts together -- do not queue their loads at the same instant.
+#ifndef MCTQ_STAGGER
+#define MCTQ_STAGGER 0
+#endif
+__device__ __forceinline__ void stagger_start() {
+#if MCTQ_STAGGER
+  const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u;       // HW_REG_HW_ID[3:0]: the wave's slot on its SIMD
+  for (uint32_t i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(MCTQ_STAGGER);
+#endif
+}
+
 // One tile whose parameters are wave-uniform, FULL known at compile time so the hot (full) path and
 // the guarded (row-end) path never share code: the compiler otherwise merges their tails and ends up
 // serialising the loads of the hot path.
@@ -823,6 +809,7 @@ __device__ __forceinline__ void one_tile(const Op& op, float* smem, const TI* __
                                          int64_t first, int64_t limit, GetParam get_param) {
   typedef IO<TI, TO> io;
   typename io::VI v[U];
+  stagger_start();
   // Issue the data loads early; the parameter fetch (dependent scalar loads + an IEEE divide) and the table's LDS
   // write + barrier then run in the shadow of the HBM latency.  An op whose table is read through vector loads asks for
   // it BEFORE the data loads (in-order return: see LutTableOp::prefetch).
@@ -997,6 +984,7 @@ __device__ __forceinline__ void lastaxis_body(const Op& op, float* smem, const T
   if constexpr (std::is_same<typename Op::Book, NoBook>::value) {
     if (g >= slab) return;                                   // idle lanes of the slab's last piece (ops with a table stay for its barrier)
   }
+  stagger_start();
   // lanes of slab u that hold a row of the tensor (wave-uniform bound; the last group of a launch may be short)
   uint32_t lim[U];
 #pragma unroll
@@ -1292,8 +1280,7 @@ int cu_count();
 template <class TI, class TO>
 static bool vec_aligned(const void* x, const void* y) {
   typedef IO<TI, TO> io;
-  constexpr size_t ya = io::N * sizeof(TO) > 16 ? 16 : io::N * sizeof(TO);       // (a wide output goes out as two 16-byte stores)
-  return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % ya) == 0;
+  return ((uintptr_t)x % (io::N * sizeof(TI))) == 0 && ((uintptr_t)y % (io::N * sizeof(TO))) == 0;
 }
 
 // Launch through hipModuleLaunchKernel with the kernel's hipFunction_t resolved once per (kernel, device): skips
@@ -1426,10 +1413,43 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   const int64_t rows = outer * channels;
   const bool vec_ok = vec_aligned<TI, TO>(x, y);
 
+  // shortrows shape (affine quantizers only): rows of at least one lane-vector, tile offsets exact in float32.
+  // Tuning key "shortrows": 0 never, 1 (default) where it measured faster, 2 whenever eligible.  Measured (profiles/r06/
+  // ab_shortrows3.log, sweep_routes_b.log; A / B in one process): 16-bit tensors -- 4-9 % faster than window_kernel on EVERY
+  // short- or ragged-row shape (16384 x 1024 12.6 -> 11.8 us, 1048576 x 16 13.6 -> 12.3, 50257 x 768 28.1 -> 26.8, 16384 x 1020
+  // 13.6 -> 12.9), and 2-14 % faster than rows_kernel / rowsteps_kernel on long rows while the launch is at most ONE round of
+  // resident blocks (4096^2 12.0 -> 11.75, 256 x 65536 12.45 -> 11.8, 2048 x 4608 10.1 -> 8.65) but 3 % slower on several
+  // rounds (8192^2 42.0 -> 43.2); float32 -- equal to the gather launch and to rows_kernel within 1 % everywhere, so only
+  // the rows the gather launch does not take (4 ... 31 elements: 23.9 -> 22.2 us) come here.
+  if constexpr (std::is_same<Op, AffineOp>::value && std::is_same<TI, TO>::value) {
+    constexpr int64_t TILE = (int64_t)kThreads * 4 * io::N;
+    const bool eligible = vec_ok && inner >= io::N && channels > 1 && n < (1ll << 32) - TILE && inner + TILE < (1 << 24) &&
+                          channels + TILE < (1 << 24);
+    const bool long_rows = inner % io::N == 0 && inner / io::N >= kThreads;
+    const bool one_round = (n + TILE - 1) / TILE <= 8LL * cu_count();
+    // (a FORCED rowsteps_kernel -- tuning key "rowsteps" = 1 -- keeps its long rows)
+    const bool rule = sizeof(TI) == 2 ? (!long_rows || (one_round && g_rowsteps != 1)) : (!long_rows && inner < 32);
+    if (eligible && (g_shortrows == 2 || (g_shortrows == 1 && rule))) {
+      const bool whole = inner % io::N == 0;
+      uint32_t shift = 32;
+      if ((inner & (inner - 1)) == 0) { shift = 0; while ((1ll << shift) < inner) ++shift; }
+      const float ri = 1.0f / (float)inner, rc = 1.0f / (float)channels;
+      const unsigned grid = (unsigned)((n + TILE - 1) / TILE);
+#define MCTQ_SHORTROWS(NT_, ZP_, W_)                                                                                   \
+      hipLaunchKernelGGL((shortrows_kernel<TI, 4, NT_, ZP_, W_>), dim3(grid), dim3(kThreads), 0, st, x, y, (uint32_t)n,  \
+                         (uint32_t)inner, (uint32_t)channels, ri, rc, shift, op)
+      MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
+        if (op.zps) { if (whole) MCTQ_SHORTROWS(NT, true, true); else MCTQ_SHORTROWS(NT, true, false); }
+        else { if (whole) MCTQ_SHORTROWS(NT, false, true); else MCTQ_SHORTROWS(NT, false, false); }
+        note<Op, TI, TO>("shortrows_kernel", 4, NT);
+      });
+#undef MCTQ_SHORTROWS
+      return check_launch("shortrows launch");
+    }
+  }
+
   // rows shape: long, vector-divisible rows.
-  const bool shortrows_everywhere = std::is_same<Op, AffineOp>::value && g_shortrows == 3;      // (timing experiment)
-  if (!shortrows_everywhere && vec_ok && (inner % io::N) == 0 && inner / io::N >= kThreads && channels <= 0xffffffffLL &&
-      rows <= 0xffffffffLL) {
+  if (vec_ok && (inner % io::N) == 0 && inner / io::N >= kThreads && channels <= 0xffffffffLL && rows <= 0xffffffffLL) {
     const int64_t innerv = inner / io::N;
     if constexpr (Op::kHeavy) {
       // Lane-vectors per lane per tile: the widest of {4, 2, 1} whose idle lanes in the last tile
@@ -1534,30 +1554,6 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
 #undef MCTQ_LASTAXIS
         return check_launch("lastaxis launch");
       }
-    }
-  }
-
-  // shortrows shape (affine quantizers only; tuning key "shortrows": 0 never, 1 the measured rule, 2 every eligible tensor).
-  if constexpr (std::is_same<Op, AffineOp>::value && std::is_same<TI, TO>::value) {
-    constexpr int64_t TILE = (int64_t)kThreads * 4 * io::N;
-    const bool whole = inner % io::N == 0;
-    const bool rule = sizeof(TI) == 2 ? (!whole || inner < 64) : inner < 32;
-    if (vec_ok && g_shortrows != 0 && (g_shortrows >= 2 || rule) && inner >= io::N && channels > 1 &&
-        n < (1ll << 32) - TILE && inner + TILE < (1 << 24) && channels + TILE < (1 << 24)) {
-      uint32_t shift = 32;
-      if ((inner & (inner - 1)) == 0) { shift = 0; while ((1ll << shift) < inner) ++shift; }
-      const float ri = 1.0f / (float)inner, rc = 1.0f / (float)channels;
-      const unsigned grid = (unsigned)((n + TILE - 1) / TILE);
-#define MCTQ_SHORTROWS(NT_, ZP_, W_)                                                                                   \
-      hipLaunchKernelGGL((shortrows_kernel<TI, 4, NT_, ZP_, W_>), dim3(grid), dim3(kThreads), 0, st, x, y, (uint32_t)n,  \
-                         (uint32_t)inner, (uint32_t)channels, ri, rc, shift, op)
-      MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
-        if (op.zps) { if (whole) MCTQ_SHORTROWS(NT, true, true); else MCTQ_SHORTROWS(NT, true, false); }
-        else { if (whole) MCTQ_SHORTROWS(NT, false, true); else MCTQ_SHORTROWS(NT, false, false); }
-        note<Op, TI, TO>("shortrows_kernel", 4, NT);
-      });
-#undef MCTQ_SHORTROWS
-      return check_launch("shortrows launch");
     }
   }
 

@@ -165,7 +165,7 @@ int mctq_set_tuning(const char* key, int32_t value) {
     return 0;
   }
   if (!strcmp(key, "shortrows")) {
-    if (value < 0 || value > 3) return fail_arg("shortrows must be 0, 1, 2 (or 3: timing experiment)");
+    if (value != 0 && value != 1 && value != 2) return fail_arg("shortrows must be 0, 1 or 2");
     g_shortrows = value;
     return 0;
   }

@@ -58,6 +58,8 @@ def _build_lock():
 # hash is recomputed from the files (~1 ms) and compared -- by needs_build() before deciding to reuse, and by the loader
 # (hip/native.py) before any call.
 
+UNIT_SECONDS = {}            # translation unit -> compile wall seconds of the last _build() in this process (None: cached object reused)
+
 ID_MARKER = b"MCTQ_BUILD_ID="
 BINDING_ID_MARKER = b"MCTQ_BINDING_ID="
 
@@ -120,7 +122,9 @@ def _build(verbose: bool, force: bool = False) -> str:
     build_id = tree_build_id()
     # one hipcc per translation unit, in parallel (the units are independent).  Objects are cached by the hash of what
     # they were compiled from (the unit, every header, the flags): an unchanged unit is not recompiled.
+    import time
     procs, objs, keep = [], [], set()
+    UNIT_SECONDS.clear()
     for src in SOURCES:
         stamp = ['-DMCTQ_BUILD_ID="%s"' % build_id] if os.path.basename(src) == "mctq_misc.hip" else []
         key = _digest([src] + HEADERS, FLAGS + stamp)
@@ -128,15 +132,29 @@ def _build(verbose: bool, force: bool = False) -> str:
         objs.append(obj)
         keep.add(os.path.basename(obj))
         if os.path.exists(obj) and not force:
+            UNIT_SECONDS[os.path.basename(src)] = None          # object of the same sources, headers and flags reused
             continue
         cmd = [hipcc, *FLAGS, *stamp, *inc, "-c", "-o", obj + ".tmp", src]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((obj, cmd, subprocess.Popen(cmd)))
-    for obj, cmd, proc in procs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
-        os.replace(obj + ".tmp", obj)
+        procs.append((obj, cmd, subprocess.Popen(cmd), time.time(), os.path.basename(src)))
+    # wall time per translation unit (the jobs run in parallel: a unit's time is start -> exit as seen by polling)
+    pending = list(procs)
+    while pending:
+        for job in list(pending):
+            obj, cmd, proc, t0, name = job
+            rc = proc.poll()
+            if rc is None:
+                continue
+            pending.remove(job)
+            UNIT_SECONDS[name] = time.time() - t0
+            if rc != 0:
+                for other in pending:
+                    other[2].kill()
+                raise subprocess.CalledProcessError(rc, cmd)
+            os.replace(obj + ".tmp", obj)
+        if pending:
+            time.sleep(0.05)
     keep.add("mctq_torch.binding.o")                 # the binding's object (build_all compiles it beside these jobs)
     for name in os.listdir(objdir):                  # objects of earlier source versions
         if name not in keep and not name.endswith(".tmp"):

@@ -93,11 +93,20 @@ def make_input(cfg: str, shape=None, batch: int = 8) -> np.ndarray:
         shape = shape or (8192, 8192)
         x = bell_f32(int(np.prod(shape)), 1005).reshape(shape)
         return (x * _row_gain(shape[0], 1005)[:, None]).astype(np.float32)
+    if cfg == "sym":                     # any shape (bench.py --config sym --shape AxB --axis k): the launch-shape sweeps
+        assert shape, "the generic per-channel workload needs a shape"
+        return bell_f32(int(np.prod(shape)), 1100).reshape(shape)
     raise KeyError(cfg)
 
 
-def make_workload(cfg: str, x: np.ndarray) -> Workload:
+def make_workload(cfg: str, x: np.ndarray, axis: int = 0) -> Workload:
     """Quantizer class + constructor arguments for a configuration, derived from its input."""
+    if cfg == "sym":                     # WeightsSymmetric 8 bit per channel along ``axis`` of any shape
+        axis = axis % x.ndim
+        other = tuple(d for d in range(x.ndim) if d != axis)
+        thr = [float(v) for v in np.max(np.abs(x), axis=other)] if other else [float(abs(v)) for v in x]
+        return Workload(f"sym WeightsSymmetric per-channel(axis{axis}) 8b", "WeightsSymmetricInferableQuantizer",
+                        dict(num_bits=8, threshold=thr, per_channel=True, channel_axis=axis), x.shape, 1100)
     if cfg == "cfg1":
         thr = [float(np.max(np.abs(x)))]
         return Workload("cfg1 WeightsSymmetric per-tensor 8b", "WeightsSymmetricInferableQuantizer",

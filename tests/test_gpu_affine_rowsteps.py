@@ -74,7 +74,13 @@ def test_rows_of_four_steps_or_ragged_rows_keep_their_kernels():
     q(torch.randn(64, 2048, device="cuda"))
     assert native.last_launch().startswith("rows_kernel")            # the default: 32 four-step blocks are no full round
     q4 = Q.WeightsSymmetricInferableQuantizer(8, [1.0] * 4096, True, 0)
-    q4(torch.randn(4096, 4096, device="cuda").bfloat16())            # 8192 steps = 2048 blocks = one round of 8 per CU
-    assert native.last_launch().startswith("rowsteps_kernel"), native.last_launch()
+    q4(torch.randn(4096, 4096, device="cuda").bfloat16())            # 8192 steps = 2048 blocks = one round of 8 per CU:
+    assert native.last_launch().startswith("shortrows_kernel"), native.last_launch()   # 16-bit one-round launches (round 6)
+    native.set_tuning("shortrows", 0)
+    try:
+        q4(torch.randn(4096, 4096, device="cuda").bfloat16())
+        assert native.last_launch().startswith("rowsteps_kernel"), native.last_launch()   # ... rowsteps_kernel's window without it
+    finally:
+        native.set_tuning("shortrows", 1)
     q4(torch.randn(4096, 4096, device="cuda"))
     assert native.last_launch().startswith("rows_kernel")

@@ -86,8 +86,12 @@ def run(label, nb, make_call, ys_of):
           f"[A {variants[0]} | B {variants[1]}]", flush=True)
 
 
-def affine_cases(dts):
-    shapes = [("pc0", 4096, 4096), ("pc0", 16384, 1024), ("pc0", 16384, 1020), ("pc0", 65536, 256), ("pc0", 1048576, 16),
+ROUNDS = [("pc0", 8192, 2048), ("pc0", 6144, 4096), ("pc0", 8192, 4096), ("pc0", 12288, 4096), ("pc0", 16384, 4096), ("pc0", 4096, 2048),
+          ("pc0", 2048, 3072), ("pc0", 1024, 4096), ("pc0", 512, 4096)]
+
+
+def affine_cases(dts, shapes=None):
+    shapes = shapes or [("pc0", 4096, 4096), ("pc0", 16384, 1024), ("pc0", 16384, 1020), ("pc0", 65536, 256), ("pc0", 1048576, 16),
               ("pc0", 4096, 4100), ("pc0", 256, 65536), ("pc0", 8192, 8192), ("pc0", 50257, 768), ("pc0", 2048, 4608),
               ("pc1", 4096, 4096), ("pc1", 200704, 256), ("pt", 4096, 4096), ("pt", 9633792, 8), ("pt", 1024, 4096)]
     for dt in dts:
@@ -140,5 +144,7 @@ for c in args.cases.split(","):
     if c == "affine16": affine_cases(["bf16", "f16"])
     elif c == "affinebf16": affine_cases(["bf16"])
     elif c == "affine32": affine_cases(["f32"])
+    elif c == "rounds16": affine_cases(["bf16"], ROUNDS)
+    elif c == "rounds32": affine_cases(["f32"], ROUNDS)
     elif c == "lut16": lut16_cases()
     else: raise SystemExit(f"unknown case set {c}")

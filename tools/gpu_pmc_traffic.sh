@@ -38,6 +38,14 @@ run_cfg cfg2_bf16 --dtype bf16
 run_cfg cfg2_f16 --dtype f16
 run_cfg cfg5_bf16 --config cfg5 --dtype bf16 --steps 300
 run_cfg cfg4_bf16 --config cfg4 --dtype bf16 --steps 300
+# round 6: the launch shapes VERDICT r05 #1 names (16-bit channel-last and short / ragged rows), and their float32 twins
+run_cfg sym_4096x4096_axis1_bf16 --config sym --shape 4096x4096 --axis 1 --dtype bf16
+run_cfg sym_65536x200_axis1_bf16 --config sym --shape 65536x200 --axis 1 --dtype bf16
+run_cfg sym_16384x1020_axis0_bf16 --config sym --shape 16384x1020 --axis 0 --dtype bf16
+run_cfg sym_1048576x16_axis0_bf16 --config sym --shape 1048576x16 --axis 0 --dtype bf16
+run_cfg sym_16384x1024_axis0_bf16 --config sym --shape 16384x1024 --axis 0 --dtype bf16
+run_cfg sym_64x56x56x256_axis3_bf16 --config sym --shape 64x56x56x256 --axis 3 --dtype bf16
+run_cfg sym_4096x4096_axis1 --config sym --shape 4096x4096 --axis 1
 # stall counters of the headline kernel and of the batched launch: one pass per group (8 SQ slots, 4 TCC slots)
 stall_passes() {   # name, bench args...
   local name=$1; shift
@@ -59,5 +67,10 @@ stall_passes() {   # name, bench args...
 }
 stall_passes cfg2
 stall_passes cfg2_batched16 --batched 16 --steps 30 --warmup 5
+stall_passes cfg2_bf16 --dtype bf16
+stall_passes sym_4096x4096_axis1_bf16 --config sym --shape 4096x4096 --axis 1 --dtype bf16
+stall_passes sym_65536x200_axis1_bf16 --config sym --shape 65536x200 --axis 1 --dtype bf16
+stall_passes sym_16384x1020_axis0_bf16 --config sym --shape 16384x1020 --axis 0 --dtype bf16
+stall_passes sym_1048576x16_axis0_bf16 --config sym --shape 1048576x16 --axis 0 --dtype bf16
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
-for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5 cfg2_bf16 cfg2_f16 cfg5_bf16 cfg4_bf16; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
+for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg4 cfg5 cfg2_bf16 cfg2_f16 cfg5_bf16 cfg4_bf16 sym_4096x4096_axis1_bf16 sym_65536x200_axis1_bf16 sym_16384x1020_axis0_bf16 sym_1048576x16_axis0_bf16 sym_16384x1024_axis0_bf16 sym_64x56x56x256_axis3_bf16 sym_4096x4096_axis1; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
