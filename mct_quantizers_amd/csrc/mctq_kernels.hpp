@@ -789,18 +789,6 @@ __device__ __forceinline__ void finish_tile(const Op& op, const typename Op::Par
   }
 }
 
-// Timing experiment (round 6): a wave delays its first loads by its slot number on the SIMD x MCTQ_STAGGER x 64 cycles, so that
-// the 8 waves of a SIMD -- which a one-round launch starts together -- do not queue their loads at the same instant.
-#ifndef MCTQ_STAGGER
-#define MCTQ_STAGGER 0
-#endif
-__device__ __forceinline__ void stagger_start() {
-#if MCTQ_STAGGER
-  const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u;       // HW_REG_HW_ID[3:0]: the wave's slot on its SIMD
-  for (uint32_t i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(MCTQ_STAGGER);
-#endif
-}
-
 // One tile whose parameters are wave-uniform, FULL known at compile time so the hot (full) path and
 // the guarded (row-end) path never share code: the compiler otherwise merges their tails and ends up
 // serialising the loads of the hot path.
@@ -809,7 +797,6 @@ __device__ __forceinline__ void one_tile(const Op& op, float* smem, const TI* __
                                          int64_t first, int64_t limit, GetParam get_param) {
   typedef IO<TI, TO> io;
   typename io::VI v[U];
-  stagger_start();
   // Issue the data loads early; the parameter fetch (dependent scalar loads + an IEEE divide) and the table's LDS
   // write + barrier then run in the shadow of the HBM latency.  An op whose table is read through vector loads asks for
   // it BEFORE the data loads (in-order return: see LutTableOp::prefetch).
@@ -984,7 +971,6 @@ __device__ __forceinline__ void lastaxis_body(const Op& op, float* smem, const T
   if constexpr (std::is_same<typename Op::Book, NoBook>::value) {
     if (g >= slab) return;                                   // idle lanes of the slab's last piece (ops with a table stay for its barrier)
   }
-  stagger_start();
   // lanes of slab u that hold a row of the tensor (wave-uniform bound; the last group of a launch may be short)
   uint32_t lim[U];
 #pragma unroll
@@ -1423,6 +1409,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   // the rows the gather launch does not take (4 ... 31 elements: 23.9 -> 22.2 us) come here.
   if constexpr (std::is_same<Op, AffineOp>::value && std::is_same<TI, TO>::value) {
     constexpr int64_t TILE = (int64_t)kThreads * 4 * io::N;
+    // (channels > 1: a per-tensor launch through this kernel is equal at 64 MiB and 13-23 % slower below, profiles/r06/ab_tqp.log)
     const bool eligible = vec_ok && inner >= io::N && channels > 1 && n < (1ll << 32) - TILE && inner + TILE < (1 << 24) &&
                           channels + TILE < (1 << 24);
     const bool long_rows = inner % io::N == 0 && inner / io::N >= kThreads;

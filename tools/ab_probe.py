@@ -28,6 +28,7 @@ def arm(spec):
     lib = ctypes.CDLL(path)
     lib.mctq_fq_per_channel.argtypes = [P, P, I64, I64, I64, I32, P, P, I32, I32, P]
     lib.mctq_fq_per_tensor.argtypes = [P, P, I64, I32, F32, I32, I32, I32, P]
+    lib.mctq_fq_per_tensor_tqp.argtypes = [P, P, I64, I32, P, P, I32, I32, P]
     lib.mctq_lutt_per_channel.argtypes = [P, P, I64, I64, I64, I32, P, F32, P, I32, F32, F32, F32, P]
     lib.mctq_set_tuning.argtypes = [ctypes.c_char_p, I32]
     lib.mctq_last_launch.restype = ctypes.c_char_p
@@ -86,6 +87,8 @@ def run(label, nb, make_call, ys_of):
           f"[A {variants[0]} | B {variants[1]}]", flush=True)
 
 
+TQP = [("tqp", 4096, 4096), ("pt", 4096, 4096), ("tqp", 2048, 4096), ("pt", 2048, 4096), ("tqp", 1024, 4096), ("tqp", 64, 150528), ("pt", 64, 150528),
+       ("tqp", 8, 150528), ("pt", 8, 150528)]
 ROUNDS = [("pc0", 8192, 2048), ("pc0", 6144, 4096), ("pc0", 8192, 4096), ("pc0", 12288, 4096), ("pc0", 16384, 4096), ("pc0", 4096, 2048),
           ("pc0", 2048, 3072), ("pc0", 1024, 4096), ("pc0", 512, 4096)]
 
@@ -104,12 +107,16 @@ def affine_cases(dts, shapes=None):
             ys = [torch.empty_like(x) for x in xs]
             C = rows if kind == "pc0" else cols
             s = (torch.rand(C, device=dev) * 0.05 + 0.01)
+            s1 = torch.tensor([0.031], device=dev)
+            z1 = torch.tensor([3], dtype=torch.int32, device=dev)
 
             def make_call(lib):
                 if kind == "pc0":
                     return lambda i: lib.mctq_fq_per_channel(xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), 1, rows, cols, dtc, s.data_ptr(), None, -128, 127, stream)
                 if kind == "pc1":
                     return lambda i: lib.mctq_fq_per_channel(xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, cols, 1, dtc, s.data_ptr(), None, -128, 127, stream)
+                if kind == "tqp":
+                    return lambda i: lib.mctq_fq_per_tensor_tqp(xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows * cols, dtc, s1.data_ptr(), z1.data_ptr(), 0, 255, stream)
                 return lambda i: lib.mctq_fq_per_tensor(xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows * cols, dtc, 0.031, 3, 0, 255, stream)
             run(f"{dt} {kind} {rows}x{cols}", nb, make_call, lambda: [ys[0]])
             del xs, ys
@@ -144,6 +151,8 @@ for c in args.cases.split(","):
     if c == "affine16": affine_cases(["bf16", "f16"])
     elif c == "affinebf16": affine_cases(["bf16"])
     elif c == "affine32": affine_cases(["f32"])
+    elif c == "tqp16": affine_cases(["bf16", "f16"], TQP)
+    elif c == "tqp32": affine_cases(["f32"], TQP)
     elif c == "rounds16": affine_cases(["bf16"], ROUNDS)
     elif c == "rounds32": affine_cases(["f32"], ROUNDS)
     elif c == "lut16": lut16_cases()

@@ -256,6 +256,93 @@ __global__ __launch_bounds__(kThreads) void lastaxis2_loop_kernel(const TI* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// lastaxis3: the channel-last tensor cut like the short-row launch -- block b owns U x 256 CONSECUTIVE lane-vectors (one contiguous
+// 8 or 16 KiB read) whatever rows they fall in; every lane-vector fetches its own N channels' scales (no sharing between a lane's
+// vectors unless the row length divides the step) and inverts them right where they are used.
+// ------------------------------------------------------------------------------------------------------------------
+template <class TI, int U, int NT, bool HASZP>
+__global__ __launch_bounds__(kThreads) void lastaxis3_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n_lv,
+                                                             uint32_t vc, float rvc, float lo, float hi,
+                                                             const float* __restrict__ scales, const int32_t* __restrict__ zps) {
+  typedef IO<TI, TI> io;
+  constexpr int N = io::N;
+  typedef typename io::VI VI;
+  const uint32_t b0 = blockIdx.x * (U * kThreads);
+  const bool full = b0 + U * kThreads <= n_lv;
+  VI v[U];
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads + threadIdx.x);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (b0 + u * kThreads + threadIdx.x < n_lv) v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads + threadIdx.x);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const uint32_t base = b0 % vc;                                   // uniform
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 s4[U][N / 4];
+  i32x4 z4[U][N / 4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    uint32_t c = base + u * kThreads + threadIdx.x;                // < vc + U * 256: exact through float32
+    c -= div_small(c, vc, rvc) * vc;
+#pragma unroll
+    for (int j = 0; j < N / 4; ++j) {
+      s4[u][j] = *reinterpret_cast<const f32x4*>(scales + (size_t)c * N + 4 * j);
+      if (HASZP) z4[u][j] = *reinterpret_cast<const i32x4*>(zps + (size_t)c * N + 4 * j);
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int j = 0; j < N / 4; ++j) { float t[4] = {s4[u][j][0], s4[u][j][1], s4[u][j][2], s4[u][j][3]}; ok = ok && recip_all_ok(t); }
+  const bool exact = __builtin_amdgcn_ballot_w64(!ok) == 0;
+  VI r[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (!full && b0 + u * kThreads + threadIdx.x >= n_lv) continue;
+    float in[N], out[N];
+    io::unpack(v[u], in);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float sc = s4[u][j / 4][j % 4];
+      const float inv = exact ? recip_nr2(sc) : 1.0f / sc;
+      const float zf = HASZP ? (float)z4[u][j / 4][j % 4] : 0.0f;
+      const float q = __builtin_amdgcn_fmed3f(__builtin_rintf(in[j] * inv), lo - zf, hi - zf);
+      float y = __builtin_fmaf(q, sc, 0.0f);
+      asm("" : "+v"(y));
+      out[j] = y;
+    }
+    r[u] = io::pack(out);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (full || b0 + u * kThreads + threadIdx.x < n_lv) io::template store<NT>(ys + ((size_t)b0 + u * kThreads + threadIdx.x) * N, r[u]);
+}
+
+template <class TI>
+static int launch_lastaxis3(int u_sel, const void* xv, void* yv, int64_t rows, int64_t channels, const float* scales,
+                            const int32_t* zps, int32_t qmin, int32_t qmax, int nt, hipStream_t st) {
+  typedef IO<TI, TI> io;
+  const TI* x = static_cast<const TI*>(xv);
+  TI* y = static_cast<TI*>(yv);
+  if (channels % io::N) return fail_arg("channels % N");
+  const int64_t vc = channels / io::N, n_lv = rows * vc;
+  if (n_lv >= (1ll << 32) - 2048 || vc + 2048 >= (1 << 24)) return fail_arg("too large for the experiment");
+  const float rvc = 1.0f / (float)vc, lo = (float)qmin, hi = (float)qmax;
+  const unsigned grid = (unsigned)((n_lv + u_sel * kThreads - 1) / (u_sel * kThreads));
+#define LA3(U_, NT_, Z_) hipLaunchKernelGGL((lastaxis3_kernel<TI, U_, NT_, Z_>), dim3(grid), dim3(kThreads), 0, st, x, y, (uint32_t)n_lv, \
+                                             (uint32_t)vc, rvc, lo, hi, scales, zps)
+  if (u_sel == 4) { if (nt == 2) { if (zps) LA3(4, 2, true); else LA3(4, 2, false); } else { if (zps) LA3(4, 1, true); else LA3(4, 1, false); } }
+  else if (u_sel == 2) { if (nt == 2) { if (zps) LA3(2, 2, true); else LA3(2, 2, false); } else { if (zps) LA3(2, 1, true); else LA3(2, 1, false); } }
+  else return fail_arg("U");
+  return check_launch("lastaxis3");
+}
+
 template <class TI>
 static int launch_lastaxis2(int mode, int u_sel, int loops, const void* xv, void* yv, int64_t rows, int64_t channels,
                             const float* scales, const int32_t* zps, int32_t qmin, int32_t qmax, int nt, hipStream_t st) {
@@ -459,6 +546,14 @@ extern "C" int mctq_x_lastaxis(int32_t mode, int32_t u, int32_t loops, const voi
                                void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (loops < 1) loops = 1;
+  if (mode == 21) {                                      // contiguous tiles (lastaxis3)
+    switch (dtype) {
+      case MCTQ_DT_F32: return launch_lastaxis3<float>(u, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      case MCTQ_DT_F16: return launch_lastaxis3<_Float16>(u, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      case MCTQ_DT_BF16: return launch_lastaxis3<__bf16>(u, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      default: return fail_arg("dtype");
+    }
+  }
   switch (dtype) {
     case MCTQ_DT_F32: return launch_lastaxis2<float>(mode, u, loops, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
     case MCTQ_DT_F16: return launch_lastaxis2<_Float16>(mode, u, loops, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);

@@ -23,7 +23,7 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 DT = {"f32": (torch.float32, 0, 4), "f16": (torch.float16, 1, 2), "bf16": (torch.bfloat16, 2, 2)}
 what = set(sys.argv[1:]) or {"recip", "lastaxis", "shortrows"}
-if "sched" in what:
+if "sched" in what or "contig" in what:
     what.add("lastaxis")
 
 
@@ -107,7 +107,9 @@ if "lastaxis" in what:
         def mk(mode, u, loops):
             return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, loops, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
                                                       s.data_ptr(), zp, -128, 127, nt, stream)
-        if "sched" in what:
+        if "contig" in what:
+            modes = [("slab U2", mk(2, 2, 1), True), ("slab U4", mk(2, 4, 1), True), ("contig U2", mk(21, 2, 1), True), ("contig U4", mk(21, 4, 1), True)]
+        elif "sched" in what:
             def mkn(mode, u, ntx):
                 return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, 1, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
                                                           s.data_ptr(), zp, -128, 127, ntx, stream)
