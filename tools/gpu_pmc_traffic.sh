@@ -16,11 +16,11 @@ run_cfg() {   # name, bench args...   (MCTQ_PMC_ONLY="cfg2_bf16 cfg2_f16": only 
   local out=$R/gpurun_out/pmc/$name; mkdir -p $out
   rm -rf /tmp/prof_$name
   # the stats pass runs the judged command as it is (at N = 1 the default run also carries the batched_16x4096 object)
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --no-cpu --no-eager-extra --evidence-launches 0 "$@" > $out/bench_stats.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --no-cpu --no-eager-extra --no-sharded-extra --evidence-launches 0 "$@" > $out/bench_stats.log 2>&1
   find /tmp/prof_$name -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
   for pass in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${name}_$pass
-    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --no-batched-extra --no-eager-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_${name}_$pass -- python3 $R/bench.py --no-cpu --no-batched-extra --no-eager-extra --no-sharded-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 100 --warmup 10 "$@" > $out/bench_$pass.log 2>&1
     f=$(find /tmp/pmc_${name}_$pass -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then head -1 $f > $out/$pass.csv; grep -E "mctq" $f | tail -120 >> $out/$pass.csv; fi
   done
@@ -60,7 +60,7 @@ stall_passes() {   # name, bench args...
              "TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" \
              "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_NC_READ_REQ_sum"; do
     i=$((i+1)); rm -rf /tmp/pmc_stall_${name}_$i
-    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_${name}_$i -- python3 $R/bench.py --no-cpu --no-batched-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 "$@" > $out/bench_stall_$i.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_stall_${name}_$i -- python3 $R/bench.py --no-cpu --no-batched-extra --no-sharded-extra --evidence-launches 0 --prewarm-seconds 0.2 --steps 60 --warmup 10 "$@" > $out/bench_stall_$i.log 2>&1
     f=$(find /tmp/pmc_stall_${name}_$i -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then head -1 $f > $out/stall_$i.csv; grep -E "mctq" $f | tail -400 >> $out/stall_$i.csv; else echo "$name group $i: no counter file (unknown counter name?)"; tail -3 $out/bench_stall_$i.log; fi
   done
