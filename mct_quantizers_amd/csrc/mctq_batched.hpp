@@ -50,7 +50,9 @@ constexpr uint32_t kMaxChunksT = 16384;  // chunk-map entries of a packed table 
 #endif
 constexpr int kBatchU = MCTQ_BATCH_U;
 #ifndef MCTQ_BATCH_EXACT_RECIP
-#define MCTQ_BATCH_EXACT_RECIP 1         // 0: timing experiment (tools/build_variant.py): per-lane scales inverted by the IEEE division as until round 5
+// Per-lane scales of the several-rows path inverted by recip_exact: 1 = in the one-tensor gather launch only (default: +1 % there,
+// -1 % on the 54-weight list launch, profiles/r06/batched_ab.log), 2 = everywhere, 0 = nowhere (timing experiments, tools/build_variant.py)
+#define MCTQ_BATCH_EXACT_RECIP 1
 #endif
 
 struct __attribute__((aligned(16))) BatchItem {   // 64 bytes
@@ -110,7 +112,7 @@ struct GIO {
 // init() runs after the tile's data loads have been issued (it may stage a table in LDS and synchronise the block);
 // uniform(c) / lane(c) build channel c's parameter set from a wave-uniform / per-lane index; run<UNI, N>() quantizes N
 // elements that share one set (UNI: the set is wave-uniform); pick() selects between two sets.
-template <class TI_, class TO_>
+template <class TI_, class TO_, bool EXACT = false>
 struct AffinePol {
   typedef TI_ TI;
   typedef TO_ TO;
@@ -138,7 +140,7 @@ struct AffinePol {
     float sv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { sv[u] = s_lane[c[u]]; r[u].s = sv[u]; r[u].zf = z_lane ? (float)z_lane[c[u]] : 0.0f; }
-    return MCTQ_BATCH_EXACT_RECIP && __builtin_amdgcn_ballot_w64(!recip_all_in_range(sv)) == 0;
+    return EXACT && __builtin_amdgcn_ballot_w64(!recip_all_in_range(sv)) == 0;
   }
   __device__ __forceinline__ static Param finish(const Raw& r, bool exact /* wave-uniform */) {
     Param p; p.s = r.s; p.zf = r.zf;
@@ -398,9 +400,10 @@ __device__ __forceinline__ void batched_block(const Src& src) {
   if (!batched_head(src, it, index)) return;
   const uint32_t e0 = (blockIdx.x - it.tile_begin) * TILE;
   const uint32_t left = it.n - e0;
-  AffinePol<TI, TO> pol(it);
-  if (left >= TILE) batched_tile<true, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, TILE);   // wave-uniform: straight-line code
-  else batched_tile<false, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, left);
+  typedef AffinePol<TI, TO, MCTQ_BATCH_EXACT_RECIP == 2> Pol;
+  Pol pol(it);
+  if (left >= TILE) batched_tile<true, Pol, U, NT>(it, pol, nullptr, e0, TILE);   // wave-uniform: straight-line code
+  else batched_tile<false, Pol, U, NT>(it, pol, nullptr, e0, left);
 }
 
 template <class TI, class TO, int U, int NT>
@@ -433,9 +436,10 @@ __global__ __launch_bounds__(kThreads) void batched_one_kernel(const TI* __restr
   it.tile_begin = 0; it.tiles = gridDim.x; it.reserved = 0; it.lo = lo; it.hi = hi;
   const uint32_t e0 = blockIdx.x * TILE;
   const uint32_t left = n - e0;
-  AffinePol<TI, TO> pol(it);
-  if (left >= TILE) batched_tile<true, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, TILE);
-  else batched_tile<false, AffinePol<TI, TO>, U, NT>(it, pol, nullptr, e0, left);
+  typedef AffinePol<TI, TO, MCTQ_BATCH_EXACT_RECIP != 0> Pol;
+  Pol pol(it);
+  if (left >= TILE) batched_tile<true, Pol, U, NT>(it, pol, nullptr, e0, TILE);
+  else batched_tile<false, Pol, U, NT>(it, pol, nullptr, e0, left);
 }
 
 // The same grid for LUT quantizers with a decision table: all LUT weights of a model, or a group of LUT activation

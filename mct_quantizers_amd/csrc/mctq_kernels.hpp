@@ -17,18 +17,23 @@
 //   rows          per-channel, long vector-divisible rows: one block = one tile of one
 //                 (outer, channel) row; data loads are issued first, then the channel's parameters
 //                 arrive through scalar loads (wave-uniform index) -> SGPR broadcast.
-//   lastaxis      per-channel along the fastest axis (inner == 1): parameters by 16-byte loads from the
-//                 L1/L2-resident tables, one set per element.
-//   window        per-channel, any inner (channel-last, conv kernels, ragged, unaligned): one
-//                 block = one contiguous tile; the parameters of the rows that tile touches are
-//                 staged in LDS once per block and looked up per element without any per-element
-//                 division.
+//   lastaxis      per-channel along the fastest axis (inner == 1): a lane keeps its N channels while stepping down the
+//                 tensor slab by slab; parameters by 16-byte loads from the L1/L2-resident tables once per lane,
+//                 inverted by a five-instruction exact reciprocal.
+//   shortrows     (affine ops) rows shorter than a tile but at least one lane-vector long, and long 16-bit rows of
+//                 launches that fit one round of resident blocks: one block = one contiguous tile; every lane-vector
+//                 reads its own row's scale behind the tile's data loads -- no LDS, no barrier.
+//   window        what is left (rows shorter than a lane-vector, unaligned tensors, > 2^32 elements, the non-affine
+//                 ops' short rows): one block = one contiguous tile; the parameters of the rows that tile touches are
+//                 staged in LDS once per block and looked up per element without any per-element division.
 // The LUT ops stage their codebook table in LDS after the block's data loads are in flight.
 //
 // What is instantiated is what the dispatchers below can select (evidence: the launch-variant log of the
 // whole GPU suite + every bench configuration + the shape sweeps, profiles/r05/launch_variants_all.log):
 //   tuned ops (AffineOp, LutTableOp): lane-vectors per lane U in {1, 2, 4} (16-bit affine: {2, 4}) x cache policy
 //     NT in {1, 2}; window tiles of 4 lane-vectors, or 1 when the parameter window of a 4-wide tile would not fit LDS;
+//     lastaxis: two slabs per lane without a zero-point table, four with one (AffineOp), two for every other op;
+//     shortrows (AffineOp): {zero points or none} x {rows of whole lane-vectors or not} x NT;
 //   every other op (integer codes, export grid, literal scan, threshold lists): ONE variant per launch shape.
 // Experiments that were measured and not adopted (persistent blocks, the compact decision table, staging ablations) live
 // under tools/experiments/, outside the library.
@@ -1035,6 +1040,10 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict
 // lies in one row or crosses exactly one row boundary.  No LDS window, no block barrier: after the tile's data loads every
 // lane reads its own row's scale (and, where vectors can cross, the next row's) from the L1 / L2-resident tables -- all
 // table reads issued back to back -- and inverts it with recip_exact (wave-uniform fallback to the IEEE division).
+// (Why it also beats the per-tensor kernel on the same bytes -- 11.75 vs 12.2 us for 64 MiB in 16-bit storage -- is NOT understood:
+// stores grouped at the end, a wait for all loads, a start staggered by wave slot and an explicit 3 + 1 load stagger -- which
+// is what the compiler happens to emit here -- were each tried on flat / rows kernels and bought nothing or cost 3-5 %:
+// profiles/EXPERIMENTS.md, round 6.)
 // Measured against window_kernel (tools/experiments/chanlast2/, profiles/r06/chanlast2_a.log): bfloat16 16384 x 1020
 // 13.7 -> 12.5 us, 4096 x 4100 13.3 -> 12.3, 1048576 x 16 13.5 -> 13.0, float32 1048576 x 16 23.9 -> 22.1; whole-vector
 // 16-bit rows of 64 ... 2040 elements are equal or slower and stay with the window.  Reading the parameters BEFORE the data

@@ -5,8 +5,8 @@ both libraries loaded into ONE process and timed alternately (A B A B ...) on th
 a few short-row float32 shapes.  bench.py's protocol per arm: pre-warm 0.4 s, cold ring (> 512 MiB between two uses of a buffer),
 outputs kept, HIP events around 100 launches, best / median of 5.
 
-    python tools/build_variant.py batch_ieee -DMCTQ_BATCH_EXACT_RECIP=0 --units=mctq_batched.hip
-    python tools/batched_ab_probe.py [A.so] [B.so]        (defaults: the shipped library, tools/ablate/libmctq_hip_batch_ieee.so)"""
+    python tools/build_variant.py batch_exact -DMCTQ_BATCH_EXACT_RECIP=2 --units=mctq_batched.hip   (B arm: recip_exact in the list launches too)
+    python tools/batched_ab_probe.py [A.so] [B.so]        (defaults: the shipped library, tools/ablate/libmctq_hip_batch_exact.so)"""
 import ctypes, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,7 +16,7 @@ from mct_quantizers_amd import workloads
 from mct_quantizers_amd.hip import native
 
 paths = sys.argv[1:3] if len(sys.argv) >= 3 else [os.path.join(REPO, "mct_quantizers_amd", "lib", "libmctq_hip.so"),
-                                                    os.path.join(REPO, "tools", "ablate", "libmctq_hip_batch_ieee.so")]
+                                                    os.path.join(REPO, "tools", "ablate", "libmctq_hip_batch_exact.so")]
 libs = []
 P, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
 for p in paths:
