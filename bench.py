@@ -220,11 +220,25 @@ def event_timed(step, steps: int):
     return ef.elapsed_time(e1) * 1e3 / max(1, steps - 1), e0.elapsed_time(e1) * 1e3 / steps
 
 
+def own_stdout():
+    """The process's standard output carries ONE JSON line and nothing else: libraries that write to file descriptor 1 on their own
+    (RCCL prints "Librccl path : ..." through C stdio, flushed at exit, i.e. BEHIND the line) are sent to stderr for the whole run --
+    descriptor 1 is re-pointed at descriptor 2 and Python's sys.stdout at a private duplicate of the original."""
+    try:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real, "w", buffering=1)
+    except OSError:
+        pass
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (child process; nothing here has touched the GPU)
         sys.exit(bench_dist.self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+    own_stdout()                                     # (a rank, or the single process: never the launcher, whose children inherit)
     if args.e2e:
         if args.config != "resnet50" or args.gpus != 1:
             raise SystemExit("--e2e goes with --config resnet50 at --gpus 1")
@@ -260,7 +274,7 @@ def main():
     # which physical device every rank computes on (uuid | PCI address | name): a line that claims N GPUs shows N distinct ones
     wrapped = bool(os.environ.get("MCTQ_BENCH_WRAP_DEVICES")) and not dry
     rank_devs, devices_distinct = bench_dist.rank_devices(dist, control_plane, device)
-    if world > 1 and (wrapped or not devices_distinct) and not args.allow_gloo:
+    if world > 1 and (wrapped or devices_distinct is False) and not args.allow_gloo:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus}: the ranks do not sit on {args.gpus} distinct devices "
                   f"({'MCTQ_BENCH_WRAP_DEVICES is set; ' if wrapped else ''}rank_devices = {rank_devs}) and --allow-gloo was not "
@@ -448,7 +462,7 @@ def main():
         "n_gpus": world,
         "ranks_seen": ranks_seen,
         "rank_devices": rank_devs,                            # uuid | PCI domain:bus:device | name of every rank's device
-        "devices_distinct": devices_distinct and not wrapped,
+        "devices_distinct": False if wrapped else devices_distinct,   # null: the runtime reports neither a uuid nor a PCI address
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps,

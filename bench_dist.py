@@ -52,9 +52,20 @@ def device_identity(device: torch.device) -> str:
     if device.type != "cuda":
         return f"cpu|pid {os.getpid()}"
     p = torch.cuda.get_device_properties(device)
-    uuid = str(getattr(p, "uuid", "no-uuid"))
+    uuid = str(getattr(p, "uuid", "") or "")
+    if not uuid.strip("0-") or uuid.lower() in ("none", "no-uuid"):
+        uuid = "no-uuid"
     bus = "%04x:%02x:%02x" % (int(getattr(p, "pci_domain_id", 0)), int(getattr(p, "pci_bus_id", 0)), int(getattr(p, "pci_device_id", 0)))
     return f"{uuid}|{bus}|{p.name}"
+
+
+def identity_known(ident: str) -> bool:
+    """Does the string tell one device from another?  (A runtime that reports neither a uuid nor a PCI address leaves
+    ``no-uuid|0000:00:00|<name>``: equal strings then prove nothing, and the job must not be refused on them.)"""
+    parts = ident.split("|")
+    if len(parts) < 2 or parts[0] == "cpu":
+        return True
+    return parts[0] != "no-uuid" or parts[1] != "0000:00:00"
 
 
 def gather_strings(dist, text: str, control: Optional[str], device: torch.device, width: int = 256):
@@ -71,8 +82,10 @@ def gather_strings(dist, text: str, control: Optional[str], device: torch.device
 
 
 def rank_devices(dist, control: Optional[str], device: torch.device):
-    """(identities of every rank's device, are they pairwise distinct)."""
+    """(identities of every rank's device, are they pairwise distinct: True / False, or None when the runtime gives no identity)."""
     ids = gather_strings(dist, device_identity(device), control, device)
+    if not all(identity_known(i) for i in ids):
+        return ids, None
     return ids, len(set(ids)) == len(ids)
 
 

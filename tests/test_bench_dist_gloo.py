@@ -187,6 +187,9 @@ def _line(r):
     import json
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
+    # ONE JSON line and nothing else on standard output: what libraries print to descriptor 1 on their own (RCCL's "Librccl path"
+    # at exit, gloo's connection notes) goes to stderr (bench.py: own_stdout)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[-800:]
     return json.loads(lines[0])
 
 
@@ -200,6 +203,9 @@ def test_the_multi_rank_line_names_every_ranks_device_and_refuses_shared_ones():
     out = _line(_bench(base))
     assert len(out["rank_devices"]) == 2 and len(set(out["rank_devices"])) == 2 and out["devices_distinct"] is True
     assert all(d.startswith("cpu|pid ") for d in out["rank_devices"])
+    r = _bench(base, MCTQ_BENCH_FAKE_DEVICE_ID="no-uuid|0000:00:00|a runtime that reports no identity")
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert _line(r)["devices_distinct"] is None                      # unknown is not "shared": the job runs, the line says null
     r = _bench(base, MCTQ_BENCH_FAKE_DEVICE_ID="GPU-feed|0000:05:00|one device for both ranks")
     assert r.returncode != 0 and re.search(r"exitcode\s*:\s*8\b", r.stderr), (r.returncode, r.stderr[-1500:])
     assert "do not sit on 2 distinct devices" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -230,3 +236,6 @@ def test_device_identity_helpers():
     assert bench_dist.gather_strings(None, "abc", None, torch.device("cpu")) == ["abc"]
     ids, distinct = bench_dist.rank_devices(None, None, torch.device("cpu"))
     assert len(ids) == 1 and distinct is True
+    # a runtime without uuid and PCI address proves nothing either way: unknown, never a refusal
+    assert bench_dist.identity_known("GPU-1234|0000:05:00|MI355X") and bench_dist.identity_known("no-uuid|0000:05:00|MI355X")
+    assert not bench_dist.identity_known("no-uuid|0000:00:00|MI355X")
