@@ -89,6 +89,9 @@ def run(label, nb, make_call, ys_of):
 
 TQP = [("tqp", 4096, 4096), ("pt", 4096, 4096), ("tqp", 2048, 4096), ("pt", 2048, 4096), ("tqp", 1024, 4096), ("tqp", 64, 150528), ("pt", 64, 150528),
        ("tqp", 8, 150528), ("pt", 8, 150528)]
+SMALL = [("pc0", 128, 4096), ("pc0", 256, 4096), ("pc0", 512, 4096), ("pc0", 1024, 4096), ("pc0", 1536, 4096), ("pc0", 2048, 4096), ("pc0", 3072, 4096),
+         ("pc0", 512, 4608), ("pc0", 64, 65536), ("pc0", 16, 262144), ("pc0", 4, 1048576), ("pc0", 3, 1605632), ("pc0", 8, 2097152), ("pc0", 32, 524288),
+         ("pc0", 4096, 256), ("pc0", 16384, 64), ("pc0", 1024, 1024), ("pc0", 256, 1020), ("pc0", 65536, 16), ("pc0", 8192, 1020), ("pc0", 300, 576)]
 ROUNDS = [("pc0", 8192, 2048), ("pc0", 6144, 4096), ("pc0", 8192, 4096), ("pc0", 12288, 4096), ("pc0", 16384, 4096), ("pc0", 4096, 2048),
           ("pc0", 2048, 3072), ("pc0", 1024, 4096), ("pc0", 512, 4096)]
 
@@ -153,6 +156,8 @@ for c in args.cases.split(","):
     elif c == "affine32": affine_cases(["f32"])
     elif c == "tqp16": affine_cases(["bf16", "f16"], TQP)
     elif c == "tqp32": affine_cases(["f32"], TQP)
+    elif c == "small16": affine_cases(["bf16"], SMALL)
+    elif c == "small32": affine_cases(["f32"], SMALL)
     elif c == "rounds16": affine_cases(["bf16"], ROUNDS)
     elif c == "rounds32": affine_cases(["f32"], ROUNDS)
     elif c == "lut16": lut16_cases()
