@@ -484,7 +484,7 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
  *   key "shortrows" : affine per-channel tensors through shortrows_kernel (per-lane parameter reads behind the tile's data loads,
  *                  no LDS window): 0 = never, 1 (default) = where it measured faster (16-bit storage: every short or ragged row
- *                  shape, and long rows while the launch is at most one round of resident blocks; float32: rows of 4 ... 31
+ *                  shape, and long rows of launches that fill 7/8 ... 1 round of resident blocks; float32: rows of 4 ... 31
  *                  elements), 2 = every eligible tensor (rows of at least one lane-vector, fewer than 2^24 elements per row)
  * Only variants a default dispatcher can select are instantiated; every value of every key is exercised by the GPU tests.
  * Returns 0, or MCTQ_E_ARG for an unknown key/value.  Numerical results never depend on it.

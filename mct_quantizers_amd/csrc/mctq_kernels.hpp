@@ -1413,17 +1413,21 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
   // ab_shortrows3.log, sweep_routes_b.log; A / B in one process): 16-bit tensors -- 4-9 % faster than window_kernel on EVERY
   // short- or ragged-row shape (16384 x 1024 12.6 -> 11.8 us, 1048576 x 16 13.6 -> 12.3, 50257 x 768 28.1 -> 26.8, 16384 x 1020
   // 13.6 -> 12.9), and 2-14 % faster than rows_kernel / rowsteps_kernel on long rows while the launch is at most ONE round of
-  // resident blocks (4096^2 12.0 -> 11.75, 256 x 65536 12.45 -> 11.8, 2048 x 4608 10.1 -> 8.65) but 3 % slower on several
-  // rounds (8192^2 42.0 -> 43.2); float32 -- equal to the gather launch and to rows_kernel within 1 % everywhere, so only
-  // the rows the gather launch does not take (4 ... 31 elements: 23.9 -> 22.2 us) come here.
+  // resident blocks and at least 7/8 of one (4096^2 12.0 -> 11.75, 256 x 65536 12.45 -> 11.8) but 3-6 % slower on several
+  // rounds (8192^2 42.0 -> 43.2) and 4-28 % slower on fractions of a round (2048 x 4096 6.9 -> 7.9); float32 -- equal to the
+  // gather launch and to rows_kernel within 1 % everywhere, so only the rows the gather launch does not take (4 ... 31
+  // elements: 23.9 -> 22.2 us) come here.
   if constexpr (std::is_same<Op, AffineOp>::value && std::is_same<TI, TO>::value) {
     constexpr int64_t TILE = (int64_t)kThreads * 4 * io::N;
     // (channels > 1: a per-tensor launch through this kernel is equal at 64 MiB and 13-23 % slower below, profiles/r06/ab_tqp.log)
     const bool eligible = vec_ok && inner >= io::N && channels > 1 && n < (1ll << 32) - TILE && inner + TILE < (1 << 24) &&
                           channels + TILE < (1 << 24);
     const bool long_rows = inner % io::N == 0 && inner / io::N >= kThreads;
-    const bool one_round = (n + TILE - 1) / TILE <= 8LL * cu_count();
-    // (a FORCED rowsteps_kernel -- tuning key "rowsteps" = 1 -- keeps its long rows)
+    // (long rows: only a launch of 7/8 ... 1 round -- below that rows_kernel / rowsteps_kernel win by 4-28 %: 3072 x 4096 +4 %,
+    // 2048 x 4096 +16 %, 1024 x 4096 +28 %, 64 x 65536 +23 %, profiles/r06/ab_small.log; short and ragged rows at every size:
+    // 4096 x 256 -8 %, 65536 x 16 -14 %.  A FORCED rowsteps_kernel -- tuning key "rowsteps" = 1 -- keeps its long rows.)
+    const int64_t sr_blocks = (n + TILE - 1) / TILE, round = 8LL * cu_count();
+    const bool one_round = sr_blocks <= round && sr_blocks * 8 > round * 7;
     const bool rule = sizeof(TI) == 2 ? (!long_rows || (one_round && g_rowsteps != 1)) : (!long_rows && inner < 32);
     if (eligible && (g_shortrows == 2 || (g_shortrows == 1 && rule))) {
       const bool whole = inner % io::N == 0;
