@@ -21,7 +21,7 @@
 //                 tensor slab by slab; parameters by 16-byte loads from the L1/L2-resident tables once per lane,
 //                 inverted by a five-instruction exact reciprocal.
 //   shortrows     (affine ops) rows shorter than a tile but at least one lane-vector long, and long 16-bit rows of
-//                 launches that fit one round of resident blocks: one block = one contiguous tile; every lane-vector
+//                 launches that fill 7/8 ... 1 round of resident blocks: one block = one contiguous tile; every lane-vector
 //                 reads its own row's scale behind the tile's data loads -- no LDS, no barrier.
 //   window        what is left (rows shorter than a lane-vector, unaligned tensors, > 2^32 elements, the non-affine
 //                 ops' short rows): one block = one contiguous tile; the parameters of the rows that tile touches are
