@@ -394,7 +394,7 @@ static int launch_lastaxis2(int mode, int u_sel, int loops, const void* xv, void
 // ORDER 1: parameter reads first (they return first), reciprocals under the data loads' latency.
 // ------------------------------------------------------------------------------------------------------------------
 template <class TI, int U, int NT, int ORDER, int RECIP, bool HASZP, bool SAMEROW>
-__global__ __launch_bounds__(kThreads) void shortrows_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n,
+__global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n,
                                                              uint32_t inner, uint32_t channels, float r_inner, float r_channels,
                                                              uint32_t sh, float lo, float hi, const float* __restrict__ scales,
                                                              const int32_t* __restrict__ zps) {
@@ -517,7 +517,7 @@ static int launch_shortrows(int mode, const void* xv, void* yv, int64_t rows, in
   if ((inner & (inner - 1)) == 0) { sh = 0; while ((1ll << sh) < inner) ++sh; }
   const bool same = inner % io::N == 0;
   const float ri = 1.0f / (float)inner, rc = 1.0f / (float)channels, lo = (float)qmin, hi = (float)qmax;
-#define SR(NT_, O_, R_, Z_, S_) hipLaunchKernelGGL((shortrows_kernel<TI, U, NT_, O_, R_, Z_, S_>), dim3(grid), dim3(kThreads), 0, st, x, y, \
+#define SR(NT_, O_, R_, Z_, S_) hipLaunchKernelGGL((shortrows_x_kernel<TI, U, NT_, O_, R_, Z_, S_>), dim3(grid), dim3(kThreads), 0, st, x, y, \
                                                     (uint32_t)n, (uint32_t)inner, (uint32_t)channels, ri, rc, sh, lo, hi, scales, zps)
 #define BY_S(...) do { if (same) { constexpr bool S = true; __VA_ARGS__; } else { constexpr bool S = false; __VA_ARGS__; } } while (0)
   switch (mode) {

@@ -65,7 +65,7 @@ with open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w") as f:
 # stall counters of the headline kernel and of the batched launch -> one table each
 for cfg, needle, fname in (("cfg2", "rows_kernel", "cfg2_rows_kernel_stall_counters.csv"),
                            ("cfg2_batched16", "batched_table_kernel", "cfg2_batched16_table_kernel_stall_counters.csv"),
-                           ("cfg2_bf16", "rowsteps_kernel", "cfg2_bf16_rowsteps_kernel_stall_counters.csv"),
+                           ("cfg2_bf16", "shortrows_kernel", "cfg2_bf16_shortrows_kernel_stall_counters.csv"),
                            ("sym_4096x4096_axis1_bf16", "lastaxis_kernel", "sym_4096x4096_axis1_bf16_lastaxis_kernel_stall_counters.csv"),
                            ("sym_65536x200_axis1_bf16", "lastaxis_kernel", "sym_65536x200_axis1_bf16_lastaxis_kernel_stall_counters.csv"),
                            ("sym_16384x1020_axis0_bf16", "shortrows_kernel", "sym_16384x1020_axis0_bf16_shortrows_kernel_stall_counters.csv"),
