@@ -324,6 +324,92 @@ __global__ __launch_bounds__(kThreads) void lastaxis3_kernel(const TI* __restric
     if (full || b0 + u * kThreads + threadIdx.x < n_lv) io::template store<NT>(ys + ((size_t)b0 + u * kThreads + threadIdx.x) * N, r[u]);
 }
 
+// lastaxis4: contiguous tiles as lastaxis3, for row lengths that make a lane's columns REPEAT across its U vectors: 256 % vc == 0 (one column
+// for all U vectors: SETS = 1) or vc == 512 (columns alternate: SETS = 2).  The table traffic per byte of data is then that of the slab
+// kernel (N scales per lane and SETS), the reads are one contiguous 16 KiB piece per block on a 1-D grid, as in shortrows_kernel.
+template <class TI, int NT, bool HASZP, int SETS>
+__global__ __launch_bounds__(kThreads) void lastaxis4_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n_lv,
+                                                             uint32_t vc, float lo, float hi,
+                                                             const float* __restrict__ scales, const int32_t* __restrict__ zps) {
+  typedef IO<TI, TI> io;
+  constexpr int N = io::N, U = 4;
+  typedef typename io::VI VI;
+  const uint32_t b0 = blockIdx.x * (U * kThreads);
+  const bool full = b0 + U * kThreads <= n_lv;
+  VI v[U];
+  if (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads + threadIdx.x);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (b0 + u * kThreads + threadIdx.x < n_lv) v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads + threadIdx.x);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // b0 is a multiple of 1024 lane-vectors: with 256 % vc == 0 or vc == 512 it is a multiple of vc as well
+  float s[SETS][N], inv[SETS][N], zf[SETS][N];
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  float all[SETS * N];
+#pragma unroll
+  for (int k = 0; k < SETS; ++k) {
+    const uint32_t c = SETS == 1 ? (threadIdx.x & (vc - 1)) : threadIdx.x + k * kThreads;     // vc a power of two (256 % vc == 0)
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(scales + (size_t)c * N + j);
+      i32x4 z4 = {0, 0, 0, 0};
+      if (HASZP) z4 = *reinterpret_cast<const i32x4*>(zps + (size_t)c * N + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[k][j + i] = s4[i]; all[k * N + j + i] = s4[i]; zf[k][j + i] = HASZP ? (float)z4[i] : 0.0f; }
+    }
+  }
+  const bool exact = __builtin_amdgcn_ballot_w64(!recip_all_ok(all)) == 0;
+#pragma unroll
+  for (int k = 0; k < SETS; ++k)
+#pragma unroll
+    for (int j = 0; j < N; ++j) inv[k][j] = exact ? recip_nr2(s[k][j]) : 1.0f / s[k][j];
+  VI r[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (!full && b0 + u * kThreads + threadIdx.x >= n_lv) continue;
+    constexpr int dummy = 0; (void)dummy;
+    const int k = SETS == 1 ? 0 : (u & 1);
+    float in[N], out[N];
+    io::unpack(v[u], in);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float q = __builtin_amdgcn_fmed3f(__builtin_rintf(in[j] * inv[k][j]), lo - zf[k][j], hi - zf[k][j]);
+      float y = __builtin_fmaf(q, s[k][j], 0.0f);
+      asm("" : "+v"(y));
+      out[j] = y;
+    }
+    r[u] = io::pack(out);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (full || b0 + u * kThreads + threadIdx.x < n_lv) io::template store<NT>(ys + ((size_t)b0 + u * kThreads + threadIdx.x) * N, r[u]);
+}
+
+template <class TI>
+static int launch_lastaxis4(const void* xv, void* yv, int64_t rows, int64_t channels, const float* scales, const int32_t* zps,
+                            int32_t qmin, int32_t qmax, int nt, hipStream_t st) {
+  typedef IO<TI, TI> io;
+  const TI* x = static_cast<const TI*>(xv);
+  TI* y = static_cast<TI*>(yv);
+  if (channels % io::N) return fail_arg("channels % N");
+  const int64_t vc = channels / io::N, n_lv = rows * vc;
+  const int sets = (vc <= 256 && 256 % vc == 0) ? 1 : (vc == 512 ? 2 : 0);
+  if (!sets) return fail_arg("row length does not repeat over a tile");
+  if (n_lv >= (1ll << 32) - 2048) return fail_arg("too large for the experiment");
+  const float lo = (float)qmin, hi = (float)qmax;
+  const unsigned grid = (unsigned)((n_lv + 4 * kThreads - 1) / (4 * kThreads));
+#define LA4(NT_, Z_, S_) hipLaunchKernelGGL((lastaxis4_kernel<TI, NT_, Z_, S_>), dim3(grid), dim3(kThreads), 0, st, x, y, (uint32_t)n_lv, \
+                                             (uint32_t)vc, lo, hi, scales, zps)
+  if (sets == 1) { if (nt == 2) { if (zps) LA4(2, true, 1); else LA4(2, false, 1); } else { if (zps) LA4(1, true, 1); else LA4(1, false, 1); } }
+  else { if (nt == 2) { if (zps) LA4(2, true, 2); else LA4(2, false, 2); } else { if (zps) LA4(1, true, 2); else LA4(1, false, 2); } }
+  return check_launch("lastaxis4");
+}
+
 template <class TI>
 static int launch_lastaxis3(int u_sel, const void* xv, void* yv, int64_t rows, int64_t channels, const float* scales,
                             const int32_t* zps, int32_t qmin, int32_t qmax, int nt, hipStream_t st) {
@@ -546,6 +632,14 @@ extern "C" int mctq_x_lastaxis(int32_t mode, int32_t u, int32_t loops, const voi
                                void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (loops < 1) loops = 1;
+  if (mode == 22) {                                      // contiguous tiles, repeating columns (lastaxis4)
+    switch (dtype) {
+      case MCTQ_DT_F32: return launch_lastaxis4<float>(x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      case MCTQ_DT_F16: return launch_lastaxis4<_Float16>(x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      case MCTQ_DT_BF16: return launch_lastaxis4<__bf16>(x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      default: return fail_arg("dtype");
+    }
+  }
   if (mode == 21) {                                      // contiguous tiles (lastaxis3)
     switch (dtype) {
       case MCTQ_DT_F32: return launch_lastaxis3<float>(u, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);

@@ -78,7 +78,7 @@ def run_case(label, nb, ring, xs, lib_call, modes):
         ys = [torch.empty_like(x) for x in xs]
         rc = fn(0, ys)
         if rc != 0:
-            cells.append(f"{name} rc={rc}")
+            cells.append(f"{name} n/a")
             continue
         torch.cuda.synchronize()
         same = torch.equal(ys[0].view(torch.int16 if ys[0].element_size() == 2 else torch.int32),
@@ -108,7 +108,8 @@ if "lastaxis" in what:
             return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, loops, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
                                                       s.data_ptr(), zp, -128, 127, nt, stream)
         if "contig" in what:
-            modes = [("slab U2", mk(2, 2, 1), True), ("slab U4", mk(2, 4, 1), True), ("contig U2", mk(21, 2, 1), True), ("contig U4", mk(21, 4, 1), True)]
+            modes = [("slab U2", mk(2, 2, 1), True), ("slab U4", mk(2, 4, 1), True), ("contig U2", mk(21, 2, 1), True), ("contig U4", mk(21, 4, 1), True),
+                     ("contig repeat", mk(22, 4, 1), True)]
         elif "sched" in what:
             def mkn(mode, u, ntx):
                 return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, 1, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
