@@ -1546,6 +1546,10 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
           if constexpr (std::is_same<Op, AffineOp>::value) {
             if (zp4) MCTQ_LASTAXIS(4, NT, true);
             else MCTQ_LASTAXIS(2, NT, false);
+          } else if constexpr (std::is_base_of<AffineOp, Op>::value) {
+            // (the integer-code op: its zero-point table may be NULL as well -- the ZP = true form reads it unconditionally)
+            if (has_zero_points(op)) MCTQ_LASTAXIS(2, NT, true);
+            else MCTQ_LASTAXIS(2, NT, false);
           } else {
             MCTQ_LASTAXIS(2, NT, true);
           }

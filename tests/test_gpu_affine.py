@@ -558,3 +558,30 @@ def test_a_tensor_above_the_launch_limit_of_the_short_row_kernels_is_cut_into_ro
         assert torch.equal(ops.grid_per_channel(x, -s * 100, s * 100, s, 1), want_grid)
         got = lut(xcl)
         assert torch.equal(got, want_lut_cl) and got.is_contiguous()
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+def test_integer_codes_channel_last_without_a_zero_point_table(lib, dt):
+    """mctq_fq_codes_per_channel with zero_points == NULL (all zero) on a channel-last layout: the channel-last kernel's variant
+    without a zero-point table -- the ZP form reads the table unconditionally and must not be launched with a NULL one."""
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(12)
+    code = {"float32": 0, "bfloat16": 2}[dt]
+    rows, C = 777, 4096
+    scales = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+    zps = np.zeros(C, dtype=np.int32)
+    x32 = _tie_heavy_r6(rng, (rows, C, 1), scales.reshape(1, C, 1), np.float32(0), -128, 127).reshape(rows, C)
+    xh = _dev(x32).to(getattr(torch, dt))
+    x_np = xh.float().cpu().numpy()
+    want = O.fake_quant_affine(x_np, scales, zps, -128, 127, axis=1, return_index=True)[1]
+    s_d = _dev(scales)
+    for zp_ptr in (None, _dev(zps)):
+        codes = torch.full((rows, C), 99, dtype=torch.int8, device="cuda")
+        rc = lib.mctq_fq_codes_per_channel(xh.data_ptr(), codes.data_ptr(), rows, C, 1, code, 0, s_d.data_ptr(),
+                                           zp_ptr.data_ptr() if zp_ptr is not None else None, -128, 127, _stream())
+        assert rc == 0, lib.mctq_last_error()
+        torch.cuda.synchronize()
+        from mct_quantizers_amd.hip import native
+        assert native.last_launch().startswith("lastaxis_kernel<AffineCodesOp"), native.last_launch()
+        m = np.isfinite(x_np)
+        assert np.array_equal(codes.cpu().numpy().astype(np.int64)[m], want[m])
