@@ -1106,7 +1106,11 @@ __global__ __launch_bounds__(kThreads) void shortrows_kernel(const TI* __restric
     if (full || off + N <= count) {
       float in[N], out[N];
       io::unpack(v[u], in);
-      if (WHOLE || split[u] >= N) {
+      // Wave-uniform test: a wave with a crossing vector runs the per-element selection for ALL its lanes (lanes whose vector
+      // lies in one row select their own set throughout) instead of both forms one after the other -- 16384 x 1020 bfloat16
+      // 13.0 -> 12.67 us, 65536 x 252 -7.6 %, 131072 x 100 -5.8 % (profiles/r06/ab_sr1.log).  Taking the next row's parameters
+      // from the neighbouring lane by a shuffle instead of a table read was 0.5-5 % slower (ab_sr2.log).
+      if (WHOLE || __builtin_amdgcn_ballot_w64(split[u] < N) == 0) {
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], pa, NoBook());
       } else {

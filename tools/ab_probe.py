@@ -92,6 +92,8 @@ TQP = [("tqp", 4096, 4096), ("pt", 4096, 4096), ("tqp", 2048, 4096), ("pt", 2048
 SMALL = [("pc0", 128, 4096), ("pc0", 256, 4096), ("pc0", 512, 4096), ("pc0", 1024, 4096), ("pc0", 1536, 4096), ("pc0", 2048, 4096), ("pc0", 3072, 4096),
          ("pc0", 512, 4608), ("pc0", 64, 65536), ("pc0", 16, 262144), ("pc0", 4, 1048576), ("pc0", 3, 1605632), ("pc0", 8, 2097152), ("pc0", 32, 524288),
          ("pc0", 4096, 256), ("pc0", 16384, 64), ("pc0", 1024, 1024), ("pc0", 256, 1020), ("pc0", 65536, 16), ("pc0", 8192, 1020), ("pc0", 300, 576)]
+RAGGED = [("pc0", 16384, 1020), ("pc0", 4096, 4100), ("pc0", 4096, 4099), ("pc0", 8192, 1020), ("pc0", 65536, 252), ("pc0", 32768, 516), ("pc0", 2048, 8190),
+          ("pc0", 131072, 100), ("pc0", 1048576, 12), ("pc0", 50257, 772), ("pc0", 300, 1020), ("pc0", 16384, 1024)]
 ROUNDS = [("pc0", 8192, 2048), ("pc0", 6144, 4096), ("pc0", 8192, 4096), ("pc0", 12288, 4096), ("pc0", 16384, 4096), ("pc0", 4096, 2048),
           ("pc0", 2048, 3072), ("pc0", 1024, 4096), ("pc0", 512, 4096)]
 
@@ -158,6 +160,8 @@ for c in args.cases.split(","):
     elif c == "tqp32": affine_cases(["f32"], TQP)
     elif c == "small16": affine_cases(["bf16"], SMALL)
     elif c == "small32": affine_cases(["f32"], SMALL)
+    elif c == "ragged16": affine_cases(["bf16", "f16"], RAGGED)
+    elif c == "ragged32": affine_cases(["f32"], [("pc0", 1048576, 13), ("pc0", 2097152, 7), ("pc0", 1048576, 16)])
     elif c == "rounds16": affine_cases(["bf16"], ROUNDS)
     elif c == "rounds32": affine_cases(["f32"], ROUNDS)
     elif c == "lut16": lut16_cases()
