@@ -255,7 +255,11 @@ def main():
         args.config, args.batched, args.graph, args.streams, args.extras = "cfg1", 0, False, 1, False
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU"
-        if os.environ.get("MCTQ_BENCH_WRAP_DEVICES"):        # rehearsal of the N > 1 path on fewer GPUs than ranks (tests)
+        # fewer visible devices than LOCAL_RANK + 1: either the rehearsal of the N > 1 path on one GPU (tests set
+        # MCTQ_BENCH_WRAP_DEVICES) or a launcher that gave every rank its own HIP_VISIBLE_DEVICES -- told apart below by the
+        # physical identities the ranks exchange, never assumed
+        implicit_wrap = local_rank >= torch.cuda.device_count()
+        if os.environ.get("MCTQ_BENCH_WRAP_DEVICES") or implicit_wrap:
             local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
@@ -274,6 +278,8 @@ def main():
     # which physical device every rank computes on (uuid | PCI address | name): a line that claims N GPUs shows N distinct ones
     wrapped = bool(os.environ.get("MCTQ_BENCH_WRAP_DEVICES")) and not dry
     rank_devs, devices_distinct = bench_dist.rank_devices(dist, control_plane, device)
+    if not dry and implicit_wrap and devices_distinct is not True:
+        wrapped = True                                # LOCAL_RANK beyond the visible devices and no proof of distinct ones
     if world > 1 and (wrapped or devices_distinct is False) and not args.allow_gloo:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus}: the ranks do not sit on {args.gpus} distinct devices "

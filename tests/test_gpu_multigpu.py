@@ -101,13 +101,14 @@ def test_dim0_shards_reassemble_to_the_reference_digest_of_config_5(lib, world):
     assert covered == rows and h.hexdigest() == rec["y_sha256"]
 
 
-def _bench_wrapped(n, *flags, env_extra=None, timeout=1500):
+def _bench_wrapped(n, *flags, env_extra=None, timeout=1500, wrap_env=True):
     """`python bench.py --gpus n` with no launcher and no RANK, all ranks sharing the box's one GPU."""
     import subprocess
     import sys
     from conftest import REPO
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MCTQ_BENCH_WRAP_DEVICES="1", **(env_extra or {}))
+    env.pop("MCTQ_BENCH_WRAP_DEVICES", None)
+    env.update(**({"MCTQ_BENCH_WRAP_DEVICES": "1"} if wrap_env else {}), **(env_extra or {}))
     return subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "20", "--warmup", "5", "--prewarm-seconds", "0.1",
                            "--evidence-launches", "0", *flags], cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -145,6 +146,21 @@ def test_plain_python_bench_gpus_2_on_the_gpu_box():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     _check_self_verifying_line(json.loads(lines[0]), 2)
+
+
+def test_local_rank_beyond_the_visible_devices_is_judged_by_identity():
+    """A launcher that hands every rank its own HIP_VISIBLE_DEVICES leaves LOCAL_RANK >= device_count(): the rank then takes
+    device LOCAL_RANK % count and the exchanged identities decide.  Here (one GPU, no MCTQ_BENCH_WRAP_DEVICES) both ranks
+    land on the same device: the line says so (devices_distinct false, two equal rank_devices) instead of the job dying on
+    an invalid device ordinal."""
+    r = _bench_wrapped(2, "--cpu-seconds", "1", "--allow-gloo", "--no-sharded-extra", env_extra={"MCTQ_BENCH_FORCE_GLOO": "1"},
+                       wrap_env=False)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["devices_distinct"] is False and len(d["rank_devices"]) == 2 and d["rank_devices"][0] == d["rank_devices"][1]
+    assert d["ranks_parity_ok"] == [True, True]
 
 
 def test_eight_ranks_rehearsed_on_the_one_gpu():
