@@ -522,6 +522,55 @@ def test_channel_last_and_short_row_launches_vs_oracle(lib, dt, with_zp):
     assert {"lastaxis_kernel", "shortrows_kernel"} <= seen, seen
 
 
+def test_fuzz_channel_last_and_short_row_launch_geometry_vs_oracle(lib):
+    """Seeded fuzz of the round-6 launch geometry through the C ABI: random (outer, C, inner) with inner drawn around the
+    lane-vector and tile sizes (1, below a vector, whole vectors, one past / one short of them, rows longer than a tile), C from 1
+    to tens of thousands, the three storage types, with and without a zero-point table, every "shortrows" route -- bit for bit
+    against the oracle.  MCTQ_FUZZ_SEED / MCTQ_FUZZ_CASES widen it for the soak runs."""
+    import os
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "606")))
+    inners = [1, 1, 1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 20, 24, 31, 32, 33, 40, 63, 64, 65, 100, 127, 128, 200, 252, 255, 256, 257,
+              500, 511, 512, 516, 1000, 1020, 1023, 1024, 1025, 1032, 2047, 2048, 2056, 4095, 4096, 4100, 8200, 16385]
+    seen = set()
+    try:
+        for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "150"))):
+            inner = int(rng.choice(inners))
+            C = int(rng.choice([1, 2, 3, 5, 7, 8, 13, 16, 31, 64, 100, 200, 255, 256, 768, 1000, 2048, 4096, 4104, 20480, 70001]))
+            budget = 1 << int(rng.integers(10, 22))              # elements: a handful of waves ... a few rounds of blocks
+            outer = max(1, min(int(rng.integers(1, 9)) if rng.random() < 0.5 else 1 << 20, budget // max(1, C * inner)))
+            if outer * C * inner > (1 << 23):
+                continue
+            dt = ["float32", "float16", "bfloat16"][int(rng.integers(0, 3))]
+            code, tdt = {"float32": 0, "float16": 1, "bfloat16": 2}[dt], getattr(torch, dt)
+            with_zp = bool(rng.integers(0, 2))
+            route = 1 if dt == "float32" and rng.random() < 0.5 else int(rng.integers(0, 3))
+            native.set_tuning("shortrows", route)
+            qmin, qmax = [(-8, 7), (-128, 127), (0, 255), (0, 3)][int(rng.integers(0, 4))]
+            scales = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+            if rng.random() < 0.3:                                # some divisors outside recip_exact's range
+                scales[:: int(rng.integers(1, 120))] = np.float32(3e-33)
+                scales[int(rng.integers(0, C)):: int(rng.integers(1, 250))] = np.float32(2e31)
+            zps = rng.integers(-5, 6, size=C).astype(np.int32) if with_zp else np.zeros(C, dtype=np.int32)
+            shape = (outer, C, inner)
+            x32 = _tie_heavy_r6(rng, shape, scales.reshape(1, C, 1), zps.reshape(1, C, 1).astype(np.float32), qmin, qmax)
+            xh = _dev(x32).to(tdt)
+            x_np = xh.float().cpu().numpy()
+            y = torch.full_like(xh, 300.0)
+            s_d, z_d = _dev(scales), _dev(zps)
+            rc = lib.mctq_fq_per_channel(xh.data_ptr(), y.data_ptr(), outer, C, inner, code, s_d.data_ptr(),
+                                         z_d.data_ptr() if with_zp else None, qmin, qmax, _stream())
+            assert rc == 0, lib.mctq_last_error()
+            seen.add(native.last_launch().split("<")[0])
+            want = O.narrow(O.fake_quant_affine(x_np, scales, zps, qmin, qmax, axis=1), dt)
+            got = y.float().cpu().numpy()
+            assert finite_equal(got, want, x_np), (case, shape, dt, with_zp, route, native.last_launch(), first_mismatch(got, want, x_np))
+    finally:
+        native.set_tuning("shortrows", 1)
+    assert {"lastaxis_kernel", "shortrows_kernel", "rows_kernel"} <= seen, seen
+
+
 def _tie_heavy_r6(rng, shape, s_b, zp_b, qmin, qmax):
     n = int(np.prod(shape))
     with np.errstate(all="ignore"):
