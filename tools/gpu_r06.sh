@@ -59,4 +59,16 @@ sweep() {         # tools/sweep_shapes.py with the round-6 protocol (the three s
   timeout 900 python tools/sweep_shapes.py --dtypes f32,bf16,f16 > $O/sweep_shapes.log 2>&1; grep -c . $O/sweep_shapes.log; grep "spread >" $O/sweep_shapes.log | head
 }
 
+modes() {         # the GPU suite through the other binding / with roctx ranges, and the seeded fuzz suites on further seeds
+  MCTQ_BINDING=ctypes timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu_ctypes.log 2>&1; echo "rc=$?" >> $O/pytest_gpu_ctypes.log; tail -2 $O/pytest_gpu_ctypes.log
+  MCTQ_ROCTX=1 timeout 1800 python -m pytest tests -m gpu -q -k "not every_float and not 2_32" > $O/pytest_gpu_roctx.log 2>&1; echo "rc=$?" >> $O/pytest_gpu_roctx.log; tail -2 $O/pytest_gpu_roctx.log
+  MCTQ_ROUND=r06 SEEDS="${SEEDS:-55 56 57 58}" bash tools/gpu_fuzz_soak.sh
+}
+
+e2e() {           # bench.py --config resnet50 --e2e at the final build
+  timeout 600 python bench.py --config resnet50 --e2e --steps 100 2>$O/e2e.err | tail -1 > $O/bench_e2e_resnet50.json
+  python -c "
+import json; d=json.load(open('$O/bench_e2e_resnet50.json')); print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k in ('value', 'ms_per_step') or k.startswith('ms_')})" 2>/dev/null || head -c 600 $O/bench_e2e_resnet50.json
+}
+
 for s in "$@"; do $s; done
