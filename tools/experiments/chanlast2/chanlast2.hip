@@ -475,6 +475,152 @@ static int launch_lastaxis2(int mode, int u_sel, int loops, const void* xv, void
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// lastaxis5: the parameter table SHARED by the block's four waves through LDS.  The slab kernel's lanes each read their N scales
+// from the table (N * 4 bytes per lane and U rows: as many L1 accesses as a row of data); here a block is ONE 64-lane piece of
+// the slab x (4 waves x U slabs): the four waves own the same columns in different slabs, the piece's 64 * N scales are read from
+// memory once per block (threads 0 .. 64*N/4-1, 16 bytes each) into LDS, every lane takes its N from there.  PREINV: the loader
+// threads also invert (one reciprocal per scale and block instead of one per scale and wave).
+// Grid (pieces of 64 lane-vectors per slab, groups of 4 * U slabs).
+// ------------------------------------------------------------------------------------------------------------------
+template <class TI, int U, int NT, bool HASZP, bool PREINV>
+__global__ __launch_bounds__(kThreads) void lastaxis5_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint64_t rows,
+                                                             uint32_t vc, uint32_t k, float rvc, float lo, float hi,
+                                                             uint32_t groups, const float* __restrict__ scales,
+                                                             const int32_t* __restrict__ zps) {
+  typedef IO<TI, TI> io;
+  constexpr int N = io::N, Q = N / 4, W = kThreads / 64;
+  typedef typename io::VI VI;
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  __shared__ f32x4 sh_s[Q][64];
+  __shared__ f32x4 sh_inv[PREINV ? Q : 1][64];
+  __shared__ i32x4 sh_z[HASZP ? Q : 1][64];
+  const uint32_t slab = k * vc;
+  const uint32_t group = blockIdx.y + blockIdx.z * gridDim.y;
+  if (group >= groups) return;                                     // (the whole block)
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x * 64 + lane;
+  const uint64_t grow0 = (uint64_t)group * (uint32_t)(W * U * k);
+  const uint64_t rows_left = rows - grow0;
+  const VI* px = reinterpret_cast<const VI*>(xs + grow0 * vc * N) + g;
+  VI* py = reinterpret_cast<VI*>(ys + grow0 * vc * N) + g;
+  uint32_t lim[U], si[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    si[u] = u * W + wave;                                          // adjacent waves: adjacent slabs
+    const uint64_t r = rows_left > (uint64_t)si[u] * k ? rows_left - (uint64_t)si[u] * k : 0;
+    lim[u] = (r >= k ? k : (uint32_t)r) * vc;
+  }
+  VI v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (g < lim[u]) v[u] = __builtin_nontemporal_load(px + (size_t)si[u] * slab);
+  __builtin_amdgcn_sched_barrier(0);
+  // the piece's table -> LDS
+  {
+    const uint32_t t = threadIdx.x;
+    const bool zpart = HASZP && t >= 64 * Q && t < 128 * Q;
+    const uint32_t tt = zpart ? t - 64 * Q : t;
+    const uint32_t L = tt / Q, h = tt % Q;
+    const uint32_t gl = blockIdx.x * 64 + L;
+    if (tt < 64 * Q && (t < 64 * Q || zpart) && gl < slab) {
+      const uint32_t col = gl - div_small(gl, vc, rvc) * vc;
+      if (zpart) {
+        sh_z[h][L] = *reinterpret_cast<const i32x4*>(zps + (size_t)col * N + 4 * h);
+      } else {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(scales + (size_t)col * N + 4 * h);
+        sh_s[h][L] = s4;
+        if (PREINV) {
+          float sv[4] = {s4[0], s4[1], s4[2], s4[3]};
+          const bool ok = recip_all_ok(sv);
+          f32x4 i4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) i4[i] = ok ? recip_nr2(sv[i]) : 1.0f / sv[i];
+          sh_inv[h][L] = i4;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float s[N], inv[N], blo[N], bhi[N];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const f32x4 s4 = sh_s[q][lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[4 * q + i] = s4[i];
+    if (PREINV) {
+      const f32x4 i4 = sh_inv[q][lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) inv[4 * q + i] = i4[i];
+    }
+    if (HASZP) {
+      const i32x4 z4 = sh_z[q][lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float zf = (float)z4[i]; blo[4 * q + i] = lo - zf; bhi[4 * q + i] = hi - zf; }
+    }
+  }
+  if (!PREINV) {
+    const bool ok = g < slab ? recip_all_ok(s) : true;
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) inv[j] = recip_nr2(s[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) inv[j] = 1.0f / s[j];
+    }
+  }
+  VI res[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (g < lim[u]) {
+      float in[N], out[N];
+      io::unpack(v[u], in);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float r = __builtin_rintf(in[j] * inv[j]);
+        const float q = HASZP ? __builtin_amdgcn_fmed3f(r, blo[j], bhi[j]) : __builtin_amdgcn_fmed3f(r, lo, hi);
+        float y = __builtin_fmaf(q, s[j], 0.0f);
+        asm("" : "+v"(y));
+        out[j] = y;
+      }
+      res[u] = io::pack(out);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (g < lim[u]) io::template store<NT>(reinterpret_cast<TI*>(py + (size_t)si[u] * slab), res[u]);
+}
+
+template <class TI>
+static int launch_lastaxis5(int mode, int u_sel, int minlv, const void* xv, void* yv, int64_t rows, int64_t channels,
+                            const float* scales, const int32_t* zps, int32_t qmin, int32_t qmax, int nt, hipStream_t st) {
+  typedef IO<TI, TI> io;
+  const TI* x = static_cast<const TI*>(xv);
+  TI* y = static_cast<TI*>(yv);
+  if (channels % io::N) return fail_arg("channels % N");
+  const int64_t vc = channels / io::N;
+  if (minlv < 64) minlv = 512;                                           // lane-vectors per slab, at least
+  int64_t k = (minlv + vc - 1) / vc, best_waste = -1;
+  for (int64_t c = k; c < k + 16; ++c) {
+    const int64_t waste = (64 - (c * vc) % 64) % 64 * 4096 / (c * vc);
+    if (best_waste < 0 || waste < best_waste) { best_waste = waste; k = c; }
+  }
+  if (k * vc >= (1 << 24)) return fail_arg("slab too large for the experiment");
+  const int64_t pieces = (k * vc + 63) / 64, U = u_sel, W = kThreads / 64;
+  const int64_t groups = (rows + W * U * k - 1) / (W * U * k);
+  const int64_t gy = groups < 65535 ? groups : 65535, gz = (groups + gy - 1) / gy;
+  const dim3 grid((unsigned)pieces, (unsigned)gy, (unsigned)gz);
+  const float rvc = 1.0f / (float)vc, lo = (float)qmin, hi = (float)qmax;
+#define LA5(U_, NT_, Z_, P_) hipLaunchKernelGGL((lastaxis5_kernel<TI, U_, NT_, Z_, P_>), grid, dim3(kThreads), 0, st, x, y,                                                  (uint64_t)rows, (uint32_t)vc, (uint32_t)k, rvc, lo, hi, (uint32_t)groups, scales, zps)
+  switch (mode) {
+    case 31: BY_U(BY_NT(BY_Z(0, LA5(UU, NT, Z, false)))); break;
+    case 32: BY_U(BY_NT(BY_Z(0, LA5(UU, NT, Z, true)))); break;
+    default: return fail_arg("mode");
+  }
+  return check_launch("lastaxis5");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // shortrows: block b owns elements [b*TILE, (b+1)*TILE) of the dense [rows][inner] storage, inner >= N; a lane-vector lies
 // in one row or crosses one boundary.  ORDER 0: data loads, then the parameter reads (the shipped gather path's order);
 // ORDER 1: parameter reads first (they return first), reciprocals under the data loads' latency.
@@ -637,6 +783,14 @@ extern "C" int mctq_x_lastaxis(int32_t mode, int32_t u, int32_t loops, const voi
       case MCTQ_DT_F32: return launch_lastaxis4<float>(x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
       case MCTQ_DT_F16: return launch_lastaxis4<_Float16>(x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
       case MCTQ_DT_BF16: return launch_lastaxis4<__bf16>(x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      default: return fail_arg("dtype");
+    }
+  }
+  if (mode == 31 || mode == 32) {                        // table shared through LDS (lastaxis5); `loops` = lane-vectors per slab, at least
+    switch (dtype) {
+      case MCTQ_DT_F32: return launch_lastaxis5<float>(mode, u, loops, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      case MCTQ_DT_F16: return launch_lastaxis5<_Float16>(mode, u, loops, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
+      case MCTQ_DT_BF16: return launch_lastaxis5<__bf16>(mode, u, loops, x, y, rows, channels, scales, zps, qmin, qmax, nt, st);
       default: return fail_arg("dtype");
     }
   }

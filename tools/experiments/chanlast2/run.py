@@ -23,7 +23,7 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 DT = {"f32": (torch.float32, 0, 4), "f16": (torch.float16, 1, 2), "bf16": (torch.bfloat16, 2, 2)}
 what = set(sys.argv[1:]) or {"recip", "lastaxis", "shortrows"}
-if "sched" in what or "contig" in what:
+if "sched" in what or "contig" in what or "lds" in what:
     what.add("lastaxis")
 
 
@@ -110,6 +110,13 @@ if "lastaxis" in what:
         if "contig" in what:
             modes = [("slab U2", mk(2, 2, 1), True), ("slab U4", mk(2, 4, 1), True), ("contig U2", mk(21, 2, 1), True), ("contig U4", mk(21, 4, 1), True),
                      ("contig repeat", mk(22, 4, 1), True)]
+        elif "lds" in what:
+            def mkn(mode, u, ntx, lv=1):
+                return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, lv, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
+                                                          s.data_ptr(), zp, -128, 127, ntx, stream)
+            modes = [("U2end", mk(11, 2, 1), True), ("U4end", mk(11, 4, 1), True), ("lds U2", mk(31, 2, 1), True), ("lds U4", mk(31, 4, 1), True),
+                     ("ldsinv U2", mk(32, 2, 1), True), ("ldsinv U4", mk(32, 4, 1), True), ("lds U2 s2048", mk(31, 2, 2048), True),
+                     ("lds U4 s2048", mk(31, 4, 2048), True), (f"lds U2 nt{3 - nt}", mkn(31, 2, 3 - nt), True), (f"lds U4 nt{3 - nt}", mkn(31, 4, 3 - nt), True)]
         elif "sched" in what:
             def mkn(mode, u, ntx):
                 return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, 1, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
