@@ -87,9 +87,14 @@ __device__ __forceinline__ void lastaxis2_body(const TI* __restrict__ xs, TI* __
   const uint32_t col = g - div_small(g, vc, rvc) * vc;
   float s[N], inv[N], blo[N], bhi[N];
   typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  // RECIP 3 / 4: timing bounds only (wrong results) -- 3: ONE dword of the table per lane, used for all N elements (the table's
+  // bytes gone, its dependent load kept); 4: no table access at all (a constant scale)
 #pragma unroll
   for (int j = 0; j < N; j += 4) {
-    const f32x4 s4 = *reinterpret_cast<const f32x4*>(scales + (size_t)col * N + j);
+    f32x4 s4;
+    if (RECIP == 3) { const float one = scales[(size_t)col * N]; s4 = f32x4{one, one, one, one}; }
+    else if (RECIP == 4) s4 = f32x4{0.03f, 0.03f, 0.03f, 0.03f};
+    else s4 = *reinterpret_cast<const f32x4*>(scales + (size_t)col * N + j);
     i32x4 z4 = {0, 0, 0, 0};
     if (HASZP) z4 = *reinterpret_cast<const i32x4*>(zps + (size_t)col * N + j);
 #pragma unroll
@@ -464,6 +469,8 @@ static int launch_lastaxis2(int mode, int u_sel, int loops, const void* xv, void
     case 1: BY_U(BY_NT(BY_Z(0, LA2(UU, NT, 0, Z)))); break;
     case 2: BY_U(BY_NT(BY_Z(0, LA2(UU, NT, 1, Z)))); break;
     case 3: BY_U(BY_NT(BY_Z(0, LA2(UU, NT, 2, Z)))); break;
+    case 6: BY_U(BY_NT(BY_Z(0, LA2(UU, NT, 3, Z)))); break;
+    case 7: BY_U(BY_NT(BY_Z(0, LA2(UU, NT, 4, Z)))); break;
     case 11: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 1)))); break;
     case 12: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 2)))); break;
     case 13: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 3)))); break;

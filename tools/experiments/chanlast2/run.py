@@ -23,7 +23,7 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 DT = {"f32": (torch.float32, 0, 4), "f16": (torch.float16, 1, 2), "bf16": (torch.bfloat16, 2, 2)}
 what = set(sys.argv[1:]) or {"recip", "lastaxis", "shortrows"}
-if "sched" in what or "contig" in what or "lds" in what:
+if "sched" in what or "contig" in what or "lds" in what or "bisect" in what:
     what.add("lastaxis")
 
 
@@ -110,6 +110,9 @@ if "lastaxis" in what:
         if "contig" in what:
             modes = [("slab U2", mk(2, 2, 1), True), ("slab U4", mk(2, 4, 1), True), ("contig U2", mk(21, 2, 1), True), ("contig U4", mk(21, 4, 1), True),
                      ("contig repeat", mk(22, 4, 1), True)]
+        elif "bisect" in what:
+            modes = [("U2", mk(2, 2, 1), True), ("U4", mk(2, 4, 1), True), ("U2 norcp", mk(3, 2, 1), False), ("U2 1dword", mk(6, 2, 1), False),
+                     ("U4 1dword", mk(6, 4, 1), False), ("U2 notable", mk(7, 2, 1), False), ("U4 notable", mk(7, 4, 1), False)]
         elif "lds" in what:
             def mkn(mode, u, ntx, lv=1):
                 return lambda i, ys: xlib.mctq_x_lastaxis(mode, u, lv, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, C, dtc,
@@ -132,7 +135,7 @@ if "lastaxis" in what:
         del xs
         torch.cuda.empty_cache()
 
-if "sched" in what:
+if "sched" in what or "bisect" in what:
     print("\n== reference launches of the same byte count on this box (shipped library) ==", flush=True)
     xlib.mctq_fq_per_tensor.argtypes = [P, P, I64, I32, ctypes.c_float, I32, I32, I32, P]
     for dt_name in ("bf16", "f32"):
