@@ -113,6 +113,7 @@ __device__ __forceinline__ void lastaxis2_body(const TI* __restrict__ xs, TI* __
     for (int j = 0; j < N; ++j) inv[j] = recip_mode<RECIP>(s[j], false);
   }
   typename io::VO res[U];
+  if (SCHED == 5) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }     // everything landed first
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (FULL || g < lim[u]) {
@@ -128,6 +129,7 @@ __device__ __forceinline__ void lastaxis2_body(const TI* __restrict__ xs, TI* __
       }
       if (SCHED == 1) res[u] = io::pack(out);
       else io::template store<NT>(reinterpret_cast<TI*>(py + (size_t)u * slab), io::pack(out));
+      if ((SCHED == 4 || SCHED == 5) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // PACED: vmcnt(0)
     }
   }
   if (SCHED == 1) {                                 // every result first, then the stores back to back
@@ -474,6 +476,8 @@ static int launch_lastaxis2(int mode, int u_sel, int loops, const void* xv, void
     case 11: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 1)))); break;
     case 12: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 2)))); break;
     case 13: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 3)))); break;
+    case 14: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 4)))); break;      // paced stores
+    case 15: BY_U(BY_NT(BY_Z(0, LA2S(UU, NT, Z, 5)))); break;      // all loads landed first, then paced stores
     case 4: BY_U(BY_NT(BY_Z(0, LA2L(UU, NT, Z, false)))); break;
     case 5: BY_U(BY_NT(BY_Z(0, LA2L(UU, NT, Z, true)))); break;
     default: return fail_arg("mode");
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
       }
     }
   };
-  if (ORDER == 0) { data_loads(); __builtin_amdgcn_sched_barrier(0); }
+  if (ORDER == 0 || ORDER == 2 || ORDER == 3) { data_loads(); __builtin_amdgcn_sched_barrier(0); }
 
   uint32_t ca[U], cb[U], split[U];
   float sa[U], sb[U], za[U], zb[U];
@@ -700,6 +704,7 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u) { ia[u] = 1.0f / sa[u]; if (!SAMEROW) ib[u] = 1.0f / sb[u]; }
   }
+  if (ORDER == 3) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
@@ -728,6 +733,7 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
         }
       }
       io::template store<NT>(ys + e0 + off, io::pack(out));
+      if ((ORDER == 2 || ORDER == 3) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // PACED: vmcnt(0)
     } else {
       // the tensor's last, partial lane-vector: element by element
       AffineOp op; op.scales = scales; op.zps = zps; op.lo = lo; op.hi = hi;
@@ -764,6 +770,8 @@ static int launch_shortrows(int mode, const void* xv, void* yv, int64_t rows, in
     case 2: BY_NT(BY_Z(0, BY_S(SR(NT, 0, 1, Z, S)))); break;      // data first, fast reciprocal
     case 3: BY_NT(BY_Z(0, BY_S(SR(NT, 1, 0, Z, S)))); break;      // parameters first, IEEE
     case 4: BY_NT(BY_Z(0, BY_S(SR(NT, 1, 1, Z, S)))); break;      // parameters first, fast reciprocal
+    case 5: BY_NT(BY_Z(0, BY_S(SR(NT, 2, 1, Z, S)))); break;      // data first, fast reciprocal, paced stores
+    case 6: BY_NT(BY_Z(0, BY_S(SR(NT, 3, 1, Z, S)))); break;      // data first, fast reciprocal, all loads landed first, paced stores
     default: return fail_arg("mode");
   }
   return check_launch("shortrows");
@@ -776,6 +784,126 @@ using namespace mctq;
 extern "C" int mctq_x_recip_check(unsigned long long* dev_out3, void* stream) {
   hipLaunchKernelGGL(recip_check_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, dev_out3);
   return check_launch("recip_check");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// flat_x: the per-tensor launch (block b owns 4 x 256 consecutive lane-vectors, scale / bounds in scalar registers) with something
+// BETWEEN the arrival of the data and the arithmetic, to find what gives shortrows_kernel its edge over flat_kernel on identical
+// work (edge.py: 11.72 vs 12.11 us, same output bits).  MODE 0: nothing (flat_kernel's shape); 1: one dependent dword load per block
+// from a 16 KiB table, a different word for every block (shortrows_kernel's scale read); 2: the same load, one hot word for all blocks;
+// 3: s_sleep SLEEP after the loads have landed; 4: MODE 1's load issued BEFORE the data loads.
+// The loaded word d enters as fma(d, 0, scale): the scale exactly (table entries are finite), a true dependency for the compiler.
+// ------------------------------------------------------------------------------------------------------------------
+template <class TI, int NT, int MODE, int SLEEP>
+__global__ __launch_bounds__(kThreads) void flat_x_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n_lv, float scale,
+                                                          float lo, float hi, const float* __restrict__ table) {
+  typedef IO<TI, TI> io;
+  constexpr int N = io::N, U = 4;
+  typedef typename io::VI VI;
+  const uint32_t b0 = blockIdx.x * (U * kThreads) + threadIdx.x;
+  if ((MODE >= 5 && MODE <= 9) && blockIdx.x * (U * kThreads) + U * kThreads <= n_lv) {
+    // full tile, no masks: the shipped flat_kernel's shape; 5: every store waited for before the next vector is touched (PACED);
+    // 6: unpaced (control); 7: the first store unpaced, then paced
+    VI w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads);
+    __builtin_amdgcn_sched_barrier(0);
+    const float inv0 = 1.0f / scale;
+    if (MODE == 8 || MODE == 9) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // 8 / 9: ALL loads landed first
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float in[N], out[N];
+      io::unpack(w[u], in);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float q = __builtin_amdgcn_fmed3f(__builtin_rintf(in[j] * inv0), lo, hi);
+        float y = __builtin_fmaf(q, scale, 0.0f);
+        asm("" : "+v"(y));
+        out[j] = y;
+      }
+      io::template store<NT>(ys + ((size_t)b0 + u * kThreads) * N, io::pack(out));
+      if ((MODE == 5 || MODE == 8 || (MODE == 7 && u > 0)) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }
+    }
+    return;
+  }
+  float d = 0.0f;
+  if (MODE == 4) d = table[(blockIdx.x * 2u) & 4095u];
+  VI v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (b0 + u * kThreads < n_lv) v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads);
+  __builtin_amdgcn_sched_barrier(0);
+  if (MODE == 1) d = table[(blockIdx.x * 2u) & 4095u];
+  if (MODE == 2) d = table[0];
+  if (MODE == 3) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0) (gfx9 encoding: vmcnt low 4 bits 0, high bits 15:14 0; expcnt 7, lgkmcnt 15)
+    __builtin_amdgcn_s_sleep(SLEEP);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float s = MODE == 0 || MODE == 3 ? scale : __builtin_fmaf(d, 0.0f, scale);
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (b0 + u * kThreads < n_lv) {
+      float in[N], out[N];
+      io::unpack(v[u], in);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float q = __builtin_amdgcn_fmed3f(__builtin_rintf(in[j] * inv), lo, hi);
+        float y = __builtin_fmaf(q, s, 0.0f);
+        asm("" : "+v"(y));
+        out[j] = y;
+      }
+      io::template store<NT>(ys + ((size_t)b0 + u * kThreads) * N, io::pack(out));
+    }
+  }
+}
+
+template <class TI>
+static int launch_flat_x(int mode, int sleep, const void* xv, void* yv, int64_t n, float scale, int32_t qmin, int32_t qmax, int nt,
+                         const float* table, hipStream_t st) {
+  typedef IO<TI, TI> io;
+  if (n % io::N || n / io::N >= (1ll << 32) - 4096) return fail_arg("n");
+  const uint32_t n_lv = (uint32_t)(n / io::N);
+  const unsigned grid = (n_lv + 4 * kThreads - 1) / (4 * kThreads);
+  const TI* x = static_cast<const TI*>(xv);
+  TI* y = static_cast<TI*>(yv);
+  const float lo = (float)qmin, hi = (float)qmax;
+#define FX(NT_, M_, S_) hipLaunchKernelGGL((flat_x_kernel<TI, NT_, M_, S_>), dim3(grid), dim3(kThreads), 0, st, x, y, n_lv, scale, lo, hi, table)
+#define FXN(M_, S_) do { if (nt == 2) FX(2, M_, S_); else FX(1, M_, S_); } while (0)
+  switch (mode) {
+    case 0: FXN(0, 0); break;
+    case 1: FXN(1, 0); break;
+    case 2: FXN(2, 0); break;
+    case 4: FXN(4, 0); break;
+    case 5: FXN(5, 0); break;
+    case 6: FXN(6, 0); break;
+    case 7: FXN(7, 0); break;
+    case 8: FXN(8, 0); break;
+    case 9: FXN(9, 0); break;
+    case 3:
+      switch (sleep) {
+        case 4: FXN(3, 4); break;
+        case 8: FXN(3, 8); break;
+        case 16: FXN(3, 16); break;
+        case 32: FXN(3, 32); break;
+        default: return fail_arg("sleep");
+      }
+      break;
+    default: return fail_arg("mode");
+  }
+  return check_launch("flat_x");
+}
+
+extern "C" int mctq_x_flat(int32_t mode, int32_t sleep, const void* x, void* y, int64_t n, int32_t dtype, float scale, int32_t qmin,
+                           int32_t qmax, int32_t nt, const float* table, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case MCTQ_DT_F32: return launch_flat_x<float>(mode, sleep, x, y, n, scale, qmin, qmax, nt, table, st);
+    case MCTQ_DT_F16: return launch_flat_x<_Float16>(mode, sleep, x, y, n, scale, qmin, qmax, nt, table, st);
+    case MCTQ_DT_BF16: return launch_flat_x<__bf16>(mode, sleep, x, y, n, scale, qmin, qmax, nt, table, st);
+    default: return fail_arg("dtype");
+  }
 }
 
 // mode 1: early loads + IEEE reciprocal; 2: + fast exact reciprocal; 3: no reciprocal (timing bound, wrong results);

@@ -23,7 +23,7 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 DT = {"f32": (torch.float32, 0, 4), "f16": (torch.float16, 1, 2), "bf16": (torch.bfloat16, 2, 2)}
 what = set(sys.argv[1:]) or {"recip", "lastaxis", "shortrows"}
-if "sched" in what or "contig" in what or "lds" in what or "bisect" in what:
+if "sched" in what or "contig" in what or "lds" in what or "bisect" in what or "paced" in what:
     what.add("lastaxis")
 
 
@@ -110,6 +110,9 @@ if "lastaxis" in what:
         if "contig" in what:
             modes = [("slab U2", mk(2, 2, 1), True), ("slab U4", mk(2, 4, 1), True), ("contig U2", mk(21, 2, 1), True), ("contig U4", mk(21, 4, 1), True),
                      ("contig repeat", mk(22, 4, 1), True)]
+        elif "paced" in what:
+            modes = [("U2end", mk(11, 2, 1), True), ("U4end", mk(11, 4, 1), True), ("U2asgo", mk(2, 2, 1), True), ("U4asgo", mk(2, 4, 1), True),
+                     ("U2paced", mk(14, 2, 1), True), ("U4paced", mk(14, 4, 1), True), ("U2wait+paced", mk(15, 2, 1), True), ("U4wait+paced", mk(15, 4, 1), True)]
         elif "bisect" in what:
             modes = [("U2", mk(2, 2, 1), True), ("U4", mk(2, 4, 1), True), ("U2 norcp", mk(3, 2, 1), False), ("U2 1dword", mk(6, 2, 1), False),
                      ("U4 1dword", mk(6, 4, 1), False), ("U2 notable", mk(7, 2, 1), False), ("U4 notable", mk(7, 4, 1), False)]
@@ -170,7 +173,7 @@ if "shortrows" in what:
         def mk(mode):
             return lambda i, ys: xlib.mctq_x_shortrows(mode, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, inner, rows, dtc,
                                                        s.data_ptr(), zp, -128, 127, nt, stream)
-        modes = [("d/ieee", mk(1), True), ("d/rcp", mk(2), True), ("p/ieee", mk(3), True), ("p/rcp", mk(4), True)]
+        modes = [("d/ieee", mk(1), True), ("d/rcp", mk(2), True), ("p/ieee", mk(3), True), ("p/rcp", mk(4), True), ("d/rcp paced", mk(5), True), ("d/rcp wait+paced", mk(6), True)]
         run_case(f"{dt_name} {rows}x{inner}" + (" zp" if with_zp else ""), nb, ring, xs, lib_call, modes)
         del xs
         torch.cuda.empty_cache()
