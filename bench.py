@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--unroll", type=int, default=None)
     ap.add_argument("--heavy-unroll", type=int, default=None)
     ap.add_argument("--rowsteps", type=int, default=None, help="tuning key rowsteps (include/mctq_hip.h): 1 = rowsteps_kernel for short whole-step rows")
+    ap.add_argument("--paced", type=int, default=None, help="tuning key paced (include/mctq_hip.h): 0 = per-tensor launches never through flat_paced_kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batched-extra", action="store_true", help="skip the batched_16x4096 object of the default run")
@@ -294,7 +295,7 @@ def main():
     if not dry:
         native.load()
         for key, val in (("nt", args.nt), ("unroll", args.unroll), ("heavy_unroll", args.heavy_unroll), ("rowsteps", args.rowsteps),
-                         ("cached_store_max_mb", args.cached_store_max_mb)):
+                         ("cached_store_max_mb", args.cached_store_max_mb), ("paced", args.paced)):
             if val is not None:
                 native.set_tuning(key, val)
 

@@ -54,7 +54,7 @@ extern "C" {
  * points return MCTQ_E_ARG for it ("per-channel rows shorter than 256 lane-vectors above 2^32 elements: affine quantizers
  * only") -- the Python layer (hip/ops.py: _split_rows) cuts such a tensor into row blocks below the limit and issues one launch
  * per block, which is what a caller of the C ABI has to do as well.  Long rows and per-tensor launches have no such limit. */
-/* v9 (round 6): + mctq_selftest_reciprocal, + tuning key "shortrows"; the channel-last (lastaxis) launch and the new launch of
+/* v9 (round 6): + mctq_selftest_reciprocal, + tuning keys "shortrows", "paced"; the channel-last (lastaxis) launch and the new launch of
  * short / ragged per-channel rows (shortrows) invert a lane's own scales with a five-instruction exact reciprocal (no signature
  * changed; results are bit-identical). */
 #define MCTQ_ABI_VERSION 9
@@ -482,6 +482,10 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *                  2544, 2548 (wave-wide tiles), 2560 (256 x 256 ping-pong)
  *   key "ql_band" : tile rows per XCD band of the tiled kernel (0 = automatic); "ql_rot", "ql_stagger": experiments of the
  *                  tiled kernel (K rotation between blocks sharing a weight tile; half of the waves copy after multiplying), 0 / 1, default 0
+ *   key "paced" : the affine per-tensor launch through flat_paced_kernel (flat_kernel's tile under another order of waits: loads
+ *                  128 clocks apart, every load landed before the first store, every store completed before the next lane-vector):
+ *                  0 = never, 1 (default) = launches that fill 3/4 ... 1 round of resident blocks, where it measured 4-6 % faster
+ *                  (48-64 MiB of traffic on this chip; 3-9 % slower outside), 2 = every launch with a full four-vector tile
  *   key "shortrows" : affine per-channel tensors through shortrows_kernel (per-lane parameter reads behind the tile's data loads,
  *                  no LDS window): 0 = never, 1 (default) = where it measured faster (16-bit storage: every short or ragged row
  *                  shape, and long rows of launches that fill 7/8 ... 1 round of resident blocks; float32: rows of 4 ... 31

@@ -850,6 +850,58 @@ __global__ __launch_bounds__(kThreads) void flat_kernel(const TI* __restrict__ x
   }
 }
 
+// flat, for launches that fill 3/4 ... 1 round of resident blocks (8 per CU; 48-64 MiB of traffic on this chip): the same tile as
+// flat_kernel<U = 4> under a different order of waits -- the tile's four loads 128 clocks apart, EVERY load landed before the first
+// store is issued, and every store acknowledged before the next lane-vector is touched.  All three together are worth 4-6 % on
+// such launches (all waves of the launch are resident at once: the chip reads first and writes after, instead of turning the HBM
+// around under the read burst); any one or two of them do nothing, and on launches of other sizes the three cost 3-9 %
+// (profiles/EXPERIMENTS.md round 6, profiles/r06/flatx*.log: bfloat16 4096^2 12.12 -> 11.38 us, float32 2048 x 4096 12.15 -> 11.47,
+// 7/8 of a round 10.82 -> 10.33, 3/4 9.53 -> 9.14; 5/8 8.06 -> 8.31, 9/8 13.5 -> 14.7, two rounds 22.0 -> 23.4).  launch_flat
+// takes it for the affine per-tensor launch inside that window only (tuning key "paced").  Arithmetic: flat_kernel's, call for call.
+template <bool FAST, class TI, int NT>
+__device__ __forceinline__ void paced_tile(const AffineOp& op, const AffineOp::Param& p, const typename IO<TI, TI>::VI (&v)[4],
+                                           TI* __restrict__ ys, int64_t first) {
+  typedef IO<TI, TI> io;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    typename io::VI one[1] = {v[u]};
+    typename io::VO res[1];
+    run_vectors<FAST, AffineOp, TI, TI, 1>(op, one, res, p, NoBook());
+    io::template store<NT>(ys + (first + u * kThreads) * io::N, res[0]);
+    if (u < 3) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }     // vmcnt(0): the store has completed
+  }
+}
+
+template <class TI, int NT>
+__global__ __launch_bounds__(kThreads) void flat_paced_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, int64_t n,
+                                                              AffineOp op, AffineOp::Param p) {
+  typedef IO<TI, TI> io;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t nv = n / io::N;
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * 4) + threadIdx.x;
+  if (((int64_t)blockIdx.x + 1) * (kThreads * 4) <= nv) {
+    typename io::VI v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = io::template load<NT>(xs + (base + u * kThreads) * io::N);
+      if (u < 3) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(2); __builtin_amdgcn_sched_barrier(0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool fast = __builtin_amdgcn_readfirstlane((int)AffineOp::can_fast(p)) != 0;
+    __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): all four loads have landed
+    __builtin_amdgcn_sched_barrier(0);
+    if (fast) paced_tile<true, TI, NT>(op, p, v, ys, base);
+    else paced_tile<false, TI, NT>(op, p, v, ys, base);
+  } else {
+    auto get_param = [&]() { return p; };
+    one_tile<false, AffineOp, TI, TI, 4, NT>(op, smem, xs, ys, base, nv, get_param);
+  }
+  if (blockIdx.x == 0 && nv * io::N < n) {                    // n % N trailing elements (uniform branch)
+    const int64_t i = nv * io::N + threadIdx.x;
+    if (i < n) ys[i] = narrow_to<TI>(op.template apply<false>((float)xs[i], p, NoBook()));
+  }
+}
+
 // flat, one element per lane: used when x or y is not vector-aligned.
 template <class Op, class TI, class TO>
 __global__ __launch_bounds__(kThreads) void flat_scalar_kernel(Op op, typename Op::Param p, const TI* __restrict__ x,
@@ -1270,6 +1322,7 @@ inline void note(const char* shape, int unroll, int nt) {
   ++g_note.count;
   if (g_launch_log) log_launch();
 }
+extern int g_paced;          // the per-tensor launch of 3/4 ... 1 round through flat_paced_kernel: 0 never, 1 (default) inside that window, 2 whenever there is a full tile
 extern int g_shortrows;      // rows shorter than a tile through shortrows_kernel: 0 never, 1 (default) where it measured faster, 2 whenever eligible
 extern int g_rowsteps;       // short whole-step rows: 0 rows_kernel, 1 rowsteps_kernel, 2 (default) rowsteps_kernel when its grid is one round
 extern int g_heavy_unroll;   // 0 = automatic
@@ -1389,6 +1442,18 @@ static int launch_flat(const Op& op, const typename Op::Param& p, const void* xv
     // small tensors: fewer lane-vectors per lane so that the grid still covers the chip (>= 2 blocks per CU)
     int u_sel = g_unroll;
     while (u_sel > 1 && nv < (int64_t)kThreads * u_sel * 2 * cu_count()) u_sel >>= 1;
+    if constexpr (std::is_same<Op, AffineOp>::value && std::is_same<TI, TO>::value) {
+      // 3/4 ... 1 round of resident blocks (8 blocks of four waves per CU): flat_paced_kernel (see there)
+      const int64_t blocks4 = (nv + kThreads * 4 - 1) / (kThreads * 4), round = 8 * (int64_t)cu_count();
+      const bool window = blocks4 * 4 >= round * 3 && blocks4 <= round;
+      if (u_sel == 4 && nv >= kThreads * 4 && blocks4 <= 0x7fffffffLL && ((g_paced == 1 && window) || g_paced == 2)) {
+        MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
+          launch_resolved<flat_paced_kernel<TI, NT>>(dim3((unsigned)blocks4), dim3(kThreads), book_bytes, st, x, y, n, op, p);
+          note<Op, TI, TO>("flat_paced_kernel", 4, NT);
+        });
+        return check_launch("flat paced launch");
+      }
+    }
     MCTQ_DISPATCH_U_NT(u_sel, nt_mode(n * (int64_t)sizeof(TO)), {
       int64_t blocks = (nv + kThreads * U - 1) / (kThreads * U);
       if (blocks == 0) blocks = 1;

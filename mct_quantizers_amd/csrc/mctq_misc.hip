@@ -17,6 +17,7 @@ int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggrega
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_rowsteps = 2;           // 2: rowsteps_kernel only where it measured faster (see launch_channels)
+int g_paced = 1;              // per-tensor launches of 3/4 ... 1 round through flat_paced_kernel: 0 never, 1 inside the window, 2 whenever a full tile exists (launch_flat)
 int g_shortrows = 1;          // short / ragged rows through shortrows_kernel: 0 never, 1 the measured rule, 2 whenever eligible (launch_channels)
 int g_ql_variant = 0;
 int g_ql_band = 0;
@@ -162,6 +163,11 @@ int mctq_set_tuning(const char* key, int32_t value) {
     if (value != 0 && value != 1 && value != 2 && value != 4)
       return fail_arg("heavy_unroll must be 0, 1, 2 or 4");
     g_heavy_unroll = value;
+    return 0;
+  }
+  if (!strcmp(key, "paced")) {
+    if (value != 0 && value != 1 && value != 2) return fail_arg("paced must be 0, 1 or 2");
+    g_paced = value;
     return 0;
   }
   if (!strcmp(key, "shortrows")) {

@@ -338,11 +338,37 @@ def check_headline_schedule(text):
     assert m and int(m.group(1)) <= 64, m and m.group(1)
 
 
+def check_paced_schedule(text):
+    """flat_paced_kernel (per-tensor launches of 3/4 ... 1 round) is nothing but an order of waits; on the ISA of the bfloat16 and the
+    float32 instance: the tile's four non-temporal loads with an s_sleep between them, ONE s_waitcnt vmcnt(0) between the fourth load
+    and the first rounding, an s_waitcnt vmcnt(0) between every two stores of the tile, at most 64 VGPRs."""
+    for name in ("_ZN4mctq17flat_paced_kernelIDF16bLi2EEEvPKT_PS1_lNS_8AffineOpENS5_5ParamE",
+                 "_ZN4mctq17flat_paced_kernelIfLi2EEEvPKT_PS1_lNS_8AffineOpENS5_5ParamE"):
+        assert name + ":" in text, f"{name} is not instantiated"
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        ins = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        ins = [ln for ln in ins if ln and not ln.startswith(".") and not ln.endswith(":")]
+        loads = [i for i, x in enumerate(ins) if x.startswith("global_load_dwordx4")]
+        stores = [i for i, x in enumerate(ins) if x.startswith("global_store_dwordx4")]
+        assert len(loads) >= 4 and len(stores) >= 4
+        for a, b in zip(loads[:3], loads[1:4]):
+            assert any(x.startswith("s_sleep") for x in ins[a:b]), "the tile's loads are not spaced"
+        first_round = next(i for i, x in enumerate(ins) if x.startswith("v_rndne_f32"))
+        assert loads[3] < first_round and any(x.startswith("s_waitcnt vmcnt(0)") for x in ins[loads[3]:first_round]), "arithmetic before all loads landed"
+        for a, b in zip(stores[:3], stores[1:4]):
+            assert any(x.startswith("s_waitcnt vmcnt(0)") for x in ins[a:b]), "two stores without a completed one between them"
+        m = re.search(re.escape(name) + r"\.num_vgpr, (\d+)", text)
+        assert m and int(m.group(1)) <= 64, m and m.group(1)
+
+
 def test_headline_kernel_keeps_the_schedule_its_roofline_figure_rests_on(tmp_path):
     """... and the check has teeth: the same translation unit compiled against a copy of the kernel header in which the
     parameter fetch is written IN FRONT of the tile's loads fails it."""
     from mct_quantizers_amd.hip import build as B
-    check_headline_schedule(_compile_affine_asm(tmp_path))
+    text = _compile_affine_asm(tmp_path)
+    check_headline_schedule(text)
+    check_paced_schedule(text)
     hdr = open(os.path.join(B.CSRC, "mctq_kernels.hpp")).read()
     a = "  typename Op::Book book;\n  if constexpr (HasPrefetch<Op>::value) {"
     b = "  const typename Op::Param p = get_param();\n  const bool fast = __builtin_amdgcn_readfirstlane"

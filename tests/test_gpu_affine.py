@@ -522,6 +522,45 @@ def test_channel_last_and_short_row_launches_vs_oracle(lib, dt, with_zp):
     assert {"lastaxis_kernel", "shortrows_kernel"} <= seen, seen
 
 
+@pytest.mark.parametrize("dt", ["float32", "float16", "bfloat16"])
+def test_per_tensor_launches_of_one_round_take_the_paced_kernel_and_agree_with_the_oracle(lib, dt):
+    """launch_flat's window (3/4 ... 1 round of resident blocks, 8 per CU) goes through flat_paced_kernel -- the same tile under another
+    order of waits -- and nothing outside it does; tuning key "paced": 0 never, 1 the window, 2 whenever a full four-vector tile
+    exists.  Sizes on both edges of the window, a partial last tile, n % N trailing elements; a zero point; bit for bit against the
+    oracle, and equal to flat_kernel's result."""
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    code, tdt = {"float32": 0, "float16": 1, "bfloat16": 2}[dt], getattr(torch, dt)
+    N = 4 if dt == "float32" else 8
+    tile = 1024 * N
+    rnd = 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    lo_edge = -(-3 * rnd // 4)
+    sizes = [(lo_edge * tile, True), ((lo_edge - 1) * tile, False), (rnd * tile + N - 1, True), (rnd * tile + N, False),
+             ((lo_edge + 7) * tile + tile // 2 + 3, True), ((rnd - 1) * tile + 5 * N + 1, True)]
+    scale, zp, qmin, qmax = 0.0371, 3, -128, 127
+    rng = np.random.default_rng(77)
+    try:
+        for n, in_window in sizes:
+            x32 = _tie_heavy_r6(rng, (n,), np.float32(scale), np.float32(zp), qmin, qmax)
+            xh = _dev(x32).to(tdt)
+            x_np = xh.float().cpu().numpy()
+            want = O.narrow(O.fake_quant_affine(x_np, np.float32([scale]), np.int32([zp]), qmin, qmax, axis=None), dt)
+            got = {}
+            for mode in (1, 0, 2):
+                native.set_tuning("paced", mode)
+                y = torch.full_like(xh, 300.0)
+                assert lib.mctq_fq_per_tensor(xh.data_ptr(), y.data_ptr(), n, code, scale, zp, qmin, qmax, _stream()) == 0, lib.mctq_last_error()
+                kernel = native.last_launch().split("<")[0]
+                assert kernel == ("flat_paced_kernel" if mode == 2 or (mode == 1 and in_window) else "flat_kernel"), (n, mode, native.last_launch())
+                got[mode] = y.float().cpu().numpy()
+                assert finite_equal(got[mode], want, x_np), (n, dt, mode, native.last_launch(), first_mismatch(got[mode], want, x_np))
+            assert bits_equal(got[1], got[0]) and bits_equal(got[2], got[0])
+        with pytest.raises(Exception):
+            native.set_tuning("paced", 3)
+    finally:
+        native.set_tuning("paced", 1)
+
+
 def test_fuzz_channel_last_and_short_row_launch_geometry_vs_oracle(lib):
     """Seeded fuzz of the round-6 launch geometry through the C ABI: random (outer, C, inner) with inner drawn around the
     lane-vector and tile sizes (1, below a vector, whole vectors, one past / one short of them, rows longer than a tile), C from 1

@@ -36,7 +36,7 @@ def arm(spec):
 
     def apply(reset=False):
         for k, v in keys:
-            assert lib.mctq_set_tuning(k.encode(), {"shortrows": 1, "rowsteps": 2, "unroll": 4, "nt": 1}.get(k, 0) if reset else int(v)) == 0, (k, v)
+            assert lib.mctq_set_tuning(k.encode(), {"shortrows": 1, "paced": 1, "rowsteps": 2, "unroll": 4, "nt": 1}.get(k, 0) if reset else int(v)) == 0, (k, v)
     return spec, lib, apply
 
 
@@ -94,6 +94,8 @@ SMALL = [("pc0", 128, 4096), ("pc0", 256, 4096), ("pc0", 512, 4096), ("pc0", 102
          ("pc0", 4096, 256), ("pc0", 16384, 64), ("pc0", 1024, 1024), ("pc0", 256, 1020), ("pc0", 65536, 16), ("pc0", 8192, 1020), ("pc0", 300, 576)]
 RAGGED = [("pc0", 16384, 1020), ("pc0", 4096, 4100), ("pc0", 4096, 4099), ("pc0", 8192, 1020), ("pc0", 65536, 252), ("pc0", 32768, 516), ("pc0", 2048, 8190),
           ("pc0", 131072, 100), ("pc0", 1048576, 12), ("pc0", 50257, 772), ("pc0", 300, 1020), ("pc0", 16384, 1024)]
+PACED16 = [("pt", r, 4096) for r in (2048, 2560, 2816, 3072, 3328, 3584, 3840, 4096, 4104, 4352, 4608, 8192)]     # 1/2 ... 2 rounds of 16-bit blocks
+PACED32 = [("pt", r, 4096) for r in (1024, 1280, 1408, 1536, 1664, 1792, 1920, 2048, 2052, 2304, 4096)]
 ROUNDS = [("pc0", 8192, 2048), ("pc0", 6144, 4096), ("pc0", 8192, 4096), ("pc0", 12288, 4096), ("pc0", 16384, 4096), ("pc0", 4096, 2048),
           ("pc0", 2048, 3072), ("pc0", 1024, 4096), ("pc0", 512, 4096)]
 
@@ -158,6 +160,8 @@ for c in args.cases.split(","):
     elif c == "affine32": affine_cases(["f32"])
     elif c == "tqp16": affine_cases(["bf16", "f16"], TQP)
     elif c == "tqp32": affine_cases(["f32"], TQP)
+    elif c == "paced16": affine_cases(["bf16", "f16"], PACED16)
+    elif c == "paced32": affine_cases(["f32"], PACED32)
     elif c == "small16": affine_cases(["bf16"], SMALL)
     elif c == "small32": affine_cases(["f32"], SMALL)
     elif c == "ragged16": affine_cases(["bf16", "f16"], RAGGED)

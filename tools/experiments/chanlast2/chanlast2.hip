@@ -801,17 +801,23 @@ __global__ __launch_bounds__(kThreads) void flat_x_kernel(const TI* __restrict__
   constexpr int N = io::N, U = 4;
   typedef typename io::VI VI;
   const uint32_t b0 = blockIdx.x * (U * kThreads) + threadIdx.x;
-  if ((MODE >= 5 && MODE <= 9) && blockIdx.x * (U * kThreads) + U * kThreads <= n_lv) {
+  if ((MODE >= 5 && MODE <= 16) && blockIdx.x * (U * kThreads) + U * kThreads <= n_lv) {
     // full tile, no masks: the shipped flat_kernel's shape; 5: every store waited for before the next vector is touched (PACED);
     // 6: unpaced (control); 7: the first store unpaced, then paced
+    // 10: mode 8 with the loads 64 clocks apart; 11: mode 8 with lane-masked loads; 13: mode 8 with lane-masked arithmetic + stores
     VI w[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads);
+    for (int u = 0; u < U; ++u) {
+      if (MODE == 11) { if (b0 + u * kThreads < n_lv) w[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads); }
+      else w[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs) + b0 + u * kThreads);
+      if ((MODE == 10 || MODE >= 14) && u + 1 < U) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(SLEEP > 0 ? SLEEP : 1); __builtin_amdgcn_sched_barrier(0); }   // 14: spaced loads only; 15: + all loads first; 16: + paced stores only
+    }
     __builtin_amdgcn_sched_barrier(0);
     const float inv0 = 1.0f / scale;
-    if (MODE == 8 || MODE == 9) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // 8 / 9: ALL loads landed first
+    if (MODE == 8 || MODE == 9 || (MODE >= 10 && MODE <= 13) || MODE == 15) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // 8 / 9: ALL loads landed first
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (MODE == 13 && !(b0 + u * kThreads < n_lv)) continue;
       float in[N], out[N];
       io::unpack(w[u], in);
 #pragma unroll
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(kThreads) void flat_x_kernel(const TI* __restrict__
         out[j] = y;
       }
       io::template store<NT>(ys + ((size_t)b0 + u * kThreads) * N, io::pack(out));
-      if ((MODE == 5 || MODE == 8 || (MODE == 7 && u > 0)) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }
+      if ((MODE == 5 || MODE == 8 || (MODE >= 10 && MODE <= 13) || MODE == 16 || (MODE == 7 && u > 0)) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }
     }
     return;
   }
@@ -881,6 +887,19 @@ static int launch_flat_x(int mode, int sleep, const void* xv, void* yv, int64_t 
     case 7: FXN(7, 0); break;
     case 8: FXN(8, 0); break;
     case 9: FXN(9, 0); break;
+    case 10:
+      switch (sleep) {
+        case 2: FXN(10, 2); break;
+        case 4: FXN(10, 4); break;
+        case 8: FXN(10, 8); break;
+        default: FXN(10, 1); break;
+      }
+      break;
+    case 14: if (sleep == 4) FXN(14, 4); else FXN(14, 1); break;
+    case 15: FXN(15, 1); break;
+    case 16: FXN(16, 1); break;
+    case 11: FXN(11, 0); break;
+    case 13: FXN(13, 0); break;
     case 3:
       switch (sleep) {
         case 4: FXN(3, 4); break;

@@ -48,7 +48,17 @@ def fx(mode, sleep=0):
     return call
 
 
-arms = [("shipped per-tensor (flat_kernel)", lib_flat), ("shipped per-channel, equal scales", lib_short), ("flat_x 0: nothing", fx(0)),
+if os.environ.get("FLATX_ARMS") == "explicit":
+    arms = [("shipped per-tensor (flat_kernel)", lib_flat), ("shipped per-channel, equal scales", lib_short), ("flat_x 0: masked, compiler's waits", fx(0)),
+            ("flat_x 8: wait all + PACED", fx(8)), ("flat_x 10: 8 + loads 64 clk apart", fx(10)), ("flat_x 11: 8 + masked loads", fx(11)),
+            ("flat_x 13: 8 + masked arithmetic", fx(13)), ("flat_x 5: PACED only", fx(5))]
+elif os.environ.get("FLATX_ARMS") == "spaced":
+    arms = [("shipped per-tensor (flat_kernel)", lib_flat), ("shipped per-channel, equal scales", lib_short),
+            ("flat_x 10: spaced 64 clk + all first + PACED", fx(10, 1)), ("flat_x 10: spaced 128 clk", fx(10, 2)), ("flat_x 10: spaced 256 clk", fx(10, 4)),
+            ("flat_x 10: spaced 512 clk", fx(10, 8)), ("flat_x 14: spaced loads ONLY (64 clk)", fx(14, 1)), ("flat_x 14: spaced loads ONLY (256 clk)", fx(14, 4)),
+            ("flat_x 15: spaced + all loads first", fx(15)), ("flat_x 16: spaced + PACED", fx(16)), ("flat_x 6: the shipped shape", fx(6))]
+else:
+  arms = [("shipped per-tensor (flat_kernel)", lib_flat), ("shipped per-channel, equal scales", lib_short), ("flat_x 0: nothing", fx(0)),
         ("flat_x 1: table word per block", fx(1)), ("flat_x 2: one hot table word", fx(2)), ("flat_x 4: word per block, read first", fx(4)),
         ("flat_x 5: full tile, PACED stores", fx(5)), ("flat_x 6: full tile, unpaced", fx(6)), ("flat_x 7: paced from store 2", fx(7)), ("flat_x 8: full tile, wait all + PACED", fx(8)), ("flat_x 9: full tile, wait all, unpaced", fx(9)),
         ("flat_x 3: s_sleep 4", fx(3, 4)),]
