@@ -23,6 +23,12 @@ bench() {         # judged line + side lines (the default line now also carries 
   timeout 400 python bench.py --dtype bf16 --config cfg5 --steps 300 --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_dtype.jsonl
   timeout 400 python bench.py --dtype bf16 --config cfg4 --steps 300 --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_dtype.jsonl
   for n in 1 8 64; do timeout 400 python bench.py --config cfg3 --batch $n --steps 1000 --warmup 100 --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_cfg3.jsonl; done
+  # per-tensor launches of one round (flat_paced_kernel) beside the same launch with the key off
+  : > $O/bench_paced.jsonl
+  for pv in 1 0; do
+    timeout 400 python bench.py --config cfg3 --batch 50 --stream-depth -1 --steps 1000 --warmup 100 --paced $pv --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_paced.jsonl
+    timeout 400 python bench.py --config cfg3 --batch 100 --dtype bf16 --stream-depth -1 --steps 1000 --warmup 100 --paced $pv --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_paced.jsonl
+  done
   # the launch shapes VERDICT r05 #1 names, under the judged protocol (cold ring, 1 s pre-warm, events inside the timed region)
   for sa in "4096x4096 1" "65536x200 1" "16384x1020 0" "1048576x16 0" "16384x1024 0" "65536x256 0" "64x56x56x256 3" "4096x4100 0"; do
     set -- $sa
@@ -32,7 +38,7 @@ bench() {         # judged line + side lines (the default line now also carries 
   timeout 400 python bench.py --config sym --shape 4096x4096 --axis 1 --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_shapes.jsonl
   timeout 400 python bench.py --config sym --shape 1048576x16 --axis 0 --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_shapes.jsonl
   for f in bench_default.json bench_20.json; do line $f < $O/$f; done
-  for f in bench_other_configs bench_dtype bench_cfg3 bench_shapes; do while read -r l; do echo "$l" | line $f; done < $O/$f.jsonl; done
+  for f in bench_other_configs bench_dtype bench_cfg3 bench_paced bench_shapes; do while read -r l; do echo "$l" | line $f; done < $O/$f.jsonl; done
 }
 
 rehearse() {      # the N > 1 entry path on the one GPU: must refuse without --allow-gloo (two ranks, one device), and say so with it
@@ -69,6 +75,10 @@ e2e() {           # bench.py --config resnet50 --e2e at the final build
   timeout 600 python bench.py --config resnet50 --e2e --steps 100 2>$O/e2e.err | tail -1 > $O/bench_e2e_resnet50.json
   python -c "
 import json; d=json.load(open('$O/bench_e2e_resnet50.json')); print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k in ('value', 'ms_per_step') or k.startswith('ms_')})" 2>/dev/null || head -c 600 $O/bench_e2e_resnet50.json
+}
+
+abpaced() {       # the per-tensor window through the shipped library: paced 0 against 2 (every size through flat_paced_kernel)
+  timeout 800 python tools/ab_probe.py --a shipped:paced=0 --b shipped:paced=2 --cases paced16,paced32 > $O/ab_paced.log 2>&1; grep -c "B/A" $O/ab_paced.log
 }
 
 for s in "$@"; do $s; done
