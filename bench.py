@@ -88,6 +88,7 @@ def parse():
                          "channel-last, short and ragged rows)")
     ap.add_argument("--shape", default="4096x4096", help="--config sym: the tensor's shape, e.g. 4096x4096 or 64x56x56x256")
     ap.add_argument("--axis", type=int, default=0, help="--config sym: the channel axis")
+    ap.add_argument("--per-tensor", action="store_true", help="--config sym: one threshold for the whole tensor (the per-tensor launch) instead of one per channel")
     ap.add_argument("--batched", type=int, default=0,
                     help="T > 0: a step is ONE batched launch over T tensors of the configuration (affine configs)")
     ap.add_argument("--batch", type=int, default=64, help="N of config 3")
@@ -316,7 +317,7 @@ def main():
     else:
         if args.config == "sym":
             x_np = workloads.make_input("sym", shape=tuple(int(d) for d in args.shape.lower().split("x")))
-            wl = workloads.make_workload("sym", x_np, axis=args.axis)
+            wl = workloads.make_workload("sym", x_np, axis=None if args.per_tensor else args.axis)
         else:
             x_np = workloads.make_input(args.config, batch=args.batch)
             wl = workloads.make_workload(args.config, x_np)
@@ -570,7 +571,7 @@ def main():
     if not dry:
         key = args.config if args.config != "cfg3" else f"cfg3_n{args.batch}"
         if args.config == "sym":
-            key = f"sym_{args.shape.lower()}_axis{args.axis % len(wl.shape)}"
+            key = f"sym_{args.shape.lower()}_" + ("pertensor" if args.per_tensor else f"axis{args.axis % len(wl.shape)}")
         if args.batched and not model_mode:
             key = f"{key}_batched{tensors}"
         if stream_on:

@@ -101,6 +101,9 @@ def make_input(cfg: str, shape=None, batch: int = 8) -> np.ndarray:
 
 def make_workload(cfg: str, x: np.ndarray, axis: int = 0) -> Workload:
     """Quantizer class + constructor arguments for a configuration, derived from its input."""
+    if cfg == "sym" and axis is None:    # ... or per tensor (bench.py --config sym --shape AxB --per-tensor)
+        return Workload("sym WeightsSymmetric per-tensor 8b", "WeightsSymmetricInferableQuantizer",
+                        dict(num_bits=8, threshold=[float(np.max(np.abs(x)))], per_channel=False), x.shape, 1100)
     if cfg == "sym":                     # WeightsSymmetric 8 bit per channel along ``axis`` of any shape
         axis = axis % x.ndim
         other = tuple(d for d in range(x.ndim) if d != axis)

@@ -77,6 +77,17 @@ e2e() {           # bench.py --config resnet50 --e2e at the final build
 import json; d=json.load(open('$O/bench_e2e_resnet50.json')); print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k in ('value', 'ms_per_step') or k.startswith('ms_')})" 2>/dev/null || head -c 600 $O/bench_e2e_resnet50.json
 }
 
+pacedlines() {    # per-tensor launches at the sizes the window was found on, under the judged protocol, key on / off
+  : > $O/bench_paced_pertensor.jsonl
+  for sd in "4096x4096 bf16" "4096x4096 f16" "3584x4096 bf16" "2048x4096 f32" "1792x4096 f32"; do
+    set -- $sd
+    for pv in 1 0; do
+      timeout 400 python bench.py --config sym --shape $1 --per-tensor --dtype $2 --paced $pv --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_paced_pertensor.jsonl
+    done
+  done
+  while read -r l; do echo "$l" | line bench_paced_pertensor; done < $O/bench_paced_pertensor.jsonl
+}
+
 abpaced() {       # the per-tensor window through the shipped library: paced 0 against 2 (every size through flat_paced_kernel)
   timeout 800 python tools/ab_probe.py --a shipped:paced=0 --b shipped:paced=2 --cases paced16,paced32 > $O/ab_paced.log 2>&1; grep -c "B/A" $O/ab_paced.log
 }
