@@ -561,6 +561,43 @@ def test_per_tensor_launches_of_one_round_take_the_paced_kernel_and_agree_with_t
         native.set_tuning("paced", 1)
 
 
+def test_fuzz_paced_per_tensor_launch_sizes_vs_oracle(lib):
+    """Seeded fuzz of flat_paced_kernel's geometry: element counts anywhere in and around the window (partial last tiles, n % N
+    trailing elements, a block more or less than a round), small tensors with the key forced (paced = 2), the three storage types,
+    signed / unsigned grids with and without a zero point -- bit for bit against the oracle.  MCTQ_FUZZ_SEED / MCTQ_FUZZ_CASES widen it."""
+    import os
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    rng = np.random.default_rng(int(os.environ.get("MCTQ_FUZZ_SEED", "707")))
+    rnd = 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    seen = set()
+    try:
+        for case in range(int(os.environ.get("MCTQ_FUZZ_CASES", "24"))):
+            dt = ["float32", "float16", "bfloat16"][case % 3]
+            code, tdt = {"float32": 0, "float16": 1, "bfloat16": 2}[dt], getattr(torch, dt)
+            tile = 1024 * (4 if dt == "float32" else 8)
+            forced = case % 4 == 3
+            if forced:                                            # any size with a full tile, the key forced
+                n = int(rng.integers(tile, 40 * tile)) if rng.random() < 0.5 else int(rng.integers(rnd * tile // 4, rnd * tile // 2))
+            else:
+                n = int(rng.integers(int(0.70 * rnd) * tile, int(1.04 * rnd) * tile))
+            native.set_tuning("paced", 2 if forced else 1)
+            qmin, qmax = [(-128, 127), (0, 255), (-8, 7), (0, 15)][int(rng.integers(0, 4))]
+            scale, zp = float(rng.uniform(0.01, 0.2)), int(rng.integers(-3, 4)) if rng.random() < 0.5 else 0
+            x32 = _tie_heavy_r6(rng, (n,), np.float32(scale), np.float32(zp), qmin, qmax)
+            xh = _dev(x32).to(tdt)
+            x_np = xh.float().cpu().numpy()
+            y = torch.full_like(xh, 300.0)
+            assert lib.mctq_fq_per_tensor(xh.data_ptr(), y.data_ptr(), n, code, scale, zp, qmin, qmax, _stream()) == 0, lib.mctq_last_error()
+            seen.add(native.last_launch().split("<")[0])
+            want = O.narrow(O.fake_quant_affine(x_np, np.float32([scale]), np.int32([zp]), qmin, qmax, axis=None), dt)
+            got = y.float().cpu().numpy()
+            assert finite_equal(got, want, x_np), (case, n, dt, forced, native.last_launch(), first_mismatch(got, want, x_np))
+    finally:
+        native.set_tuning("paced", 1)
+    assert "flat_paced_kernel" in seen, seen
+
+
 def test_fuzz_channel_last_and_short_row_launch_geometry_vs_oracle(lib):
     """Seeded fuzz of the round-6 launch geometry through the C ABI: random (outer, C, inner) with inner drawn around the
     lane-vector and tile sizes (1, below a vector, whole vectors, one past / one short of them, rows longer than a tile), C from 1
