@@ -485,7 +485,9 @@ int mctq_qlinear_w4a8(const void* a_codes, int32_t a_code_dtype, int32_t a_zero_
  *   key "paced" : the affine per-tensor launch through flat_paced_kernel (flat_kernel's tile under another order of waits: loads
  *                  128 clocks apart, every load landed before the first store, every store completed before the next lane-vector):
  *                  0 = never, 1 (default) = launches that fill 3/4 ... 1 round of resident blocks, where it measured 4-6 % faster
- *                  (48-64 MiB of traffic on this chip; 3-9 % slower outside), 2 = every launch with a full four-vector tile
+ *                  (48-64 MiB of traffic on this chip; 3-9 % slower outside), 2 = every launch with a full four-vector tile.
+ *                  The same key sends symmetric float32 per-channel launches of that window (whole-vector rows) through
+ *                  shortrows_kernel with paced stores: 2048 x 4096 12.4 -> 11.3 us, 32768 x 256 12.3 -> 11.3 (16-bit: not taken, +3 %)
  *   key "shortrows" : affine per-channel tensors through shortrows_kernel (per-lane parameter reads behind the tile's data loads,
  *                  no LDS window): 0 = never, 1 (default) = where it measured faster (16-bit storage: every short or ragged row
  *                  shape, and long rows of launches that fill 7/8 ... 1 round of resident blocks; float32: rows of 4 ... 31

@@ -11,6 +11,7 @@ int fq64_per_channel(const void* x, void* y, int64_t outer, int64_t channels, in
 int fq_gather_one_f32(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner, const float* scales,
                       const int32_t* zps, int32_t qmin, int32_t qmax, hipStream_t st);
 extern int g_shortrows;
+extern int g_paced;
 }
 
 extern "C" {
@@ -53,7 +54,9 @@ int mctq_fq_per_channel(const void* x, void* y, int64_t outer, int64_t channels,
     const int64_t innerv = inner / 4, tiles = (innerv + kThreads - 1) / kThreads;
     if ((tiles * kThreads - innerv) * 12 > tiles * kThreads) long_rows = false;      // > 1/12 of the row's lanes idle
   }
-  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !long_rows && g_shortrows != 2 &&
+  // (symmetric float32 launches of 3/4 ... 1 round with whole-vector rows: shortrows_kernel with paced stores, launch_channels)
+  const bool paced_window = g_paced == 1 && g_shortrows != 0 && !zero_points && paced_rows_window<float>(n, inner, channels);
+  if (dtype == MCTQ_DT_F32 && inner >= 32 && channels > 1 && !long_rows && g_shortrows != 2 && !paced_window &&
       (((uintptr_t)x | (uintptr_t)y) & 15u) == 0 && n < (1ll << 31) - 4096 && channels <= 0x7fffffffLL) {
     return fq_gather_one_f32(x, y, outer, channels, inner, scales, zero_points, quant_min, quant_max, (hipStream_t)stream);
   }

@@ -1092,10 +1092,9 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict
 // lies in one row or crosses exactly one row boundary.  No LDS window, no block barrier: after the tile's data loads every
 // lane reads its own row's scale (and, where vectors can cross, the next row's) from the L1 / L2-resident tables -- all
 // table reads issued back to back -- and inverts it with recip_exact (wave-uniform fallback to the IEEE division).
-// (Why it also beats the per-tensor kernel on the same bytes -- 11.75 vs 12.2 us for 64 MiB in 16-bit storage -- is NOT understood:
-// stores grouped at the end, a wait for all loads, a start staggered by wave slot and an explicit 3 + 1 load stagger -- which
-// is what the compiler happens to emit here -- were each tried on flat / rows kernels and bought nothing or cost 3-5 %:
-// profiles/EXPERIMENTS.md, round 6.)
+// (Why it also beat the per-tensor kernel on the same bytes -- 11.75 vs 12.2 us for 64 MiB in 16-bit storage -- was found at the
+// end of round 6: its waves wait for ALL their loads before the first store -- the scale reads sit behind the data loads -- and
+// some 200 instructions of row arithmetic lie between two stores; see flat_paced_kernel and the `paced` argument below.)
 // Measured against window_kernel (tools/experiments/chanlast2/, profiles/r06/chanlast2_a.log): bfloat16 16384 x 1020
 // 13.7 -> 12.5 us, 4096 x 4100 13.3 -> 12.3, 1048576 x 16 13.5 -> 13.0, float32 1048576 x 16 23.9 -> 22.1; whole-vector
 // 16-bit rows of 64 ... 2040 elements are equal or slower and stay with the window.  Reading the parameters BEFORE the data
@@ -1104,7 +1103,9 @@ __global__ __launch_bounds__(kThreads) void lastaxis_kernel(const TI* __restrict
 template <class TI, int U, int NT, bool ZP, bool WHOLE>
 __global__ __launch_bounds__(kThreads) void shortrows_kernel(const TI* __restrict__ xs, TI* __restrict__ ys, uint32_t n,
                                                              uint32_t inner, uint32_t channels, float r_inner, float r_channels,
-                                                             uint32_t shift /* log2(inner), or 32 */, AffineOp op) {
+                                                             uint32_t shift /* log2(inner), or 32 */,
+                                                             uint32_t paced /* launches of 3/4 ... 1 round: one store in flight per wave */,
+                                                             AffineOp op) {
   typedef IO<TI, TI> io;
   constexpr uint32_t N = io::N;
   constexpr uint32_t TILE = kThreads * U * N;
@@ -1172,6 +1173,11 @@ __global__ __launch_bounds__(kThreads) void shortrows_kernel(const TI* __restric
         for (uint32_t j = 0; j < N; ++j) out[j] = op.apply(in[j], j < split[u] ? pa : pb, NoBook());
       }
       io::template store<NT>(ys + e0 + off, io::pack(out));
+      // PACED (a kernel argument, wave-uniform): every store completed before the next lane-vector is touched.  The kernel waits for
+      // all its loads before the first reciprocal anyway (the scale reads are issued behind the data loads and return in order);
+      // with this, a launch whose blocks are all resident at once reads first and writes after (flat_paced_kernel's note):
+      // float32 2048 x 4096 12.4 -> 11.4 us, 8192 x 1024 12.4 -> 11.4, bfloat16 4096^2 11.7 -> 11.5 (profiles/r06/chanlast2_oneround.log)
+      if (paced && u + 1 < U) __builtin_amdgcn_s_waitcnt(0x0f70);
     } else {
       // the tensor's last, partial lane-vector: element by element
       uint32_t rem = inner - split[u], c = c0 + (shift < 32 ? (rem0 + off) >> shift : div_small(rem0 + off, inner, r_inner));
@@ -1322,7 +1328,8 @@ inline void note(const char* shape, int unroll, int nt) {
   ++g_note.count;
   if (g_launch_log) log_launch();
 }
-extern int g_paced;          // the per-tensor launch of 3/4 ... 1 round through flat_paced_kernel: 0 never, 1 (default) inside that window, 2 whenever there is a full tile
+extern int g_paced;          // launches of 3/4 ... 1 round under the paced order of waits (flat_paced_kernel per tensor; shortrows_kernel's
+                             // `paced` argument per channel): 0 never, 1 (default) inside that window, 2 whenever the kernel is taken
 extern int g_shortrows;      // rows shorter than a tile through shortrows_kernel: 0 never, 1 (default) where it measured faster, 2 whenever eligible
 extern int g_rowsteps;       // short whole-step rows: 0 rows_kernel, 1 rowsteps_kernel, 2 (default) rowsteps_kernel when its grid is one round
 extern int g_heavy_unroll;   // 0 = automatic
@@ -1406,6 +1413,17 @@ inline void launch_resolved(dim3 grid, dim3 block, size_t shmem, hipStream_t st,
   } while (0)
 
 // does the launch carry a zero-point table?  (affine ops: NULL = symmetric quantizers; everything else: not a question)
+// Whole-vector per-channel rows of a launch that fills 3/4 ... 1 round of shortrows_kernel's tiles (8 blocks of four waves per CU):
+// the window in which paced stores pay (flat_paced_kernel's note; tuning key "paced").
+template <class TI>
+static bool paced_rows_window(int64_t n, int64_t inner, int64_t channels) {
+  constexpr int64_t N = IO<TI, TI>::N, TILE = (int64_t)kThreads * 4 * N;
+  if (inner % N != 0 || inner < N || channels <= 1) return false;
+  if (n >= (1ll << 32) - TILE || inner + TILE >= (1 << 24) || channels + TILE >= (1 << 24)) return false;
+  const int64_t blocks = (n + TILE - 1) / TILE, round = 8LL * cu_count();
+  return blocks * 4 >= round * 3 && blocks <= round;
+}
+
 template <class Op>
 static bool has_zero_points(const Op& op) {
   if constexpr (std::is_base_of<AffineOp, Op>::value) return op.zps != nullptr;
@@ -1497,7 +1515,15 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
     // 4096 x 256 -8 %, 65536 x 16 -14 %.  A FORCED rowsteps_kernel -- tuning key "rowsteps" = 1 -- keeps its long rows.)
     const int64_t sr_blocks = (n + TILE - 1) / TILE, round = 8LL * cu_count();
     const bool one_round = sr_blocks <= round && sr_blocks * 8 > round * 7;
-    const bool rule = sizeof(TI) == 2 ? (!long_rows || (one_round && g_rowsteps != 1)) : (!long_rows && inner < 32);
+    // float32 rows of a symmetric launch inside the paced window come here too, long or short (rows_kernel / rowsteps_kernel / the
+    // gather launch 12.3-12.5 us, this kernel with paced stores 11.3-11.4: profiles/r06/chanlast2_oneround.log, ab_paced_rows.log)
+    // (float32 only: on the 16-bit instances the same flag costs 2-4 %, ab_paced_rows.log; rows of one to three whole steps --
+    // rowsteps_kernel's -- only from 7/8 of a round: 4096 x 2048 -3 %, 2048 x 3072 at 3/4 of a round +2 %)
+    const bool window = sizeof(TI) == 4 && paced_rows_window<TI>(n, inner, channels) && !op.zps;
+    const bool paced = sizeof(TI) == 4 && (g_paced == 2 || (g_paced == 1 && window));
+    const bool steps_row = long_rows && (inner / io::N) % kThreads == 0 && inner / io::N <= 3 * kThreads;
+    const bool f32_window = g_paced == 1 && window && (!long_rows || g_rowsteps != 1) && (!steps_row || sr_blocks * 8 > round * 7);
+    const bool rule = sizeof(TI) == 2 ? (!long_rows || (one_round && g_rowsteps != 1)) : ((!long_rows && inner < 32) || f32_window);
     if (eligible && (g_shortrows == 2 || (g_shortrows == 1 && rule))) {
       const bool whole = inner % io::N == 0;
       uint32_t shift = 32;
@@ -1506,7 +1532,7 @@ static int launch_channels(const Op& op, const void* xv, void* yv, int64_t outer
       const unsigned grid = (unsigned)((n + TILE - 1) / TILE);
 #define MCTQ_SHORTROWS(NT_, ZP_, W_)                                                                                   \
       hipLaunchKernelGGL((shortrows_kernel<TI, 4, NT_, ZP_, W_>), dim3(grid), dim3(kThreads), 0, st, x, y, (uint32_t)n,  \
-                         (uint32_t)inner, (uint32_t)channels, ri, rc, shift, op)
+                         (uint32_t)inner, (uint32_t)channels, ri, rc, shift, paced ? 1u : 0u, op)
       MCTQ_WITH_MODE(nt_mode(n * (int64_t)sizeof(TO)), {
         if (op.zps) { if (whole) MCTQ_SHORTROWS(NT, true, true); else MCTQ_SHORTROWS(NT, true, false); }
         else { if (whole) MCTQ_SHORTROWS(NT, false, true); else MCTQ_SHORTROWS(NT, false, false); }

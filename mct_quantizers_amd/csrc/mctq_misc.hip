@@ -17,7 +17,7 @@ int64_t g_cached_store_max_bytes = 32ll << 20;   // outputs that fit the aggrega
 int g_unroll = 4;
 int g_heavy_unroll = 0;
 int g_rowsteps = 2;           // 2: rowsteps_kernel only where it measured faster (see launch_channels)
-int g_paced = 1;              // per-tensor launches of 3/4 ... 1 round through flat_paced_kernel: 0 never, 1 inside the window, 2 whenever a full tile exists (launch_flat)
+int g_paced = 1;              // launches of 3/4 ... 1 round under the paced order of waits: 0 never, 1 inside the window, 2 whenever the kernel is taken (launch_flat, launch_channels)
 int g_shortrows = 1;          // short / ragged rows through shortrows_kernel: 0 never, 1 the measured rule, 2 whenever eligible (launch_channels)
 int g_ql_variant = 0;
 int g_ql_band = 0;

@@ -561,6 +561,45 @@ def test_per_tensor_launches_of_one_round_take_the_paced_kernel_and_agree_with_t
         native.set_tuning("paced", 1)
 
 
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+def test_per_channel_launches_of_one_round_take_the_short_row_kernel_with_paced_stores(lib, dt):
+    """Symmetric per-channel launches with whole-vector rows that fill 3/4 ... 1 round of shortrows_kernel's tiles run it with paced
+    stores; float32 ones are routed there (from rows_kernel / rowsteps_kernel / the gather launch).  Both edges of the window, long
+    and short rows, `paced` 0 / 1 / 2, a zero-point table (keeps the old route) -- every result against the oracle bit for bit."""
+    from mct_quantizers_amd.hip import native
+    from oracle import mctq_oracle as O
+    code, tdt = {"float32": 0, "bfloat16": 2}[dt], getattr(torch, dt)
+    N = 4 if dt == "float32" else 8
+    rnd = 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    rows_full = rnd * 1024 * N // 4096                              # rows of 4096 elements that make one round
+    shapes = [(rows_full, 4096, True), (rows_full * 3 // 4, 4096, True), (rows_full * 3 // 4 - 8, 4096, False), (rows_full + 8, 4096, False),
+              (rows_full * 4, 1024, True), (rows_full * 16, 256, True), (rows_full * 2, 2048, True)]
+    rng = np.random.default_rng(99)
+    try:
+        for C, inner, in_window in shapes:
+            scales = rng.uniform(0.01, 0.2, size=C).astype(np.float32)
+            x32 = _tie_heavy_r6(rng, (1, C, inner), scales.reshape(1, C, 1), np.float32(0), -128, 127)
+            xh = _dev(x32).to(tdt)
+            x_np = xh.float().cpu().numpy()
+            want = O.narrow(O.fake_quant_affine(x_np, scales, np.zeros(C, dtype=np.int32), -128, 127, axis=1), dt)
+            s_d, z_d = _dev(scales), _dev(np.zeros(C, dtype=np.int32))
+            names = {}
+            for mode, zp in ((1, None), (0, None), (1, z_d)):
+                native.set_tuning("paced", mode)
+                y = torch.full_like(xh, 300.0)
+                rc = lib.mctq_fq_per_channel(xh.data_ptr(), y.data_ptr(), 1, C, inner, code, s_d.data_ptr(), zp.data_ptr() if zp is not None else None,
+                                             -128, 127, _stream())
+                assert rc == 0, lib.mctq_last_error()
+                names[(mode, zp is not None)] = native.last_launch().split("<")[0]
+                got = y.float().cpu().numpy()
+                assert finite_equal(got, want, x_np), (C, inner, mode, native.last_launch(), first_mismatch(got, want, x_np))
+            if dt == "float32":       # routed into shortrows_kernel by the window only (the old routes otherwise, and with zero points)
+                assert (names[(1, False)] == "shortrows_kernel") == in_window, (C, inner, names)
+                assert names[(0, False)] != "shortrows_kernel" and names[(1, True)] != "shortrows_kernel", (C, inner, names)
+    finally:
+        native.set_tuning("paced", 1)
+
+
 def test_fuzz_paced_per_tensor_launch_sizes_vs_oracle(lib):
     """Seeded fuzz of flat_paced_kernel's geometry: element counts anywhere in and around the window (partial last tiles, n % N
     trailing elements, a block more or less than a round), small tensors with the key forced (paced = 2), the three storage types,

@@ -96,6 +96,10 @@ RAGGED = [("pc0", 16384, 1020), ("pc0", 4096, 4100), ("pc0", 4096, 4099), ("pc0"
           ("pc0", 131072, 100), ("pc0", 1048576, 12), ("pc0", 50257, 772), ("pc0", 300, 1020), ("pc0", 16384, 1024)]
 PACED16 = [("pt", r, 4096) for r in (2048, 2560, 2816, 3072, 3328, 3584, 3840, 4096, 4104, 4352, 4608, 8192)]     # 1/2 ... 2 rounds of 16-bit blocks
 PACED32 = [("pt", r, 4096) for r in (1024, 1280, 1408, 1536, 1664, 1792, 1920, 2048, 2052, 2304, 4096)]
+PACEDROWS32 = [("pc0", 2048, 4096), ("pc0", 1792, 4096), ("pc0", 1536, 4096), ("pc0", 4096, 2048), ("pc0", 2048, 3072), ("pc0", 8192, 1024), ("pc0", 32768, 256),
+               ("pc0", 131072, 64), ("pc0", 7168, 1024), ("pc0", 1024, 8192), ("pc0", 8192, 1020), ("pc0", 2056, 4096), ("pc0", 1408, 4096)]
+PACEDROWS16 = [("pc0", 4096, 4096), ("pc0", 16384, 1024), ("pc0", 65536, 256), ("pc0", 262144, 64), ("pc0", 14336, 1024), ("pc0", 12288, 1024),
+               ("pc0", 1048576, 16), ("pc0", 16384, 1020), ("pc0", 3584, 4096), ("pc0", 4104, 4096)]
 ROUNDS = [("pc0", 8192, 2048), ("pc0", 6144, 4096), ("pc0", 8192, 4096), ("pc0", 12288, 4096), ("pc0", 16384, 4096), ("pc0", 4096, 2048),
           ("pc0", 2048, 3072), ("pc0", 1024, 4096), ("pc0", 512, 4096)]
 
@@ -160,6 +164,8 @@ for c in args.cases.split(","):
     elif c == "affine32": affine_cases(["f32"])
     elif c == "tqp16": affine_cases(["bf16", "f16"], TQP)
     elif c == "tqp32": affine_cases(["f32"], TQP)
+    elif c == "pacedrows32": affine_cases(["f32"], PACEDROWS32)
+    elif c == "pacedrows16": affine_cases(["bf16", "f16"], PACEDROWS16)
     elif c == "paced16": affine_cases(["bf16", "f16"], PACED16)
     elif c == "paced32": affine_cases(["f32"], PACED32)
     elif c == "small16": affine_cases(["bf16"], SMALL)

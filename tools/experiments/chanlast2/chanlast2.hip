@@ -660,7 +660,10 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
   auto data_loads = [&]() {
     if (full) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs + e0) + u * kThreads + threadIdx.x);
+      for (int u = 0; u < U; ++u) {
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const VI*>(xs + e0) + u * kThreads + threadIdx.x);
+        if (ORDER == 4 && u + 1 < U) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(2); __builtin_amdgcn_sched_barrier(0); }   // loads 128 clocks apart
+      }
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
       }
     }
   };
-  if (ORDER == 0 || ORDER == 2 || ORDER == 3) { data_loads(); __builtin_amdgcn_sched_barrier(0); }
+  if (ORDER == 0 || ORDER == 2 || ORDER == 3 || ORDER == 4) { data_loads(); __builtin_amdgcn_sched_barrier(0); }
 
   uint32_t ca[U], cb[U], split[U];
   float sa[U], sb[U], za[U], zb[U];
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u) { ia[u] = 1.0f / sa[u]; if (!SAMEROW) ib[u] = 1.0f / sb[u]; }
   }
-  if (ORDER == 3) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }
+  if (ORDER == 3 || ORDER == 4) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t off = (u * kThreads + threadIdx.x) * N;
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void shortrows_x_kernel(const TI* __restr
         }
       }
       io::template store<NT>(ys + e0 + off, io::pack(out));
-      if ((ORDER == 2 || ORDER == 3) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // PACED: vmcnt(0)
+      if ((ORDER == 2 || ORDER == 3 || ORDER == 4) && u + 1 < U) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_sched_barrier(0); }   // PACED: vmcnt(0)
     } else {
       // the tensor's last, partial lane-vector: element by element
       AffineOp op; op.scales = scales; op.zps = zps; op.lo = lo; op.hi = hi;
@@ -772,6 +775,7 @@ static int launch_shortrows(int mode, const void* xv, void* yv, int64_t rows, in
     case 4: BY_NT(BY_Z(0, BY_S(SR(NT, 1, 1, Z, S)))); break;      // parameters first, fast reciprocal
     case 5: BY_NT(BY_Z(0, BY_S(SR(NT, 2, 1, Z, S)))); break;      // data first, fast reciprocal, paced stores
     case 6: BY_NT(BY_Z(0, BY_S(SR(NT, 3, 1, Z, S)))); break;      // data first, fast reciprocal, all loads landed first, paced stores
+    case 7: BY_NT(BY_Z(0, BY_S(SR(NT, 4, 1, Z, S)))); break;      // the three ingredients of flat_paced_kernel: loads apart, all landed first, paced stores
     default: return fail_arg("mode");
   }
   return check_launch("shortrows");

@@ -25,6 +25,8 @@ DT = {"f32": (torch.float32, 0, 4), "f16": (torch.float16, 1, 2), "bf16": (torch
 what = set(sys.argv[1:]) or {"recip", "lastaxis", "shortrows"}
 if "sched" in what or "contig" in what or "lds" in what or "bisect" in what or "paced" in what:
     what.add("lastaxis")
+if "oneround" in what:
+    what.add("shortrows")
 
 
 def timed(call, pre=0.5, n=200):
@@ -162,6 +164,10 @@ if "shortrows" in what:
              ("bf16", 65536, 256, False), ("bf16", 262144, 64, False), ("bf16", 4096, 4100, False), ("bf16", 4096, 4099, False),
              ("f16", 1048576, 16, False), ("f32", 1048576, 16, False), ("f32", 16384, 1020, False), ("f32", 262144, 64, False),
              ("f32", 4096, 4100, False), ("bf16", 50257, 768, False)]
+    if "oneround" in what:              # per-channel launches of 3/4 ... 1 round of resident blocks (the window of flat_paced_kernel)
+        cases = [("bf16", 4096, 4096, False), ("f16", 4096, 4096, False), ("bf16", 3584, 4096, False), ("bf16", 16384, 1024, False),
+                 ("bf16", 65536, 256, False), ("f32", 2048, 4096, False), ("f32", 4096, 2048, False), ("f32", 8192, 1024, False),
+                 ("f32", 1792, 4096, False), ("f32", 32768, 256, False)]
     for dt_name, rows, inner, with_zp in cases:
         tdt, dtc, nb, ring, xs, s, z, nt = setup(dt_name, rows, inner, rows, with_zp)
         zp = z.data_ptr() if z is not None else None
@@ -173,7 +179,7 @@ if "shortrows" in what:
         def mk(mode):
             return lambda i, ys: xlib.mctq_x_shortrows(mode, xs[i % ring].data_ptr(), ys[i % ring].data_ptr(), rows, inner, rows, dtc,
                                                        s.data_ptr(), zp, -128, 127, nt, stream)
-        modes = [("d/ieee", mk(1), True), ("d/rcp", mk(2), True), ("p/ieee", mk(3), True), ("p/rcp", mk(4), True), ("d/rcp paced", mk(5), True), ("d/rcp wait+paced", mk(6), True)]
+        modes = [("d/ieee", mk(1), True), ("d/rcp", mk(2), True), ("p/ieee", mk(3), True), ("p/rcp", mk(4), True), ("d/rcp paced", mk(5), True), ("d/rcp wait+paced", mk(6), True), ("d/rcp apart+wait+paced", mk(7), True)]
         run_case(f"{dt_name} {rows}x{inner}" + (" zp" if with_zp else ""), nb, ring, xs, lib_call, modes)
         del xs
         torch.cuda.empty_cache()

@@ -36,6 +36,7 @@ run_cfg cfg3_n50_eager --config cfg3 --batch 50 --stream-depth -1
 run_cfg cfg3_n100_eager_bf16 --config cfg3 --batch 100 --dtype bf16 --stream-depth -1
 run_cfg sym_4096x4096_pertensor_bf16 --config sym --shape 4096x4096 --per-tensor --dtype bf16
 run_cfg sym_2048x4096_pertensor --config sym --shape 2048x4096 --per-tensor
+run_cfg sym_2048x4096_axis0 --config sym --shape 2048x4096 --axis 0
 run_cfg cfg4 --config cfg4 --steps 300
 run_cfg cfg5 --config cfg5 --steps 300
 # 16-bit storage: the headline shape and config 5 as bfloat16, config 4 (LUT: 2 B in, 4 B out)
@@ -78,4 +79,4 @@ stall_passes sym_65536x200_axis1_bf16 --config sym --shape 65536x200 --axis 1 --
 stall_passes sym_16384x1020_axis0_bf16 --config sym --shape 16384x1020 --axis 0 --dtype bf16
 stall_passes sym_1048576x16_axis0_bf16 --config sym --shape 1048576x16 --axis 0 --dtype bf16
 ls -la $R/gpurun_out/pmc/*; wc -l $R/gpurun_out/pmc/available_counters.txt
-for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg3_n50_eager cfg3_n100_eager_bf16 sym_4096x4096_pertensor_bf16 sym_2048x4096_pertensor cfg4 cfg5 cfg2_bf16 cfg2_f16 cfg5_bf16 cfg4_bf16 sym_4096x4096_axis1_bf16 sym_65536x200_axis1_bf16 sym_16384x1020_axis0_bf16 sym_1048576x16_axis0_bf16 sym_16384x1024_axis0_bf16 sym_64x56x56x256_axis3_bf16 sym_4096x4096_axis1; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done
+for c in cfg2 cfg2_batched16 resnet50 cfg3_n64 cfg3_n64_eager cfg3_n8 cfg3_n50_eager cfg3_n100_eager_bf16 sym_4096x4096_pertensor_bf16 sym_2048x4096_pertensor sym_2048x4096_axis0 cfg4 cfg5 cfg2_bf16 cfg2_f16 cfg5_bf16 cfg4_bf16 sym_4096x4096_axis1_bf16 sym_65536x200_axis1_bf16 sym_16384x1020_axis0_bf16 sym_1048576x16_axis0_bf16 sym_16384x1024_axis0_bf16 sym_64x56x56x256_axis3_bf16 sym_4096x4096_axis1; do head -2 $R/gpurun_out/pmc/$c/kernel_stats.csv | cut -c1-260; tail -1 $R/gpurun_out/pmc/$c/bench_stats.log | cut -c1-200; done

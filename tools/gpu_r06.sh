@@ -86,6 +86,18 @@ pacedlines() {    # per-tensor launches at the sizes the window was found on, un
     done
   done
   while read -r l; do echo "$l" | line bench_paced_pertensor; done < $O/bench_paced_pertensor.jsonl
+  # ... and symmetric float32 per-channel launches of the window (shortrows_kernel with paced stores against the old routes)
+  : > $O/bench_paced_rows.jsonl
+  for sh in 2048x4096 8192x1024 32768x256; do
+    for pv in 1 0; do
+      timeout 400 python bench.py --config sym --shape $sh --axis 0 --paced $pv --no-sharded-extra 2>/dev/null | tail -1 >> $O/bench_paced_rows.jsonl
+    done
+  done
+  while read -r l; do echo "$l" | line bench_paced_rows; done < $O/bench_paced_rows.jsonl
+}
+
+abrows() {        # per-channel launches of the window through the shipped library, key off against on
+  timeout 500 python tools/ab_probe.py --a shipped:paced=0 --b shipped --cases pacedrows32,pacedrows16 > $O/ab_paced_rows.log 2>&1; grep -c "B/A" $O/ab_paced_rows.log
 }
 
 abpaced() {       # the per-tensor window through the shipped library: paced 0 against 2 (every size through flat_paced_kernel)
